@@ -1,0 +1,91 @@
+"""ctypes binding of ``libsm3det_hip.so`` (the C ABI declared in ``include/sm3det_hip.h``).
+
+PyTorch is used here only as plumbing: device memory (``Tensor.data_ptr()``), the current HIP stream and
+(elsewhere) ``torch.distributed``.  There is NO fallback: if the shared library is missing or a symbol cannot be
+resolved, importing an operator fails loudly -- a product path must never silently run on eager PyTorch or on
+the CPU oracle.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libsm3det_hip.so')
+
+c_void_p, c_int, c_float, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+
+
+class SM3Error(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def _declare(lib):
+    P, I, F, S = c_void_p, c_int, c_float, c_size_t
+    sig = {
+        'sm3_version': (ctypes.c_char_p, []),
+        'sm3_compiler_version': (ctypes.c_char_p, []),
+        'sm3_error_string': (ctypes.c_char_p, [I]),
+        'sm3_box_iou_rotated': (I, [P, P, P, I, I, I, I, P]),
+        'sm3_argsort_desc_workspace_bytes': (S, [I]),
+        'sm3_argsort_desc_f32': (I, [P, I, P, P, S, P]),
+        'sm3_nms_workspace_bytes': (S, [I]),
+        'sm3_nms': (I, [P, P, P, I, F, I, P, P, P, S, P]),
+        'sm3_nms_rotated_workspace_bytes': (S, [I]),
+        'sm3_nms_rotated': (I, [P, I, P, P, I, F, I, P, P, P, S, P]),
+        'sm3_roi_align_rotated_forward': (I, [P, P, P, I, I, I, I, I, I, I, F, I, I, I, I, P]),
+        'sm3_roi_align_rotated_backward': (I, [P, P, P, I, I, I, I, I, I, I, F, I, I, I, I, P]),
+    }
+    from . import _lib_backbone
+    sig.update(_lib_backbone.signatures())
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)  # AttributeError => the .so is stale: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    return sig
+
+
+EXPORTED = None
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Raises if the extension was not built."""
+    global _lib, EXPORTED
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SM3Error(f'{LIB_PATH} not found: run `python -m sm3det_amd.build` '
+                           '(hipcc --offload-arch=gfx950); there is no CPU/eager fallback')
+        handle = ctypes.CDLL(LIB_PATH)
+        EXPORTED = _declare(handle)
+        _lib = handle
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        raise SM3Error(f'{what}: {lib().sm3_error_string(code).decode()} (code {code})')
+
+
+def stream_ptr():
+    """Raw hipStream_t of torch's current stream on the current device."""
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    if t is None:
+        return c_void_p(0)
+    return c_void_p(t.data_ptr())
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise SM3Error('sm3det_amd operators run on the MI355X only: got a CPU tensor '
+                           '(there is deliberately no CPU fallback in the product path)')
+
+
+def workspace(nbytes, device):
+    return torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)

@@ -1,0 +1,64 @@
+"""Build libsm3det_hip.so in-tree for gfx950 (hipcc cross-compiles without a GPU).
+
+    python -m sm3det_amd.build [-f] [-v]
+
+One object per ``csrc/*.hip`` (rebuilt only when the source or a header is newer), linked into
+``sm3det_amd/csrc/libsm3det_hip.so``.  The .so is git-ignored but travels to the GPU box with the snapshot.
+"""
+import glob
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIB = os.path.join(CSRC, 'libsm3det_hip.so')
+ARCH = 'gfx950'
+
+BASE_FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
+# Per-file flags.  The detection ops must round exactly like the reference's scalar CPU code (bit-exact NMS),
+# so no FMA contraction there; the backbone kernels keep the default (-ffp-contract=fast-honor-pragmas).
+FILE_FLAGS = {
+    'ops_rotated.hip': ['-ffp-contract=off'],
+    'deform_conv.hip': ['-ffp-contract=off'],
+}
+
+
+def _hipcc():
+    for c in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError('hipcc not found')
+
+
+def build(force=False, verbose=False):
+    srcs = sorted(glob.glob(os.path.join(CSRC, '*.hip')))
+    hdrs = glob.glob(os.path.join(CSRC, '*.h')) + glob.glob(os.path.join(HERE, '..', 'include', '*.h'))
+    hdr_m = max([os.path.getmtime(h) for h in hdrs] + [os.path.getmtime(__file__)])
+    objs, rebuilt = [], False
+    procs = []
+    for s in srcs:
+        o = s[:-4] + '.o'
+        objs.append(o)
+        if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hdr_m):
+            cmd = [_hipcc()] + BASE_FLAGS + FILE_FLAGS.get(os.path.basename(s), []) + ['-c', s, '-o', o]
+            if verbose:
+                print(' '.join(cmd), flush=True)
+            procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+            rebuilt = True
+    for s, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f'hipcc failed on {s}:\n{out.decode()}')
+        if verbose and out:
+            print(out.decode())
+    if rebuilt or not os.path.exists(LIB):
+        cmd = [_hipcc(), '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', LIB] + objs
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='-f' in sys.argv, verbose='-v' in sys.argv))

@@ -1,0 +1,830 @@
+// ops_rotated.hip -- rotated-detection operators for gfx950 (MI355X), wave64.
+//
+//   sm3_box_iou_rotated, sm3_nms, sm3_nms_rotated, sm3_argsort_desc_f32,
+//   sm3_roi_align_rotated_{forward,backward}
+//
+// Built with -ffp-contract=off: the parity target is the reference's CPU path (baseline x86-64, no FMA),
+// and NMS keep-lists must be bit-exact, so every float op here rounds exactly like the scalar C++ does.
+// Semantics follow (paths relative to /root/reference/mmcv/mmcv/ops/csrc):
+//   common/box_iou_rotated_utils.hpp, pytorch/cpu/{box_iou_rotated,nms_rotated,nms,roi_align_rotated}.cpp
+// The structure is NOT the reference's CUDA: 64x64 suppression tiles are one wavefront each, bitmasks are
+// built with 64-bit ballots-free per-lane words, and the greedy sweep runs on the device (no D2H of the mask).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/sm3det_hip.h"
+#include "common.h"
+
+namespace {
+
+struct Pt {
+  float x, y;
+};
+__device__ __forceinline__ float dot2(Pt a, Pt b) { return a.x * b.x + a.y * b.y; }
+__device__ __forceinline__ float cross2(Pt a, Pt b) { return a.x * b.y - b.x * a.y; }
+__device__ __forceinline__ Pt psub(Pt a, Pt b) { return Pt{a.x - b.x, a.y - b.y}; }
+
+// box_iou_rotated_utils.hpp:56-75
+__device__ __forceinline__ void rotated_vertices(float xc, float yc, float w, float h, float a, Pt* p) {
+  double theta = a;
+  float c2 = (float)cos(theta) * 0.5f;
+  float s2 = (float)sin(theta) * 0.5f;
+  p[0].x = xc - s2 * h - c2 * w;
+  p[0].y = yc + c2 * h - s2 * w;
+  p[1].x = xc + s2 * h - c2 * w;
+  p[1].y = yc - c2 * h - s2 * w;
+  p[2].x = 2 * xc - p[0].x;
+  p[2].y = 2 * yc - p[0].y;
+  p[3].x = 2 * xc - p[1].x;
+  p[3].y = 2 * yc - p[1].y;
+}
+
+// box_iou_rotated_utils.hpp:214-222 (CPU comparator; 1e-6 tie band, not a strict weak order)
+__device__ __forceinline__ bool hull_less(Pt A, Pt B) {
+  float t = cross2(A, B);
+  if (fabs((double)t) < 1e-6) return dot2(A, A) < dot2(B, B);
+  return t > 0;
+}
+
+__device__ __forceinline__ void ins_unguarded(Pt* i) {  // libstdc++ __unguarded_linear_insert
+  Pt val = *i;
+  Pt* next = i - 1;
+  while (hull_less(val, *next)) {
+    *i = *next;
+    i = next;
+    --next;
+  }
+  *i = val;
+}
+__device__ __forceinline__ void ins_sort(Pt* first, Pt* last) {  // libstdc++ __insertion_sort
+  if (first == last) return;
+  for (Pt* i = first + 1; i != last; ++i) {
+    if (hull_less(*i, *first)) {
+      Pt val = *i;
+      for (Pt* j = i; j != first; --j) *j = *(j - 1);
+      *first = val;
+    } else {
+      ins_unguarded(i);
+    }
+  }
+}
+__device__ __forceinline__ void pswap(Pt* a, Pt* b) {
+  Pt t = *a;
+  *a = *b;
+  *b = t;
+}
+// libstdc++ std::sort (introsort, threshold 16, then final insertion sort) -- the CPU reference sorts the
+// hull candidates with it (utils.hpp:213); because the comparator is not a strict weak order the algorithm
+// itself must be reproduced for bit-exact areas.  n <= 23 here, so the depth limit is never reached.
+__device__ void gcc_std_sort(Pt* first, Pt* last) {
+  if (last - first > 16) {
+    Pt* stack_lo[8];
+    Pt* stack_hi[8];
+    int sp = 0;
+    Pt* lo = first;
+    Pt* hi = last;
+    for (;;) {
+      while (hi - lo > 16) {
+        Pt* mid = lo + (hi - lo) / 2;
+        Pt *a = lo + 1, *b = mid, *c = hi - 1;
+        if (hull_less(*a, *b)) {
+          if (hull_less(*b, *c)) pswap(lo, b);
+          else if (hull_less(*a, *c)) pswap(lo, c);
+          else pswap(lo, a);
+        } else if (hull_less(*a, *c)) pswap(lo, a);
+        else if (hull_less(*b, *c)) pswap(lo, c);
+        else pswap(lo, b);
+        Pt* f = lo + 1;
+        Pt* l = hi;
+        for (;;) {
+          while (hull_less(*f, *lo)) ++f;
+          --l;
+          while (hull_less(*lo, *l)) --l;
+          if (!(f < l)) break;
+          pswap(f, l);
+          ++f;
+        }
+        stack_lo[sp] = lo;
+        stack_hi[sp] = f;
+        sp++;
+        lo = f;
+      }
+      if (sp == 0) break;
+      sp--;
+      lo = stack_lo[sp];
+      hi = stack_hi[sp];
+    }
+    ins_sort(first, first + 16);
+    for (Pt* i = first + 16; i != last; ++i) ins_unguarded(i);
+  } else {
+    ins_sort(first, last);
+  }
+}
+
+// single_box_iou_rotated<float>, box_iou_rotated_utils.hpp:344-378 with
+// get_intersection_points :77-155, convex_hull_graham (CPU branch) :157-272, polygon_area :285-297.
+__device__ float single_box_iou_rotated(const float* __restrict__ b1, const float* __restrict__ b2,
+                                        int mode_flag) {
+  double csx = (b1[0] + b2[0]) / 2.0;
+  double csy = (b1[1] + b2[1]) / 2.0;
+  float x1 = b1[0] - csx, y1 = b1[1] - csy, w1 = b1[2], h1 = b1[3], a1 = b1[4];
+  float x2 = b2[0] - csx, y2 = b2[1] - csy, w2 = b2[2], h2 = b2[3], a2 = b2[4];
+  const float area1 = w1 * h1;
+  const float area2 = w2 * h2;
+  if ((double)area1 < 1e-14 || (double)area2 < 1e-14) return 0.f;
+
+  Pt p1[4], p2[4], v1[4], v2[4];
+  rotated_vertices(x1, y1, w1, h1, a1, p1);
+  rotated_vertices(x2, y2, w2, h2, a2, p2);
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    v1[i] = psub(p1[(i + 1) & 3], p1[i]);
+    v2[i] = psub(p2[(i + 1) & 3], p2[i]);
+  }
+  Pt pts[24], q[24];
+  int num = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      float det = cross2(v2[j], v1[i]);
+      if (fabs((double)det) <= 1e-14) continue;
+      Pt v12 = psub(p2[j], p1[i]);
+      float t1 = cross2(v2[j], v12) / det;
+      float t2 = cross2(v1[i], v12) / det;
+      if (t1 >= 0.0f && t1 <= 1.0f && t2 >= 0.0f && t2 <= 1.0f) {
+        pts[num].x = p1[i].x + v1[i].x * t1;
+        pts[num].y = p1[i].y + v1[i].y * t1;
+        num++;
+      }
+    }
+  }
+  {
+    Pt AB = v2[0], DA = v2[3];
+    float ABdotAB = dot2(AB, AB), ADdotAD = dot2(DA, DA);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      Pt AP = psub(p1[i], p2[0]);
+      float APdotAB = dot2(AP, AB);
+      float APdotAD = -dot2(AP, DA);
+      if ((APdotAB >= 0) && (APdotAD >= 0) && (APdotAB <= ABdotAB) && (APdotAD <= ADdotAD))
+        pts[num++] = p1[i];
+    }
+  }
+  {
+    Pt AB = v1[0], DA = v1[3];
+    float ABdotAB = dot2(AB, AB), ADdotAD = dot2(DA, DA);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      Pt AP = psub(p2[i], p1[0]);
+      float APdotAB = dot2(AP, AB);
+      float APdotAD = -dot2(AP, DA);
+      if ((APdotAB >= 0) && (APdotAD >= 0) && (APdotAB <= ABdotAB) && (APdotAD <= ADdotAD))
+        pts[num++] = p2[i];
+    }
+  }
+  float intersection = 0.f;
+  if (num > 2) {
+    // convex hull (Graham scan), shift_to_zero = true
+    int t = 0;
+    for (int i = 1; i < num; i++)
+      if (pts[i].y < pts[t].y || (pts[i].y == pts[t].y && pts[i].x < pts[t].x)) t = i;
+    Pt start = pts[t];
+    for (int i = 0; i < num; i++) q[i] = psub(pts[i], start);
+    Pt tmp = q[0];
+    q[0] = q[t];
+    q[t] = tmp;
+    gcc_std_sort(q + 1, q + num);
+    int k;
+    for (k = 1; k < num; k++)
+      if ((double)dot2(q[k], q[k]) > 1e-8) break;
+    int m;
+    if (k == num) {
+      m = 1;
+    } else {
+      q[1] = q[k];
+      m = 2;
+      for (int i = k + 1; i < num; i++) {
+        while (m > 1 && cross2(psub(q[i], q[m - 2]), psub(q[m - 1], q[m - 2])) >= 0) m--;
+        q[m++] = q[i];
+      }
+    }
+    if (m > 2) {
+      float area = 0.f;
+      for (int i = 1; i < m - 1; i++) area += fabsf(cross2(psub(q[i], q[0]), psub(q[i + 1], q[0])));
+      intersection = area / 2.0f;
+    }
+  }
+  float baseS = 1.0f;
+  if (mode_flag == 0) baseS = (area1 + area2 - intersection);
+  else if (mode_flag == 1) baseS = area1;
+  return intersection / baseS;
+}
+
+// ---------------------------------------------------------------- box_iou_rotated
+__global__ __launch_bounds__(256) void box_iou_rotated_kernel(const float* __restrict__ boxes1,
+                                                              const float* __restrict__ boxes2,
+                                                              float* __restrict__ ious, int n1, int n2,
+                                                              int mode_flag, int aligned) {
+  const long total = aligned ? (long)n1 : (long)n1 * n2;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long)gridDim.x * blockDim.x) {
+    long i, j;
+    if (aligned) {
+      i = idx;
+      j = idx;
+    } else {
+      i = idx / n2;
+      j = idx - i * n2;
+    }
+    ious[idx] = single_box_iou_rotated(boxes1 + 5 * i, boxes2 + 5 * j, mode_flag);
+  }
+}
+
+// ---------------------------------------------------------------- argsort (bitonic on 64-bit keys)
+// key = (~orderable(score)) << 32 | index  -> ascending key order == descending score, ties by index.
+__device__ __forceinline__ uint32_t orderable(float f) {
+  uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__global__ void sort_init_kernel(const float* __restrict__ scores, int n, int npad, uint64_t* __restrict__ keys) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npad) return;
+  keys[i] = (i < n) ? (((uint64_t)(~orderable(scores[i]))) << 32) | (uint32_t)i : ~0ull;
+}
+constexpr int SORT_CHUNK = 4096;  // elements per workgroup in LDS (32 KiB of keys), 1024 threads
+// Runs every (k, j) stage with j < SORT_CHUNK for k in [k_lo, k_hi] on one chunk held in LDS.
+__global__ __launch_bounds__(1024) void sort_lds_kernel(uint64_t* __restrict__ keys, int npad, int k_lo, int k_hi) {
+  __shared__ uint64_t s[SORT_CHUNK];
+  const int base = blockIdx.x * SORT_CHUNK;
+  const int cnt = min(SORT_CHUNK, npad - base);  // npad is a power of two: cnt == SORT_CHUNK or npad
+  for (int i = threadIdx.x; i < cnt; i += blockDim.x) s[i] = keys[base + i];
+  __syncthreads();
+  for (int k = k_lo; k <= k_hi; k <<= 1) {
+    int jstart = min(k >> 1, SORT_CHUNK >> 1);
+    for (int j = jstart; j > 0; j >>= 1) {
+      for (int t = threadIdx.x; t < (cnt >> 1); t += blockDim.x) {
+        int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));  // lower index of the pair
+        int p = i | j;
+        bool up = (((base + i) & k) == 0);
+        uint64_t a = s[i], b = s[p];
+        if ((a > b) == up) {
+          s[i] = b;
+          s[p] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = threadIdx.x; i < cnt; i += blockDim.x) keys[base + i] = s[i];
+}
+__global__ void sort_global_step_kernel(uint64_t* __restrict__ keys, int npad, int k, int j) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (npad >> 1)) return;
+  int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+  int p = i | j;
+  bool up = ((i & k) == 0);
+  uint64_t a = keys[i], b = keys[p];
+  if ((a > b) == up) {
+    keys[i] = b;
+    keys[p] = a;
+  }
+}
+__global__ void sort_emit_kernel(const uint64_t* __restrict__ keys, int n, int64_t* __restrict__ order) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) order[i] = (int64_t)(uint32_t)(keys[i] & 0xffffffffu);
+}
+
+inline int next_pow2(int n) {
+  int p = 1;
+  while (p < n) p <<= 1;
+  return p;
+}
+
+int argsort_desc(const float* scores, int n, int64_t* order, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (n <= 0) return SM3_OK;
+  const int npad = next_pow2(n);
+  if (ws_bytes < (size_t)npad * 8) return SM3_ERR_WORKSPACE;
+  uint64_t* keys = (uint64_t*)ws;
+  sort_init_kernel<<<(npad + 255) / 256, 256, 0, st>>>(scores, n, npad, keys);
+  const int nchunk = (npad + SORT_CHUNK - 1) / SORT_CHUNK;
+  // all stages with k <= SORT_CHUNK are chunk-local
+  sort_lds_kernel<<<nchunk, 1024, 0, st>>>(keys, npad, 2, min(npad, SORT_CHUNK));
+  for (int k = SORT_CHUNK << 1; k <= npad; k <<= 1) {
+    for (int j = k >> 1; j >= SORT_CHUNK; j >>= 1)
+      sort_global_step_kernel<<<((npad >> 1) + 255) / 256, 256, 0, st>>>(keys, npad, k, j);
+    sort_lds_kernel<<<nchunk, 1024, 0, st>>>(keys, npad, k, k);
+  }
+  sort_emit_kernel<<<(n + 255) / 256, 256, 0, st>>>(keys, n, order);
+  return SM3_OK;
+}
+
+// ---------------------------------------------------------------- NMS (shared structure)
+// Stage 1: suppression bit-matrix over the score-sorted boxes. Tile = 64 rows x 64 cols = ONE wavefront:
+//   lane r owns sorted box rb*64+r and builds its 64-bit word against the 64 column boxes staged in LDS.
+//   Only tiles with cb >= rb are launched (triangular grid); within the diagonal tile only bits c > r are set.
+// Stage 2: greedy sweep on the device, one workgroup; per 64-box block wave 0 resolves the intra-block
+//   dependencies from the diagonal words, then all threads OR the kept rows into the removal vector.
+__device__ __forceinline__ void tri_decode(int t, int nblk, int& rb, int& cb) {
+  // t enumerates pairs (rb <= cb) row-major: rows have nblk, nblk-1, ... entries
+  int r = 0;
+  int rem = t;
+  // closed form via float sqrt then fix-up
+  float fn = (float)nblk;
+  r = (int)floorf(((2.f * fn + 1.f) - sqrtf((2.f * fn + 1.f) * (2.f * fn + 1.f) - 8.f * (float)t)) * 0.5f);
+  if (r < 0) r = 0;
+  if (r > nblk - 1) r = nblk - 1;
+  while (r > 0 && (long)r * nblk - (long)r * (r - 1) / 2 > t) r--;
+  while ((long)(r + 1) * nblk - (long)(r + 1) * r / 2 <= t) r++;
+  rem = t - (int)((long)r * nblk - (long)r * (r - 1) / 2);
+  rb = r;
+  cb = r + rem;
+}
+
+__global__ __launch_bounds__(64) void nms_rotated_mask_kernel(const float* __restrict__ dets, int stride,
+                                                             const int64_t* __restrict__ order, int n,
+                                                             int nblk, float thr, int multi_label,
+                                                             uint64_t* __restrict__ mask) {
+  int rb, cb;
+  tri_decode(blockIdx.x, nblk, rb, cb);
+  __shared__ float cbox[64 * 6];
+  const int lane = threadIdx.x;
+  const int ci = cb * 64 + lane;
+  if (ci < n) {
+    const float* d = dets + order[ci] * (int64_t)stride;
+#pragma unroll
+    for (int k = 0; k < 5; k++) cbox[lane * 6 + k] = d[k];
+    cbox[lane * 6 + 5] = multi_label ? d[5] : 0.f;
+  }
+  __syncthreads();
+  const int ri = rb * 64 + lane;
+  if (ri >= n) return;
+  float rbox[6];
+  {
+    const float* d = dets + order[ri] * (int64_t)stride;
+#pragma unroll
+    for (int k = 0; k < 5; k++) rbox[k] = d[k];
+    rbox[5] = multi_label ? d[5] : 0.f;
+  }
+  const int ncol = min(64, n - cb * 64);
+  uint64_t word = 0;
+  const int cstart = (rb == cb) ? lane + 1 : 0;
+  for (int c = cstart; c < ncol; c++) {
+    if (multi_label && cbox[c * 6 + 5] != rbox[5]) continue;
+    // row box is the higher-scoring one: reference calls iou(dets[i], dets[j]) with i kept, j candidate
+    float iou = single_box_iou_rotated(rbox, &cbox[c * 6], 0);
+    if (iou >= thr) word |= (1ull << c);  // cpu/nms_rotated.cpp:51 uses >=
+  }
+  mask[(size_t)ri * nblk + cb] = word;
+}
+
+__global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ boxes,
+                                                     const int64_t* __restrict__ order, int n, int nblk,
+                                                     float thr, float offset, uint64_t* __restrict__ mask) {
+  int rb, cb;
+  tri_decode(blockIdx.x, nblk, rb, cb);
+  __shared__ float cbox[64 * 5];
+  const int lane = threadIdx.x;
+  const int ci = cb * 64 + lane;
+  if (ci < n) {
+    const float* d = boxes + order[ci] * 4;
+    float x1 = d[0], y1 = d[1], x2 = d[2], y2 = d[3];
+    cbox[lane * 5 + 0] = x1;
+    cbox[lane * 5 + 1] = y1;
+    cbox[lane * 5 + 2] = x2;
+    cbox[lane * 5 + 3] = y2;
+    cbox[lane * 5 + 4] = (x2 - x1 + offset) * (y2 - y1 + offset);  // cpu/nms.cpp:14
+  }
+  __syncthreads();
+  const int ri = rb * 64 + lane;
+  if (ri >= n) return;
+  const float* d = boxes + order[ri] * 4;
+  const float ix1 = d[0], iy1 = d[1], ix2 = d[2], iy2 = d[3];
+  const float iarea = (ix2 - ix1 + offset) * (iy2 - iy1 + offset);
+  const int ncol = min(64, n - cb * 64);
+  uint64_t word = 0;
+  const int cstart = (rb == cb) ? lane + 1 : 0;
+  for (int c = cstart; c < ncol; c++) {
+    float xx1 = fmaxf(ix1, cbox[c * 5 + 0]);
+    float yy1 = fmaxf(iy1, cbox[c * 5 + 1]);
+    float xx2 = fminf(ix2, cbox[c * 5 + 2]);
+    float yy2 = fminf(iy2, cbox[c * 5 + 3]);
+    float w = fmaxf(0.f, xx2 - xx1 + offset);
+    float h = fmaxf(0.f, yy2 - yy1 + offset);
+    float inter = w * h;
+    float ovr = inter / (iarea + cbox[c * 5 + 4] - inter);  // division form, cpu/nms.cpp:46
+    if (ovr > thr) word |= (1ull << c);
+  }
+  mask[(size_t)ri * nblk + cb] = word;
+}
+
+constexpr int SWEEP_THREADS = 1024;
+__global__ __launch_bounds__(SWEEP_THREADS) void nms_sweep_kernel(const uint64_t* __restrict__ mask,
+                                                                 const int64_t* __restrict__ order, int n,
+                                                                 int nblk, uint64_t* __restrict__ remv_g,
+                                                                 int64_t* __restrict__ keep,
+                                                                 int32_t* __restrict__ num_keep) {
+  // removal vector lives in global scratch (nblk words) so that N is unbounded; it is L2-resident.
+  __shared__ uint64_t s_kept;
+  __shared__ int s_count;
+  const int tid = threadIdx.x;
+  for (int c = tid; c < nblk; c += SWEEP_THREADS) remv_g[c] = 0;
+  if (tid == 0) s_count = 0;
+  __syncthreads();
+  for (int blk = 0; blk < nblk; blk++) {
+    if (tid < 64) {
+      const int lane = tid;
+      const int i = blk * 64 + lane;
+      uint64_t word = (i < n) ? mask[(size_t)i * nblk + blk] : 0ull;
+      uint64_t removed = remv_g[blk];
+      const int nvalid = min(64, n - blk * 64);
+      uint64_t kept = 0;
+      for (int b = 0; b < nvalid; b++) {
+        uint64_t wb = __shfl(word, b, 64);
+        if (!((removed >> b) & 1ull)) {
+          kept |= (1ull << b);
+          removed |= wb;
+        }
+      }
+      const int base = s_count;
+      if ((kept >> lane) & 1ull) {
+        int pos = __popcll(kept & ((1ull << lane) - 1ull));
+        keep[base + pos] = order[i];
+      }
+      if (lane == 0) {
+        s_kept = kept;
+        s_count = base + __popcll(kept);
+      }
+    }
+    __syncthreads();
+    const uint64_t kept = s_kept;
+    for (int c = blk + 1 + tid; c < nblk; c += SWEEP_THREADS) {
+      uint64_t acc = 0;
+      uint64_t kk = kept;
+      while (kk) {
+        int b = __ffsll((unsigned long long)kk) - 1;
+        kk &= kk - 1;
+        acc |= mask[(size_t)(blk * 64 + b) * nblk + c];
+      }
+      if (acc) remv_g[c] |= acc;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) *num_keep = s_count;
+}
+
+size_t nms_ws_layout(int n, size_t* off_order, size_t* off_mask, size_t* off_remv, size_t* off_sort) {
+  const int nblk = (n + 63) / 64;
+  size_t o = 0;
+  *off_order = o;
+  o += align_up((size_t)n * 8, 256);
+  *off_mask = o;
+  o += align_up((size_t)n * nblk * 8, 256);
+  *off_remv = o;
+  o += align_up((size_t)nblk * 8, 256);
+  *off_sort = o;
+  o += align_up((size_t)next_pow2(n > 0 ? n : 1) * 8, 256);
+  return o;
+}
+
+// ---------------------------------------------------------------- RoIAlignRotated
+struct RoiGeom {
+  float cw, ch, rw, rh, cosv, sinv, bin_h, bin_w, start_h, start_w;
+  int grid_h, grid_w, batch;
+};
+// cpu/roi_align_rotated.cpp:129-172
+__device__ __forceinline__ RoiGeom roi_geometry(const float* __restrict__ roi, float spatial_scale,
+                                                int aligned, int clockwise, int ph, int pw,
+                                                int sampling_ratio) {
+  RoiGeom g;
+  g.batch = (int)roi[0];
+  float offset = aligned ? 0.5f : 0.0f;
+  g.cw = roi[1] * spatial_scale - offset;
+  g.ch = roi[2] * spatial_scale - offset;
+  g.rw = roi[3] * spatial_scale;
+  g.rh = roi[4] * spatial_scale;
+  float theta = roi[5];
+  if (clockwise) theta = -theta;
+  g.cosv = (float)cos((double)theta);
+  g.sinv = (float)sin((double)theta);
+  if (!aligned) {
+    g.rw = fmaxf(g.rw, 1.f);
+    g.rh = fmaxf(g.rh, 1.f);
+  }
+  g.bin_h = g.rh / (float)ph;
+  g.bin_w = g.rw / (float)pw;
+  g.grid_h = (sampling_ratio > 0) ? sampling_ratio : (int)ceilf(g.rh / ph);
+  g.grid_w = (sampling_ratio > 0) ? sampling_ratio : (int)ceilf(g.rw / pw);
+  g.start_h = (float)(-(double)g.rh / 2.0);
+  g.start_w = (float)(-(double)g.rw / 2.0);
+  return g;
+}
+
+struct Sample {
+  int p1, p2, p3, p4;  // offsets y*W+x of the four corners (-1 => sample contributes nothing)
+  float w1, w2, w3, w4;
+};
+
+// pre_calc_for_bilinear_interpolate (cpu/roi_align_rotated.cpp:24-113) for one sample point
+__device__ __forceinline__ Sample make_sample(const RoiGeom& g, int height, int width, int ph, int pw, int iy,
+                                              int ix) {
+  const float yy = g.start_h + ph * g.bin_h + (float)(iy + .5f) * g.bin_h / (float)g.grid_h;
+  const float xx = g.start_w + pw * g.bin_w + (float)(ix + .5f) * g.bin_w / (float)g.grid_w;
+  float y = yy * g.cosv - xx * g.sinv + g.ch;
+  float x = yy * g.sinv + xx * g.cosv + g.cw;
+  Sample s;
+  if (y < -1.0f || y > (float)height || x < -1.0f || x > (float)width) {
+    s.p1 = s.p2 = s.p3 = s.p4 = -1;
+    s.w1 = s.w2 = s.w3 = s.w4 = 0.f;
+    return s;
+  }
+  if (y < 0) y = 0;
+  if (x < 0) x = 0;
+  int y_low = (int)y, x_low = (int)x, y_high, x_high;
+  if (y_low >= height - 1) {
+    y_high = y_low = height - 1;
+    y = (float)y_low;
+  } else {
+    y_high = y_low + 1;
+  }
+  if (x_low >= width - 1) {
+    x_high = x_low = width - 1;
+    x = (float)x_low;
+  } else {
+    x_high = x_low + 1;
+  }
+  float ly = y - y_low, lx = x - x_low;
+  float hy = (float)(1. - (double)ly), hx = (float)(1. - (double)lx);
+  s.w1 = hy * hx;
+  s.w2 = hy * lx;
+  s.w3 = ly * hx;
+  s.w4 = ly * lx;
+  s.p1 = y_low * width + x_low;
+  s.p2 = y_low * width + x_high;
+  s.p3 = y_high * width + x_low;
+  s.p4 = y_high * width + x_high;
+  return s;
+}
+
+constexpr int ROI_THREADS = 256;
+constexpr int ROI_MAX_LDS_SAMPLES = 1024;  // 32 KiB of Sample; larger adaptive grids recompute on the fly
+
+// One workgroup per RoI.  Phase 1: the (bin, iy, ix) sample table is computed once into LDS and shared by all
+// channels (the reference's pre_calc idea).  Phase 2: threads sweep (c, bin) in OUTPUT order -> coalesced
+// stores; layout 1 (NHWC input) sweeps c fastest -> coalesced 4-byte gathers across channels, and the tile
+// is transposed through LDS when it fits.
+template <int LAYOUT>
+__global__ __launch_bounds__(ROI_THREADS) void roi_align_rotated_fwd_kernel(
+    const float* __restrict__ input, const float* __restrict__ rois, float* __restrict__ output, int channels,
+    int height, int width, int PH, int PW, float spatial_scale, int sampling_ratio, int aligned, int clockwise) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  Sample* tab = (Sample*)smem;
+  const int n = blockIdx.x;
+  const RoiGeom g = roi_geometry(rois + 6 * (size_t)n, spatial_scale, aligned, clockwise, PH, PW, sampling_ratio);
+  const int bins = PH * PW;
+  const int spb = g.grid_h * g.grid_w;  // samples per bin
+  const int nsamp = bins * spb;
+  const bool use_tab = nsamp <= ROI_MAX_LDS_SAMPLES;
+  if (use_tab) {
+    for (int s = threadIdx.x; s < nsamp; s += ROI_THREADS) {
+      int bin = s / spb, r = s - bin * spb;
+      int iy = r / g.grid_w, ix = r - iy * g.grid_w;
+      tab[s] = make_sample(g, height, width, bin / PW, bin % PW, iy, ix);
+    }
+  }
+  __syncthreads();
+  int cnt_i = spb < 1 ? 1 : spb;
+  const float count = (float)cnt_i;
+  const size_t plane = (size_t)height * width;
+  const int total = channels * bins;
+  float* out = output + (size_t)n * total;
+  for (int idx = threadIdx.x; idx < total; idx += ROI_THREADS) {
+    int c, bin;
+    if (LAYOUT == 0) {
+      c = idx / bins;
+      bin = idx - c * bins;
+    } else {
+      bin = idx / channels;
+      c = idx - bin * channels;
+    }
+    const float* in;
+    size_t cstride;
+    if (LAYOUT == 0) {
+      in = input + ((size_t)g.batch * channels + c) * plane;
+      cstride = 1;
+    } else {
+      in = input + (size_t)g.batch * plane * channels + c;
+      cstride = channels;
+    }
+    float val = 0.f;
+    for (int r = 0; r < spb; r++) {
+      Sample s;
+      if (use_tab) s = tab[bin * spb + r];
+      else s = make_sample(g, height, width, bin / PW, bin % PW, r / g.grid_w, r % g.grid_w);
+      if (s.p1 < 0) {
+        // reference multiplies the zero weights with input[pos 0] (cpu/roi_align_rotated.cpp:52-66,189-192)
+        float v0 = in[0];
+        val += 0.f * v0 + 0.f * v0 + 0.f * v0 + 0.f * v0;
+      } else {
+        val += s.w1 * in[s.p1 * cstride] + s.w2 * in[s.p2 * cstride] + s.w3 * in[s.p3 * cstride] +
+               s.w4 * in[s.p4 * cstride];
+      }
+    }
+    val /= count;
+    out[(size_t)c * bins + bin] = val;
+  }
+}
+
+template <int LAYOUT>
+__global__ __launch_bounds__(ROI_THREADS) void roi_align_rotated_bwd_kernel(
+    const float* __restrict__ grad_output, const float* __restrict__ rois, float* __restrict__ grad_input,
+    int channels, int height, int width, int PH, int PW, float spatial_scale, int sampling_ratio, int aligned,
+    int clockwise) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  Sample* tab = (Sample*)smem;
+  const int n = blockIdx.x;
+  const RoiGeom g = roi_geometry(rois + 6 * (size_t)n, spatial_scale, aligned, clockwise, PH, PW, sampling_ratio);
+  const int bins = PH * PW;
+  const int spb = g.grid_h * g.grid_w;
+  const int nsamp = bins * spb;
+  const bool use_tab = nsamp <= ROI_MAX_LDS_SAMPLES;
+  if (use_tab) {
+    for (int s = threadIdx.x; s < nsamp; s += ROI_THREADS) {
+      int bin = s / spb, r = s - bin * spb;
+      int iy = r / g.grid_w, ix = r - iy * g.grid_w;
+      tab[s] = make_sample(g, height, width, bin / PW, bin % PW, iy, ix);
+    }
+  }
+  __syncthreads();
+  const float count = (float)spb;  // cpu/roi_align_rotated.cpp:331
+  const size_t plane = (size_t)height * width;
+  const int total = channels * bins;
+  const float* go = grad_output + (size_t)n * total;
+  for (int idx = threadIdx.x; idx < total; idx += ROI_THREADS) {
+    int c, bin;
+    if (LAYOUT == 0) {
+      c = idx / bins;
+      bin = idx - c * bins;
+    } else {
+      bin = idx / channels;
+      c = idx - bin * channels;
+    }
+    float* gin;
+    size_t cstride;
+    if (LAYOUT == 0) {
+      gin = grad_input + ((size_t)g.batch * channels + c) * plane;
+      cstride = 1;
+    } else {
+      gin = grad_input + (size_t)g.batch * plane * channels + c;
+      cstride = channels;
+    }
+    const float gval = go[(size_t)c * bins + bin];
+    for (int r = 0; r < spb; r++) {
+      Sample s;
+      if (use_tab) s = tab[bin * spb + r];
+      else s = make_sample(g, height, width, bin / PW, bin % PW, r / g.grid_w, r % g.grid_w);
+      if (s.p1 < 0) continue;
+      atomicAdd(gin + s.p1 * cstride, gval * s.w1 / count);
+      atomicAdd(gin + s.p2 * cstride, gval * s.w2 / count);
+      atomicAdd(gin + s.p3 * cstride, gval * s.w3 / count);
+      atomicAdd(gin + s.p4 * cstride, gval * s.w4 / count);
+    }
+  }
+}
+
+}  // namespace
+
+// =================================================================================================== C ABI
+extern "C" {
+
+int sm3_box_iou_rotated(const float* boxes1, const float* boxes2, float* ious, int n1, int n2, int mode_flag,
+                        int aligned, sm3_stream_t stream) {
+  if (n1 < 0 || n2 < 0 || (mode_flag != 0 && mode_flag != 1)) return SM3_ERR_INVALID_ARG;
+  if (aligned && n1 != n2) return SM3_ERR_INVALID_ARG;
+  const long total = aligned ? (long)n1 : (long)n1 * n2;
+  if (total == 0) return SM3_OK;
+  if (!boxes1 || !boxes2 || !ious) return SM3_ERR_INVALID_ARG;
+  long blocks = (total + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  box_iou_rotated_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(boxes1, boxes2, ious, n1, n2, mode_flag,
+                                                                     aligned);
+  return launch_status();
+}
+
+size_t sm3_argsort_desc_workspace_bytes(int n) { return (size_t)next_pow2(n > 0 ? n : 1) * 8; }
+
+int sm3_argsort_desc_f32(const float* scores, int n, int64_t* order, void* workspace, size_t workspace_bytes,
+                         sm3_stream_t stream) {
+  if (n < 0) return SM3_ERR_INVALID_ARG;
+  if (n == 0) return SM3_OK;
+  if (!scores || !order || !workspace) return SM3_ERR_INVALID_ARG;
+  int rc = argsort_desc(scores, n, order, workspace, workspace_bytes, (hipStream_t)stream);
+  return rc ? rc : launch_status();
+}
+
+size_t sm3_nms_workspace_bytes(int n) {
+  size_t a, b, c, d;
+  return nms_ws_layout(n > 0 ? n : 1, &a, &b, &c, &d);
+}
+size_t sm3_nms_rotated_workspace_bytes(int n) { return sm3_nms_workspace_bytes(n); }
+
+static int nms_common(bool rotated, const float* boxes, int stride, const float* scores, const int64_t* order,
+                      int n, float thr, int offset, int multi_label, int64_t* keep, int32_t* num_keep,
+                      void* ws, size_t ws_bytes, hipStream_t st) {
+  if (n < 0 || !num_keep) return SM3_ERR_INVALID_ARG;
+  if (n == 0) {
+    (void)hipMemsetAsync(num_keep, 0, sizeof(int32_t), st);
+    return launch_status();
+  }
+  if (!boxes || !keep || !ws) return SM3_ERR_INVALID_ARG;
+  if (rotated && (stride < 5 || (multi_label && stride < 6))) return SM3_ERR_INVALID_ARG;
+  if (!rotated && offset != 0 && offset != 1) return SM3_ERR_INVALID_ARG;
+  size_t o_order, o_mask, o_remv, o_sort;
+  size_t need = nms_ws_layout(n, &o_order, &o_mask, &o_remv, &o_sort);
+  if (ws_bytes < need) return SM3_ERR_WORKSPACE;
+  char* w = (char*)ws;
+  const int nblk = (n + 63) / 64;
+  if (!order) {
+    if (!scores) return SM3_ERR_INVALID_ARG;
+    int rc = argsort_desc(scores, n, (int64_t*)(w + o_order), w + o_sort, ws_bytes - o_sort, st);
+    if (rc) return rc;
+    order = (const int64_t*)(w + o_order);
+  }
+  uint64_t* mask = (uint64_t*)(w + o_mask);
+  const long ntiles = (long)nblk * (nblk + 1) / 2;
+  if (rotated)
+    nms_rotated_mask_kernel<<<(int)ntiles, 64, 0, st>>>(boxes, stride, order, n, nblk, thr, multi_label, mask);
+  else
+    nms_mask_kernel<<<(int)ntiles, 64, 0, st>>>(boxes, order, n, nblk, thr, (float)offset, mask);
+  nms_sweep_kernel<<<1, SWEEP_THREADS, 0, st>>>(mask, order, n, nblk, (uint64_t*)(w + o_remv), keep, num_keep);
+  return launch_status();
+}
+
+int sm3_nms(const float* boxes, const float* scores, const int64_t* order, int n, float iou_threshold, int offset,
+            int64_t* keep, int32_t* num_keep, void* workspace, size_t workspace_bytes, sm3_stream_t stream) {
+  return nms_common(false, boxes, 4, scores, order, n, iou_threshold, offset, 0, keep, num_keep, workspace,
+                    workspace_bytes, (hipStream_t)stream);
+}
+
+int sm3_nms_rotated(const float* dets, int dets_stride, const float* scores, const int64_t* order, int n,
+                    float iou_threshold, int multi_label, int64_t* keep, int32_t* num_keep, void* workspace,
+                    size_t workspace_bytes, sm3_stream_t stream) {
+  return nms_common(true, dets, dets_stride, scores, order, n, iou_threshold, 0, multi_label, keep, num_keep,
+                    workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+static size_t roi_lds_bytes(int pooled_h, int pooled_w, int sampling_ratio) {
+  // adaptive grids (sampling_ratio <= 0) are data dependent: reserve the cap
+  long ns = sampling_ratio > 0 ? (long)pooled_h * pooled_w * sampling_ratio * sampling_ratio
+                               : ROI_MAX_LDS_SAMPLES;
+  if (ns > ROI_MAX_LDS_SAMPLES) ns = 0;
+  return (size_t)(ns > 0 ? ns : 1) * sizeof(Sample);
+}
+
+int sm3_roi_align_rotated_forward(const float* input, const float* rois, float* output, int n_rois, int batch,
+                                  int channels, int height, int width, int pooled_h, int pooled_w,
+                                  float spatial_scale, int sampling_ratio, int aligned, int clockwise, int layout,
+                                  sm3_stream_t stream) {
+  if (n_rois < 0 || batch < 0 || channels <= 0 || height <= 0 || width <= 0 || pooled_h <= 0 || pooled_w <= 0 ||
+      (layout != 0 && layout != 1))
+    return SM3_ERR_INVALID_ARG;
+  if (n_rois == 0) return SM3_OK;
+  if (!input || !rois || !output) return SM3_ERR_INVALID_ARG;
+  size_t lds = roi_lds_bytes(pooled_h, pooled_w, sampling_ratio);
+  hipStream_t st = (hipStream_t)stream;
+  if (layout == 0)
+    roi_align_rotated_fwd_kernel<0><<<n_rois, ROI_THREADS, lds, st>>>(input, rois, output, channels, height, width,
+                                                                      pooled_h, pooled_w, spatial_scale,
+                                                                      sampling_ratio, aligned, clockwise);
+  else
+    roi_align_rotated_fwd_kernel<1><<<n_rois, ROI_THREADS, lds, st>>>(input, rois, output, channels, height, width,
+                                                                      pooled_h, pooled_w, spatial_scale,
+                                                                      sampling_ratio, aligned, clockwise);
+  return launch_status();
+}
+
+int sm3_roi_align_rotated_backward(const float* grad_output, const float* rois, float* grad_input, int n_rois,
+                                   int batch, int channels, int height, int width, int pooled_h, int pooled_w,
+                                   float spatial_scale, int sampling_ratio, int aligned, int clockwise, int layout,
+                                   sm3_stream_t stream) {
+  if (n_rois < 0 || batch < 0 || channels <= 0 || height <= 0 || width <= 0 || pooled_h <= 0 || pooled_w <= 0 ||
+      (layout != 0 && layout != 1))
+    return SM3_ERR_INVALID_ARG;
+  if (n_rois == 0) return SM3_OK;
+  if (!grad_output || !rois || !grad_input) return SM3_ERR_INVALID_ARG;
+  size_t lds = roi_lds_bytes(pooled_h, pooled_w, sampling_ratio);
+  hipStream_t st = (hipStream_t)stream;
+  if (layout == 0)
+    roi_align_rotated_bwd_kernel<0><<<n_rois, ROI_THREADS, lds, st>>>(grad_output, rois, grad_input, channels,
+                                                                      height, width, pooled_h, pooled_w,
+                                                                      spatial_scale, sampling_ratio, aligned,
+                                                                      clockwise);
+  else
+    roi_align_rotated_bwd_kernel<1><<<n_rois, ROI_THREADS, lds, st>>>(grad_output, rois, grad_input, channels,
+                                                                      height, width, pooled_h, pooled_w,
+                                                                      spatial_scale, sampling_ratio, aligned,
+                                                                      clockwise);
+  return launch_status();
+}
+
+}  // extern "C"

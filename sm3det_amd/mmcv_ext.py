@@ -1,0 +1,218 @@
+"""Drop-in for the reference's native operator module ``mmcv._ext``.
+
+The reference's Python wrappers obtain their native functions with
+``ext_loader.load_ext('_ext', [names])`` = ``importlib.import_module('mmcv._ext')`` + ``hasattr`` checks
+(mmcv/mmcv/utils/ext_loader.py:12-16).  This module exposes the SAME function names, positional orders and
+keyword names as the pybind table in ``mmcv/mmcv/ops/csrc/pytorch/pybind.cpp`` for the hot set
+(``box_iou_rotated``, ``nms``, ``nms_rotated``, ``roi_align_rotated_{forward,backward}``,
+``deform_conv_{forward,backward_input,backward_parameters}``) and forwards them to the gfx950 kernels through the C
+ABI (``include/sm3det_hip.h``).  The other ~95 names the reference's ``mmcv.ops`` asserts at import time exist as
+stubs that raise ``NotImplementedError`` (out of scope).
+
+``install_as_mmcv_ext()`` registers this module as ``sys.modules['mmcv._ext']`` so the reference's unmodified
+wrappers (``mmcv/mmcv/ops/{roi_align_rotated,box_iou_rotated,nms,deform_conv}.py``) bind to it.
+
+Errors: device mismatch / wrong dtype / wrong shape raise ``RuntimeError`` like the reference's ``TORCH_CHECK``
+(pytorch_device_registry.hpp:111-124).  CPU tensors are REJECTED: there is no CPU implementation here.
+"""
+import sys
+
+import torch
+
+from . import _lib
+from ._lib import SM3Error, check, lib, ptr, require_gpu, stream_ptr, workspace
+
+
+def _f32c(t, name):
+    if t.dtype != torch.float32:
+        raise SM3Error(f'{name} must be float32 (got {t.dtype})')
+    if not t.is_contiguous():
+        raise SM3Error(f'{name} must be contiguous')
+
+
+def get_compiler_version():
+    return lib().sm3_compiler_version().decode()
+
+
+def get_compiling_cuda_version():
+    return 'ROCm/HIP gfx950 (no CUDA)'
+
+
+# ------------------------------------------------------------------------------------------- box_iou_rotated
+def box_iou_rotated(boxes1, boxes2, ious, mode_flag=0, aligned=False):
+    """pybind.cpp:308-309,746-748 -- fills ``ious`` in place."""
+    require_gpu(boxes1, boxes2, ious)
+    _f32c(boxes1, 'boxes1'); _f32c(boxes2, 'boxes2'); _f32c(ious, 'ious')
+    n1, n2 = boxes1.size(0), boxes2.size(0)
+    if n1 and boxes1.size(-1) != 5 or n2 and boxes2.size(-1) != 5:
+        raise SM3Error('boxes must have shape (N,5)')
+    if ious.numel() != (n1 if aligned else n1 * n2):
+        raise SM3Error('ious has the wrong number of elements')
+    with torch.cuda.device(boxes1.device):
+        check(lib().sm3_box_iou_rotated(ptr(boxes1), ptr(boxes2), ptr(ious), n1, n2, int(mode_flag),
+                                        int(bool(aligned)), stream_ptr()), 'box_iou_rotated')
+
+
+# ------------------------------------------------------------------------------------------- nms
+def _finish_keep(keep, num_keep):
+    k = int(num_keep.item())  # the reference returns a tensor of length num_to_keep: one sync is inherent
+    return keep[:k]
+
+
+def nms(boxes, scores, iou_threshold, offset):
+    """pybind.cpp:185,634-635 -> int64 keep indices in descending-score order."""
+    require_gpu(boxes, scores)
+    n = boxes.size(0)
+    if n == 0:
+        return boxes.new_empty((0,), dtype=torch.long)
+    _f32c(boxes, 'boxes'); _f32c(scores, 'scores')
+    if boxes.size(1) != 4 or scores.numel() != n:
+        raise SM3Error('nms expects boxes (N,4) and scores (N,)')
+    with torch.cuda.device(boxes.device):
+        keep = torch.empty(n, dtype=torch.long, device=boxes.device)
+        num = torch.empty(1, dtype=torch.int32, device=boxes.device)
+        nbytes = lib().sm3_nms_workspace_bytes(n)
+        ws = workspace(nbytes, boxes.device)
+        check(lib().sm3_nms(ptr(boxes), ptr(scores), None, n, float(iou_threshold), int(offset), ptr(keep),
+                            ptr(num), ptr(ws), nbytes, stream_ptr()), 'nms')
+        return _finish_keep(keep, num)
+
+
+def nms_rotated(dets, scores, order, dets_sorted, iou_threshold, multi_label):
+    """pybind.cpp:311-313,749-751.  Follows the CPU path (pytorch/nms_rotated.cpp:31 ->
+    cpu/nms_rotated.cpp:7-57): ``order``/``dets_sorted``/``multi_label`` are ignored, labels in a 6th column too;
+    suppression uses ``>=``.  ``order`` IS used as the precomputed permutation when it is a valid int64 tensor
+    (it equals what the CPU path recomputes on tie-free scores)."""
+    require_gpu(dets, scores)
+    n = dets.size(0)
+    if n == 0:
+        return dets.new_empty((0,), dtype=torch.long)
+    _f32c(dets, 'dets'); _f32c(scores, 'scores')
+    if dets.dim() != 2 or dets.size(1) < 5:
+        raise SM3Error('dets must have shape (N, >=5)')
+    if scores.numel() != n:
+        raise SM3Error('dets and scores must have the same length')
+    with torch.cuda.device(dets.device):
+        keep = torch.empty(n, dtype=torch.long, device=dets.device)
+        num = torch.empty(1, dtype=torch.int32, device=dets.device)
+        nbytes = lib().sm3_nms_rotated_workspace_bytes(n)
+        ws = workspace(nbytes, dets.device)
+        check(lib().sm3_nms_rotated(ptr(dets), int(dets.size(1)), ptr(scores), None, n, float(iou_threshold), 0,
+                                    ptr(keep), ptr(num), ptr(ws), nbytes, stream_ptr()), 'nms_rotated')
+        return _finish_keep(keep, num)
+
+
+# ------------------------------------------------------------------------------------------- roi_align_rotated
+def _layout_of(t):
+    """0 = NCHW contiguous, 1 = NHWC memory (torch.channels_last)."""
+    if t.is_contiguous():
+        return 0
+    if t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last):
+        return 1
+    raise SM3Error('feature map must be NCHW-contiguous or channels_last')
+
+
+def roi_align_rotated_forward(input, rois, output, pooled_height, pooled_width, spatial_scale, sampling_ratio,
+                              aligned, clockwise):
+    """pybind.cpp:323-326,761-765 -- fills ``output`` (n,C,ph,pw) in place."""
+    require_gpu(input, rois, output)
+    _f32c(rois, 'rois'); _f32c(output, 'output')
+    if input.dtype != torch.float32:
+        raise SM3Error('input must be float32')
+    layout = _layout_of(input)
+    n = rois.size(0)
+    if n and rois.size(1) != 6:
+        raise SM3Error('wrong roi size')
+    B, C, H, W = input.shape
+    with torch.cuda.device(input.device):
+        check(lib().sm3_roi_align_rotated_forward(ptr(input), ptr(rois), ptr(output), n, B, C, H, W,
+                                                  int(pooled_height), int(pooled_width), float(spatial_scale),
+                                                  int(sampling_ratio), int(bool(aligned)), int(bool(clockwise)),
+                                                  layout, stream_ptr()), 'roi_align_rotated_forward')
+
+
+def roi_align_rotated_backward(grad_output, rois, grad_input, pooled_height, pooled_width, spatial_scale,
+                               sampling_ratio, aligned, clockwise):
+    """pybind.cpp:766-770; positional order (grad_output, rois, grad_input) as the Python caller uses it
+    (mmcv/ops/roi_align_rotated.py:94-103).  ``grad_input`` must arrive zero-filled."""
+    require_gpu(grad_output, rois, grad_input)
+    _f32c(rois, 'rois'); _f32c(grad_output, 'grad_output')
+    if rois.size(0) and rois.size(1) != 6:
+        raise SM3Error('wrong roi size')  # cpu/roi_align_rotated.cpp:433-436
+    layout = _layout_of(grad_input)
+    B, C, H, W = grad_input.shape
+    with torch.cuda.device(grad_input.device):
+        check(lib().sm3_roi_align_rotated_backward(ptr(grad_output), ptr(rois), ptr(grad_input), rois.size(0), B, C,
+                                                   H, W, int(pooled_height), int(pooled_width),
+                                                   float(spatial_scale), int(sampling_ratio), int(bool(aligned)),
+                                                   int(bool(clockwise)), layout, stream_ptr()),
+              'roi_align_rotated_backward')
+
+
+# ------------------------------------------------------------------------------------------- deform_conv
+def deform_conv_forward(*args, **kwargs):
+    from . import deform_conv_host
+    return deform_conv_host.deform_conv_forward(*args, **kwargs)
+
+
+def deform_conv_backward_input(*args, **kwargs):
+    from . import deform_conv_host
+    return deform_conv_host.deform_conv_backward_input(*args, **kwargs)
+
+
+def deform_conv_backward_parameters(*args, **kwargs):
+    from . import deform_conv_host
+    return deform_conv_host.deform_conv_backward_parameters(*args, **kwargs)
+
+
+# ------------------------------------------------------------------------------------------- stubs
+HOT_SET = ['box_iou_rotated', 'nms', 'nms_rotated', 'roi_align_rotated_forward', 'roi_align_rotated_backward',
+           'deform_conv_forward', 'deform_conv_backward_input', 'deform_conv_backward_parameters',
+           'get_compiler_version', 'get_compiling_cuda_version']
+
+# every other symbol the reference's `mmcv.ops` package asserts at import time (107 in total; extracted from the
+# `load_ext('_ext', [...])` lists of mmcv/mmcv/ops/*.py)
+_STUB_NAMES = '''
+active_rotated_filter_backward active_rotated_filter_forward assign_score_withk_backward
+assign_score_withk_forward ball_query_forward bbox_overlaps border_align_backward border_align_forward
+box_iou_quadri carafe_backward carafe_forward carafe_naive_backward carafe_naive_forward
+chamfer_distance_backward chamfer_distance_forward contour_expand convex_giou convex_iou correlation_backward
+correlation_forward deform_roi_pool_backward deform_roi_pool_forward diff_iou_rotated_sort_vertices_forward
+dynamic_point_to_voxel_backward dynamic_point_to_voxel_forward dynamic_voxelize_forward
+furthest_point_sampling_forward furthest_point_sampling_with_dist_forward fused_bias_leakyrelu
+fused_indice_conv_forward gather_points_backward gather_points_forward get_indice_pairs_2d_backward
+get_indice_pairs_2d_forward get_indice_pairs_3d_backward get_indice_pairs_3d_forward get_indice_pairs_4d_forward
+group_points_backward group_points_forward hard_voxelize_forward indice_conv_backward indice_conv_forward
+indice_maxpool_backward indice_maxpool_forward iou3d_boxes_overlap_bev_forward iou3d_nms3d_forward
+iou3d_nms3d_normal_forward knn_forward masked_col2im_forward masked_im2col_forward min_area_polygons
+modulated_deform_conv_backward modulated_deform_conv_forward ms_deform_attn_backward ms_deform_attn_forward
+nms_match nms_quadri pixel_group points_in_boxes_all_forward points_in_boxes_cpu_forward
+points_in_boxes_part_forward points_in_polygons_forward prroi_pool_backward prroi_pool_coor_backward
+prroi_pool_forward psamask_backward psamask_forward riroi_align_rotated_backward riroi_align_rotated_forward
+roi_align_backward roi_align_forward roi_pool_backward roi_pool_forward roiaware_pool3d_backward
+roiaware_pool3d_forward roipoint_pool3d_forward rotated_feature_align_backward rotated_feature_align_forward
+sigmoid_focal_loss_backward sigmoid_focal_loss_forward softmax_focal_loss_backward softmax_focal_loss_forward
+softnms stack_ball_query_forward stack_group_points_backward stack_group_points_forward sync_bn_backward_data
+sync_bn_backward_param sync_bn_forward_mean sync_bn_forward_output sync_bn_forward_var three_interpolate_backward
+three_interpolate_forward three_nn_forward tin_shift_backward tin_shift_forward upfirdn2d
+'''.split()
+
+
+def _make_stub(name):
+    def stub(*args, **kwargs):
+        raise NotImplementedError(f'mmcv._ext.{name} is outside the SM3Det hot path and is not provided by '
+                                  f'sm3det_amd (SURVEY.md section 2, row 25)')
+    stub.__name__ = name
+    return stub
+
+
+for _n in _STUB_NAMES:
+    globals()[_n] = _make_stub(_n)
+
+ALL_EXT_NAMES = sorted(HOT_SET + _STUB_NAMES)
+
+
+def install_as_mmcv_ext():
+    """Register this module as ``mmcv._ext`` (what ext_loader.load_ext imports)."""
+    sys.modules['mmcv._ext'] = sys.modules[__name__]
+    return sys.modules[__name__]
