@@ -98,6 +98,53 @@ int sm3_roi_align_rotated_backward(const float* grad_output, const float* rois, 
                                    int pooled_h, int pooled_w, float spatial_scale, int sampling_ratio,
                                    int aligned, int clockwise, int layout, sm3_stream_t stream);
 
+/* =========================================================================================================
+ * Backbone hot path (a): grid-level sparse-MoE ConvNeXt.  Reference: mmrotate/models/backbones/convnext_moe.py.
+ * Activations are token-major (T, C) float32 = NHWC; T = B*H*W.
+ * ========================================================================================================= */
+
+/* ---------------------------------------------------------------------------------------------------------
+ * fp32 MFMA GEMM family (v_mfma_f32_32x32x2_f32, exact f32).  Covers FFN.forward (convnext_moe.py:397-405),
+ * the expert loop (:244) as a grouped GEMM, the cosine-gate projection (:101), stem/downsample patch GEMMs
+ * (:533-558,:783-791) and all their gradients.
+ *   mode 0 NT: C[M,N] = A[M,K] . B[N,K]^T      mode 1 NN: C[M,N] = A[M,K] . B[K,N]
+ *   mode 2 TN: C[M,N] = A[Kt,M]^T . B[Kt,N]    (split-K over the reduction rows, needs workspace)
+ * Grouping (MoE): `group_offsets` = DEVICE int32[num_groups+1] prefix of rows in expert-major slot order; group g
+ * uses B + g*stride_b, bias + g*stride_bias; TN writes C + g*M*N.  NULL => a single group.
+ * Requirements: lda, ldb, N multiples of 4; K multiple of 32 for NT/NN; TN: M multiple of 4. */
+#define SM3_GEMM_NT 0
+#define SM3_GEMM_NN 1
+#define SM3_GEMM_TN 2
+#define SM3_EPI_NONE 0           /* C = acc */
+#define SM3_EPI_BIAS 1           /* C = acc + bias[n] */
+#define SM3_EPI_BIAS_GELU 2      /* aux_out = acc + bias ; C = gelu_erf(aux_out)              (FFN first linear) */
+#define SM3_EPI_BIAS_SCALE_RES 3 /* aux_out = y = acc + bias ; C = aux_in + gamma[n]*rowscale[m/rows_per_scale]*y */
+#define SM3_EPI_GELU_BWD 4       /* C = acc * gelu_erf'(aux_in)                               (dgrad through GELU) */
+typedef struct sm3_gemm_desc {
+  int32_t mode, epilogue;
+  const float* A;
+  const float* B;
+  float* C;
+  int32_t M, N, K;
+  int32_t lda, ldb, ldc;
+  const int32_t* group_offsets;
+  int32_t num_groups;
+  int32_t splits; /* TN only: split-K factor per group */
+  int64_t stride_b, stride_bias;
+  const float* bias;
+  const float* aux_in;
+  float* aux_out;
+  const float* gamma;
+  const float* rowscale;
+  int32_t rows_per_scale;
+  int32_t ld_aux;
+} sm3_gemm_desc;
+size_t sm3_gemm_f32_workspace_bytes(const sm3_gemm_desc* desc);
+int sm3_gemm_f32(const sm3_gemm_desc* desc, void* workspace, size_t workspace_bytes, sm3_stream_t stream);
+/* out[g][n] = sum over rows of group g of x[r][n]  (bias gradients); out is overwritten */
+int sm3_colsum_f32(const float* x, int ld, int m, int n, const int32_t* group_offsets, int num_groups, float* out,
+                   sm3_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,6 +1,89 @@
-"""ctypes signatures of the backbone (MoE ConvNeXt) entry points of libsm3det_hip.so."""
+"""ctypes signatures + thin tensor-level callers for the backbone (MoE ConvNeXt) entry points of
+libsm3det_hip.so (declared in include/sm3det_hip.h)."""
 import ctypes
+
+import torch
+
+P, I, F, S = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+
+NT, NN, TN = 0, 1, 2
+EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_SCALE_RES, EPI_GELU_BWD = 0, 1, 2, 3, 4
+
+
+class GemmDesc(ctypes.Structure):
+    """mirror of `sm3_gemm_desc` (include/sm3det_hip.h)"""
+    _fields_ = [
+        ('mode', ctypes.c_int32), ('epilogue', ctypes.c_int32),
+        ('A', P), ('B', P), ('C', P),
+        ('M', ctypes.c_int32), ('N', ctypes.c_int32), ('K', ctypes.c_int32),
+        ('lda', ctypes.c_int32), ('ldb', ctypes.c_int32), ('ldc', ctypes.c_int32),
+        ('group_offsets', P), ('num_groups', ctypes.c_int32), ('splits', ctypes.c_int32),
+        ('stride_b', ctypes.c_int64), ('stride_bias', ctypes.c_int64),
+        ('bias', P), ('aux_in', P), ('aux_out', P), ('gamma', P), ('rowscale', P),
+        ('rows_per_scale', ctypes.c_int32), ('ld_aux', ctypes.c_int32),
+    ]
 
 
 def signatures():
-    return {}
+    D = ctypes.POINTER(GemmDesc)
+    return {
+        'sm3_gemm_f32_workspace_bytes': (S, [D]),
+        'sm3_gemm_f32': (I, [D, P, S, P]),
+        'sm3_colsum_f32': (I, [P, I, I, I, P, I, P, P]),
+    }
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def gemm(mode, A, B, C, M, N, K, *, epilogue=EPI_NONE, bias=None, aux_in=None, aux_out=None, gamma=None,
+         rowscale=None, rows_per_scale=1, offsets=None, num_groups=1, splits=1, lda=None, ldb=None, ldc=None,
+         ld_aux=None):
+    """Enqueue one GEMM of the family on torch's current stream.  All tensors fp32, on the current device."""
+    from . import _lib
+    L = _lib.lib()
+    d = GemmDesc()
+    d.mode, d.epilogue = mode, epilogue
+    d.A, d.B, d.C = _p(A), _p(B), _p(C)
+    d.M, d.N, d.K = M, N, K
+    if mode == NT:
+        d.lda, d.ldb = lda or K, ldb or K
+    elif mode == NN:
+        d.lda, d.ldb = lda or K, ldb or N
+    else:
+        d.lda, d.ldb = lda or M, ldb or N
+    d.ldc = ldc or N
+    d.group_offsets = _p(offsets)
+    d.num_groups = num_groups
+    d.splits = splits
+    if mode == NT:
+        d.stride_b = N * (ldb or K)
+    elif mode == NN:
+        d.stride_b = K * (ldb or N)
+    else:
+        d.stride_b = 0
+    d.stride_bias = N
+    d.bias, d.aux_in, d.aux_out, d.gamma, d.rowscale = _p(bias), _p(aux_in), _p(aux_out), _p(gamma), _p(rowscale)
+    d.rows_per_scale = rows_per_scale
+    d.ld_aux = ld_aux or N
+    ws = None
+    nbytes = 0
+    if mode == TN:
+        nbytes = L.sm3_gemm_f32_workspace_bytes(ctypes.byref(d))
+        ws = _lib.workspace(nbytes, C.device)
+    _lib.check(L.sm3_gemm_f32(ctypes.byref(d), _p(ws), nbytes, _lib.stream_ptr()), 'gemm_f32')
+
+
+def colsum(x, M, N, out, offsets=None, num_groups=1, ld=None):
+    from . import _lib
+    L = _lib.lib()
+    _lib.check(L.sm3_colsum_f32(_p(x), ld or N, M, N, _p(offsets), num_groups, _p(out), _lib.stream_ptr()),
+               'colsum_f32')
+
+
+def tn_splits(tiles, rows, target_blocks=1024):
+    """split-K factor so a weight-gradient GEMM fills the 256 CUs (>= ~4 blocks per CU) without tiny K chunks."""
+    s = max(1, target_blocks // max(tiles, 1))
+    s = min(s, max(1, rows // 256))
+    return int(s)

@@ -1,0 +1,442 @@
+// gemm_f32.hip -- fp32 GEMM family on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32: exact f32 FMA chain,
+// 157 TFLOP/s peak = 1/16 of bf16 MFMA; there is no TF32/xf32 on CDNA4).
+//
+// One kernel template covers every dense contraction of the SM3Det backbone hot path
+// (reference: mmrotate/models/backbones/convnext_moe.py FFN.forward :397-405, the expert loop :244,
+// CosineTopKGate projection :101, stem / downsample convs as patch GEMMs :533-558,783-791) and their backward:
+//
+//   MODE_NT : C[M,N] = A[M,K] . B[N,K]^T        (nn.Linear forward: x @ W^T)
+//   MODE_NN : C[M,N] = A[M,K] . B[K,N]          (dgrad: dY @ W)
+//   MODE_TN : C[M,N] = A[Kt,M]^T . B[Kt,N]      (wgrad: dY^T @ X, split-K over token rows, partials to workspace)
+//
+// Grouped (MoE experts): rows of A/C (NT, NN) or the reduction rows (TN) are partitioned into `num_groups`
+// contiguous segments by a DEVICE prefix array `offsets[G+1]` (expert-major slot order); group g uses weight block
+// g.  The tile->group map is computed in the kernel from `offsets`, so ragged expert loads never sync the host
+// (the reference does `.cpu()` per MoE block: convnext_moe.py:259).
+//
+// Tiling: 256 threads = 4 waves (2x2), block tile 128x128x32, wave tile 64x64 = 2x2 MFMA 32x32 tiles
+// (64 accumulator VGPRs), operands staged k-major in LDS (conflict-free ds_read_b32: lanes 0-31 read 32 consecutive
+// floats of row k, lanes 32-63 of row k+1 -- exactly the A[i][k]/B[k][j] fragment of the 32x32x2 instruction),
+// register-prefetched double-buffered LDS (one barrier per k-step), XCD-aware block remap so the N-tiles that
+// share an A row-panel land on one XCD's L2.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int MODE_NT = 0, MODE_NN = 1, MODE_TN = 2;
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int LD_T = BM + 1;  // leading dim of a tile written transposed (k-contiguous source): conflict-free b32 writes
+constexpr int LD_D = BM + 4;  // leading dim of a tile written directly (k-major source): 16-B aligned rows
+constexpr int NTHREADS = 256;
+
+struct GemmParams {
+  const float* A;
+  const float* B;
+  float* C;
+  int M, N, K;  // TN: M,N = output dims, K = total reduction rows (ignored when grouped: offsets decide)
+  int lda, ldb, ldc;
+  // grouping
+  const int32_t* offsets;  // device, num_groups+1 (NULL => one group covering all rows)
+  int num_groups;
+  long strideB;     // elements between consecutive groups' B blocks (NT/NN)
+  long strideBias;  // elements between groups' bias vectors
+  long strideC;     // TN: elements between groups' outputs in the partial workspace (= M*N)
+  int splits;       // TN: split-K factor per group
+  // epilogue operands
+  const float* bias;      // [N] (per group)
+  const float* aux_in;    // EPI_GELU_BWD: hpre[M,N];  EPI_BIAS_SCALE_RES: residual[M,N]
+  float* aux_out;         // EPI_BIAS_GELU: hpre[M,N]; EPI_BIAS_SCALE_RES: y[M,N]
+  const float* gamma;     // [N] layer scale
+  const float* rowscale;  // [M / rows_per_scale] (stochastic-depth keep/keep_prob per image) or NULL
+  int rows_per_scale;
+  int ld_aux;
+};
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+// EPI codes (must match include/sm3det_hip.h)
+constexpr int EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_BIAS_SCALE_RES = 3, EPI_GELU_BWD = 4;
+
+template <int MODE, int EPI>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(GemmParams p) {
+  // both operand regions are sized for the wider leading dimension (LD_D); 2 stages each: 67.6 KB -> 2 blocks/CU
+  __shared__ __attribute__((aligned(16))) float smem[4 * BK * LD_D];
+  // A tile uses LD_T when its source is k-contiguous (NT, NN), LD_D when k-major (TN).
+  // B tile uses LD_T when its source is k-contiguous (NT),     LD_D when k-major (NN, TN).
+  constexpr bool A_TRANS = (MODE != MODE_TN);
+  constexpr bool B_TRANS = (MODE == MODE_NT);
+  constexpr int LDA_S = A_TRANS ? LD_T : LD_D;
+  constexpr int LDB_S = B_TRANS ? LD_T : LD_D;
+  float* As = smem;                  // [2][BK][LDA_S]
+  float* Bs = smem + 2 * BK * LD_D;  // [2][BK][LDB_S]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm0 = (wave >> 1) * 64;
+  const int wn0 = (wave & 1) * 64;
+  const int l31 = lane & 31;
+  const int lh = lane >> 5;
+
+  // ---- XCD-aware remap of the linear block id (speed only): consecutive logical tiles share an XCD ----------
+  const int ntn = (p.N + BN - 1) / BN;
+  int nblk = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nblk / kNumXCD, r = nblk % kNumXCD;
+    const int xcd = bid % kNumXCD, idx = bid / kNumXCD;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tile_n = bid % ntn;
+  int tile_m = bid / ntn;
+
+  // ---- group / row-range resolution -------------------------------------------------------------------------
+  int g = 0;
+  int row0, row_end;  // NT/NN: rows of A and C handled by this block; TN: reduction rows [row0,row_end)
+  int m0;             // TN: first output row of this tile
+  if (MODE == MODE_TN) {
+    g = blockIdx.z / p.splits;
+    const int split = blockIdx.z - g * p.splits;
+    int seg0 = 0, seg1 = p.K;
+    if (p.offsets) {
+      seg0 = p.offsets[g];
+      seg1 = p.offsets[g + 1];
+    }
+    const int cnt = seg1 - seg0;
+    int chunk = (cnt + p.splits - 1) / p.splits;
+    chunk = (chunk + BK - 1) / BK * BK;
+    row0 = seg0 + split * chunk;
+    row_end = min(seg1, row0 + chunk);
+    m0 = tile_m * BM;
+  } else {
+    if (p.offsets) {
+      int base = 0;
+      bool found = false;
+      for (int gg = 0; gg < p.num_groups; gg++) {
+        const int o0 = p.offsets[gg], o1 = p.offsets[gg + 1];
+        const int nt = (o1 - o0 + BM - 1) / BM;
+        if (tile_m < base + nt) {
+          g = gg;
+          row0 = o0 + (tile_m - base) * BM;
+          row_end = o1;
+          found = true;
+          break;
+        }
+        base += nt;
+      }
+      if (!found) return;
+    } else {
+      row0 = tile_m * BM;
+      row_end = p.M;
+      if (row0 >= row_end) return;
+    }
+    m0 = row0;
+  }
+  const int n0 = tile_n * BN;
+  const float* __restrict__ Ag = p.A;
+  const float* __restrict__ Bg = p.B + (MODE == MODE_TN ? 0 : (long)g * p.strideB);
+
+  // ---- loaders ----------------------------------------------------------------------------------------------
+  // transposed loader: source rows are k-contiguous: thread -> (row r + 32 i, k quad kq)
+  const int t_kq = tid & 7, t_r = tid >> 3;
+  // direct loader: source is k-major: thread -> (k row kk + 8 i, column quad nq)
+  const int d_nq = tid & 31, d_kk = tid >> 5;
+
+  f32x4 ra[4], rb[4];
+  const int nk = (MODE == MODE_TN) ? (max(row_end - row0, 0) + BK - 1) / BK : p.K / BK;
+
+  auto load_tiles = [&](int kt) {
+    if (MODE == MODE_TN) {
+      const int kbase = row0 + kt * BK;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int kr = kbase + d_kk + 8 * i;
+        const int mcol = m0 + 4 * d_nq;
+        const int ncol = n0 + 4 * d_nq;
+        f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
+        if (kr < row_end) {
+          if (mcol < p.M) va = *reinterpret_cast<const f32x4*>(Ag + (long)kr * p.lda + mcol);
+          if (ncol < p.N) vb = *reinterpret_cast<const f32x4*>(Bg + (long)kr * p.ldb + ncol);
+        }
+        ra[i] = va;
+        rb[i] = vb;
+      }
+    } else {
+      const int k0 = kt * BK;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int r = row0 + t_r + 32 * i;
+        f32x4 va = {0.f, 0.f, 0.f, 0.f};
+        if (r < row_end) va = *reinterpret_cast<const f32x4*>(Ag + (long)r * p.lda + k0 + 4 * t_kq);
+        ra[i] = va;
+      }
+      if (MODE == MODE_NT) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int n = n0 + t_r + 32 * i;
+          f32x4 vb = {0.f, 0.f, 0.f, 0.f};
+          if (n < p.N) vb = *reinterpret_cast<const f32x4*>(Bg + (long)n * p.ldb + k0 + 4 * t_kq);
+          rb[i] = vb;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int kr = k0 + d_kk + 8 * i;
+          const int ncol = n0 + 4 * d_nq;
+          f32x4 vb = {0.f, 0.f, 0.f, 0.f};
+          if (ncol < p.N) vb = *reinterpret_cast<const f32x4*>(Bg + (long)kr * p.ldb + ncol);
+          rb[i] = vb;
+        }
+      }
+    }
+  };
+  auto store_tiles = [&](int buf) {
+    float* a_s = As + buf * BK * LDA_S;
+    float* b_s = Bs + buf * BK * LDB_S;
+    if (A_TRANS) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) a_s[(4 * t_kq + j) * LDA_S + t_r + 32 * i] = ra[i][j];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; i++) *reinterpret_cast<f32x4*>(a_s + (d_kk + 8 * i) * LDA_S + 4 * d_nq) = ra[i];
+    }
+    if (B_TRANS) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) b_s[(4 * t_kq + j) * LDB_S + t_r + 32 * i] = rb[i][j];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; i++) *reinterpret_cast<f32x4*>(b_s + (d_kk + 8 * i) * LDB_S + 4 * d_nq) = rb[i];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  if (nk > 0) {
+    load_tiles(0);
+    store_tiles(0);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; kt++) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_tiles(kt + 1);
+    const float* a_s = As + buf * BK * LDA_S + wm0 + l31;
+    const float* b_s = Bs + buf * BK * LDB_S + wn0 + l31;
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; kk++) {
+      const int krow = 2 * kk + lh;
+      const float a0 = a_s[krow * LDA_S];
+      const float a1 = a_s[krow * LDA_S + 32];
+      const float b0 = b_s[krow * LDB_S];
+      const float b1 = b_s[krow * LDB_S + 32];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (kt + 1 < nk) store_tiles(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue ---------------------------------------------------------------------------------------------
+  // acc[i][j][r]: row = wm0 + 32 i + (r&3) + 8 (r>>2) + 4 lh ; col = wn0 + 32 j + l31
+  float* __restrict__ Cg = p.C;
+  long c_base = 0;
+  int m_lim;
+  if (MODE == MODE_TN) {
+    c_base = (long)blockIdx.z * p.strideC;
+    m_lim = p.M;
+  } else {
+    m_lim = row_end;
+  }
+  const float* bias = (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_SCALE_RES)
+                          ? p.bias + (long)g * p.strideBias
+                          : nullptr;
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const int col = n0 + wn0 + 32 * j + l31;
+    if (col >= p.N) continue;
+    float bv = 0.f, gm = 0.f;
+    if (bias) bv = bias[col];
+    if (EPI == EPI_BIAS_SCALE_RES) gm = p.gamma[col];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int row = m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row >= m_lim) continue;
+        float v = acc[i][j][r];
+        const long ci = c_base + (long)row * p.ldc + col;
+        if (EPI == EPI_NONE) {
+          Cg[ci] = v;
+        } else if (EPI == EPI_BIAS) {
+          Cg[ci] = v + bv;
+        } else if (EPI == EPI_BIAS_GELU) {
+          const float h = v + bv;
+          p.aux_out[(long)row * p.ld_aux + col] = h;
+          Cg[ci] = gelu_erf(h);
+        } else if (EPI == EPI_BIAS_SCALE_RES) {
+          const float y = v + bv;
+          p.aux_out[(long)row * p.ld_aux + col] = y;
+          float sc = gm;
+          if (p.rowscale) sc *= p.rowscale[row / p.rows_per_scale];
+          Cg[ci] = p.aux_in[(long)row * p.ld_aux + col] + sc * y;
+        } else if (EPI == EPI_GELU_BWD) {
+          Cg[ci] = v * gelu_erf_grad(p.aux_in[(long)row * p.ld_aux + col]);
+        }
+      }
+    }
+  }
+}
+
+// Sum the split-K partials of a TN GEMM: out[g][i] = sum_s ws[(g*splits+s)][i]
+__global__ void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, long mn, int splits,
+                                     int groups) {
+  const long total = mn * groups;
+  for (long idx = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; idx < total;
+       idx += (long)gridDim.x * blockDim.x * 4) {
+    const long gidx = idx / mn;
+    const long e = idx - gidx * mn;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < splits; k++) s += *reinterpret_cast<const f32x4*>(ws + (gidx * splits + k) * mn + e);
+    *reinterpret_cast<f32x4*>(out + idx) = s;
+  }
+}
+
+// Column sums over row segments (bias gradients): out[g][n] += sum_{r in seg g} X[r][n]; `out` is zeroed by the
+// caller (memset node on the same stream); row chunks are combined with fp32 L2 atomics.
+constexpr int COLSUM_SPLITS = 64;
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int ld, int N,
+                                                    const int32_t* __restrict__ offsets, int M,
+                                                    float* __restrict__ out) {
+  // grid: (ceil(N/64), COLSUM_SPLITS, groups); block 256 = 64 columns x 4 row lanes
+  const int g = blockIdx.z;
+  int r0 = 0, r1 = M;
+  if (offsets) {
+    r0 = offsets[g];
+    r1 = offsets[g + 1];
+  }
+  const int chunk = (r1 - r0 + COLSUM_SPLITS - 1) / COLSUM_SPLITS;
+  r0 += blockIdx.y * chunk;
+  r1 = min(r1, r0 + chunk);
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  float s = 0.f;
+  if (c < N)
+    for (int r = r0 + rl; r < r1; r += 4) s += X[(long)r * ld + c];
+  __shared__ float red[4][64];
+  red[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && c < N && r0 < r1) {
+    const float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    atomicAdd(out + (long)g * N + c, t);
+  }
+}
+
+template <int MODE>
+int launch_mode(const GemmParams& p, int epi, dim3 grid, hipStream_t st) {
+#define SM3_LAUNCH(E)                                                  \
+  case E:                                                              \
+    gemm_f32_kernel<MODE, E><<<grid, NTHREADS, 0, st>>>(p);            \
+    return SM3_OK;
+  switch (epi) {
+    SM3_LAUNCH(EPI_NONE)
+    SM3_LAUNCH(EPI_BIAS)
+    SM3_LAUNCH(EPI_BIAS_GELU)
+    SM3_LAUNCH(EPI_BIAS_SCALE_RES)
+    SM3_LAUNCH(EPI_GELU_BWD)
+  }
+#undef SM3_LAUNCH
+  return SM3_ERR_INVALID_ARG;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t sm3_gemm_f32_workspace_bytes(const sm3_gemm_desc* d) {
+  if (!d || d->mode != MODE_TN) return 0;
+  const int groups = d->num_groups > 0 ? d->num_groups : 1;
+  const int splits = d->splits > 0 ? d->splits : 1;
+  return (size_t)groups * splits * d->M * d->N * sizeof(float);
+}
+
+int sm3_gemm_f32(const sm3_gemm_desc* d, void* workspace, size_t workspace_bytes, sm3_stream_t stream) {
+  if (!d) return SM3_ERR_INVALID_ARG;
+  if (d->M < 0 || d->N <= 0 || d->K < 0) return SM3_ERR_INVALID_ARG;
+  if ((d->lda & 3) || (d->ldb & 3) || (d->N & 3)) return SM3_ERR_UNSUPPORTED;  // float4 loads
+  if (d->mode != MODE_TN && (d->K % BK) != 0) return SM3_ERR_UNSUPPORTED;
+  if (d->mode == MODE_TN && (d->M & 3)) return SM3_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  GemmParams p;
+  p.A = d->A; p.B = d->B; p.C = d->C;
+  p.M = d->M; p.N = d->N; p.K = d->K;
+  p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc;
+  p.offsets = d->group_offsets;
+  p.num_groups = d->num_groups > 0 ? d->num_groups : 1;
+  p.strideB = d->stride_b; p.strideBias = d->stride_bias;
+  p.strideC = (long)d->M * d->N;
+  p.splits = d->splits > 0 ? d->splits : 1;
+  p.bias = d->bias; p.aux_in = d->aux_in; p.aux_out = d->aux_out;
+  p.gamma = d->gamma; p.rowscale = d->rowscale;
+  p.rows_per_scale = d->rows_per_scale > 0 ? d->rows_per_scale : 1;
+  p.ld_aux = d->ld_aux;
+  const int ntn = (d->N + BN - 1) / BN;
+  if (d->mode == MODE_TN) {
+    if (d->epilogue != EPI_NONE) return SM3_ERR_INVALID_ARG;
+    const size_t need = sm3_gemm_f32_workspace_bytes(d);
+    if (!workspace || workspace_bytes < need) return SM3_ERR_WORKSPACE;
+    const int ntm = (d->M + BM - 1) / BM;
+    float* out = d->C;
+    p.C = (float*)workspace;
+    p.ldc = d->N;
+    dim3 grid(ntn * ntm, 1, p.num_groups * p.splits);
+    gemm_f32_kernel<MODE_TN, EPI_NONE><<<grid, NTHREADS, 0, st>>>(p);
+    const long mn = (long)d->M * d->N;
+    long nb = (mn * p.num_groups / 4 + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    if (nb < 1) nb = 1;
+    splitk_reduce_kernel<<<(int)nb, 256, 0, st>>>((const float*)workspace, out, mn, p.splits, p.num_groups);
+    return launch_status();
+  }
+  if (d->M == 0) return SM3_OK;
+  // ragged groups: at most ceil(M/BM) + G row tiles exist; surplus blocks exit
+  const int ntm = (d->M + BM - 1) / BM + (d->group_offsets ? p.num_groups : 0);
+  dim3 grid(ntn * ntm, 1, 1);
+  int rc;
+  if (d->mode == MODE_NT) rc = launch_mode<MODE_NT>(p, d->epilogue, grid, st);
+  else if (d->mode == MODE_NN) rc = launch_mode<MODE_NN>(p, d->epilogue, grid, st);
+  else return SM3_ERR_INVALID_ARG;
+  return rc ? rc : launch_status();
+}
+
+int sm3_colsum_f32(const float* x, int ld, int m, int n, const int32_t* group_offsets, int num_groups, float* out,
+                   sm3_stream_t stream) {
+  if (n <= 0 || m < 0 || !x || !out) return SM3_ERR_INVALID_ARG;
+  const int groups = group_offsets ? num_groups : 1;
+  dim3 grid((n + 63) / 64, COLSUM_SPLITS, groups);
+  (void)hipMemsetAsync(out, 0, sizeof(float) * (size_t)groups * n, (hipStream_t)stream);
+  colsum_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, ld, n, group_offsets, m, out);
+  return launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,156 @@
+"""GPU tier: fp32 MFMA GEMM family vs a plain PyTorch fp32/fp64 reference of the same contraction.
+Tolerance: |d| <= 2e-5 * sum|a||b| scale (f32 FMA chain, K up to 3072) -- asserted as rtol 1e-4 on fp64 reference."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _mods():
+    from sm3det_amd import _lib_backbone as LB
+    return LB
+
+
+def _rand(*shape, seed=0):
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    return torch.randn(*shape, generator=g).cuda()
+
+
+def _close(a, ref64, tol=1e-4):
+    err = (a.double() - ref64).abs().max().item()
+    scale = ref64.abs().max().item() + 1e-12
+    assert err <= tol * scale, (err, scale)
+
+
+@pytest.mark.parametrize('M,N,K', [(1000, 384, 96), (4096, 96, 384), (513, 768, 192), (128, 128, 64), (77, 3072, 768)])
+def test_nt_bias(M, N, K):
+    LB = _mods()
+    A, B, bias = _rand(M, K, seed=1), _rand(N, K, seed=2), _rand(N, seed=3)
+    C = torch.empty(M, N, device='cuda')
+    LB.gemm(LB.NT, A, B, C, M, N, K, epilogue=LB.EPI_BIAS, bias=bias)
+    _close(C, A.double() @ B.double().t() + bias.double())
+    C2 = torch.full((M, N), float('nan'), device='cuda')
+    LB.gemm(LB.NT, A, B, C2, M, N, K)
+    _close(C2, A.double() @ B.double().t())
+
+
+def test_nt_asymmetric_identity():
+    """transpose-detecting check: A = I, asymmetric B."""
+    LB = _mods()
+    K = 128
+    A = torch.eye(K, device='cuda')
+    B = (torch.arange(256 * K, device='cuda', dtype=torch.float32).reshape(256, K) % 97) * 0.25
+    C = torch.empty(K, 256, device='cuda')
+    LB.gemm(LB.NT, A, B, C, K, 256, K)
+    assert torch.equal(C, B.t().contiguous())
+
+
+@pytest.mark.parametrize('M,N,K', [(1000, 96, 384), (2048, 384, 96), (300, 192, 768)])
+def test_nn(M, N, K):
+    LB = _mods()
+    A, B = _rand(M, K, seed=4), _rand(K, N, seed=5)
+    C = torch.empty(M, N, device='cuda')
+    LB.gemm(LB.NN, A, B, C, M, N, K)
+    _close(C, A.double() @ B.double())
+
+
+@pytest.mark.parametrize('Kt,M,N,splits', [(5000, 96, 384, 8), (4096, 384, 96, 4), (1000, 768, 192, 1), (70, 128, 128, 3)])
+def test_tn_splitk(Kt, M, N, splits):
+    LB = _mods()
+    A, B = _rand(Kt, M, seed=6), _rand(Kt, N, seed=7)
+    C = torch.empty(M, N, device='cuda')
+    LB.gemm(LB.TN, A, B, C, M, N, Kt, splits=splits)
+    _close(C, A.double().t() @ B.double())
+
+
+def test_epilogues():
+    LB = _mods()
+    M, N, K = 700, 384, 96
+    A, B, bias = _rand(M, K, seed=8), _rand(N, K, seed=9) * 0.2, _rand(N, seed=10)
+    hpre = torch.empty(M, N, device='cuda')
+    act = torch.empty(M, N, device='cuda')
+    LB.gemm(LB.NT, A, B, act, M, N, K, epilogue=LB.EPI_BIAS_GELU, bias=bias, aux_out=hpre)
+    h64 = A.double() @ B.double().t() + bias.double()
+    _close(hpre, h64)
+    _close(act, torch.nn.functional.gelu(h64), tol=2e-4)
+    # scale + residual (+ per-image stochastic-depth scale)
+    M2, N2, K2 = 512, 96, 384
+    A2, B2, b2 = _rand(M2, K2, seed=11), _rand(N2, K2, seed=12) * 0.1, _rand(N2, seed=13)
+    res, gamma = _rand(M2, N2, seed=14), _rand(N2, seed=15)
+    rs = torch.tensor([0.0, 1.0 / 0.9], device='cuda')
+    y = torch.empty(M2, N2, device='cuda')
+    out = torch.empty(M2, N2, device='cuda')
+    LB.gemm(LB.NT, A2, B2, out, M2, N2, K2, epilogue=LB.EPI_BIAS_SCALE_RES, bias=b2, aux_in=res, aux_out=y,
+            gamma=gamma, rowscale=rs, rows_per_scale=256)
+    y64 = A2.double() @ B2.double().t() + b2.double()
+    _close(y, y64)
+    sc = rs.double().repeat_interleave(256)[:, None] * gamma.double()[None]
+    _close(out, res.double() + sc * y64)
+    # dgrad through GELU
+    dY, W = _rand(M, K, seed=16), _rand(K, N, seed=17) * 0.2
+    dH = torch.empty(M, N, device='cuda')
+    LB.gemm(LB.NN, dY, W, dH, M, N, K, epilogue=LB.EPI_GELU_BWD, aux_in=hpre)
+    h = hpre.double().requires_grad_(True)
+    torch.nn.functional.gelu(h).backward(dY.double() @ W.double())
+    _close(dH, h.grad, tol=2e-4)
+
+
+@pytest.mark.parametrize('E,counts', [(8, [300, 0, 129, 1, 128, 500, 64, 7]), (16, [40] * 16), (4, [0, 0, 0, 1000])])
+def test_grouped(E, counts):
+    LB = _mods()
+    C_, Hd = 96, 384
+    S = sum(counts)
+    offs = torch.tensor(np.concatenate([[0], np.cumsum(counts)]), dtype=torch.int32, device='cuda')
+    X = _rand(S, C_, seed=20)
+    W1 = _rand(E, Hd, C_, seed=21) * 0.1
+    b1 = _rand(E, Hd, seed=22)
+    hpre = torch.zeros(S, Hd, device='cuda')
+    act = torch.zeros(S, Hd, device='cuda')
+    LB.gemm(LB.NT, X, W1, act, S, Hd, C_, epilogue=LB.EPI_BIAS_GELU, bias=b1, aux_out=hpre, offsets=offs,
+            num_groups=E)
+    ref = torch.cat([X[offs[e]:offs[e + 1]].double() @ W1[e].double().t() + b1[e].double() for e in range(E)])
+    _close(hpre, ref)
+    # grouped dgrad NN: dX = dH @ W1  (W1[e] is (Hd,C) = K x N)
+    dH = _rand(S, Hd, seed=23)
+    dX = torch.zeros(S, C_, device='cuda')
+    LB.gemm(LB.NN, dH, W1, dX, S, C_, Hd, offsets=offs, num_groups=E)
+    ref = torch.cat([dH[offs[e]:offs[e + 1]].double() @ W1[e].double() for e in range(E)])
+    _close(dX, ref)
+    # grouped wgrad TN: dW1[e] = dH_e^T @ X_e  (every expert gets a, possibly zero, gradient)
+    dW = torch.full((E, Hd, C_), float('nan'), device='cuda')
+    LB.gemm(LB.TN, dH, X, dW, Hd, C_, S, offsets=offs, num_groups=E, splits=4)
+    ref = torch.stack([dH[offs[e]:offs[e + 1]].double().t() @ X[offs[e]:offs[e + 1]].double() for e in range(E)])
+    _close(dW, ref)
+    # grouped bias grad
+    db = torch.empty(E, Hd, device='cuda')
+    LB.colsum(dH, S, Hd, db, offsets=offs, num_groups=E)
+    ref = torch.stack([dH[offs[e]:offs[e + 1]].double().sum(0) for e in range(E)])
+    _close(db, ref)
+
+
+def test_gemm_throughput_report():
+    """Not a pass/fail perf gate; prints achieved fp32 MFMA TFLOP/s for the stage-2 expert shape."""
+    LB = _mods()
+    M, N, K = 16384, 1536, 384
+    A, B = _rand(M, K, seed=30), _rand(N, K, seed=31)
+    C = torch.empty(M, N, device='cuda')
+    for _ in range(3):
+        LB.gemm(LB.NT, A, B, C, M, N, K)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        LB.gemm(LB.NT, A, B, C, M, N, K)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 20
+    print(f'\ngemm NT {M}x{N}x{K}: {ms * 1e3:.1f} us, {2 * M * N * K / ms / 1e9:.1f} TFLOP/s fp32 (peak 157.3)')
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record()
+    for _ in range(20):
+        torch.matmul(A, B.t(), out=C)
+    t1.record()
+    torch.cuda.synchronize()
+    ms2 = t0.elapsed_time(t1) / 20
+    print(f'torch.matmul (rocBLAS/hipBLASLt) same shape: {ms2 * 1e3:.1f} us, {2 * M * N * K / ms2 / 1e9:.1f} TFLOP/s')
