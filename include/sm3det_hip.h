@@ -145,6 +145,75 @@ int sm3_gemm_f32(const sm3_gemm_desc* desc, void* workspace, size_t workspace_by
 int sm3_colsum_f32(const float* x, int ld, int m, int n, const int32_t* group_offsets, int num_groups, float* out,
                    sm3_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * Stem: Conv2d(3,C0,k=4,s=4) (convnext_moe.py:783-791) as patchify + NT GEMM.  x (B,3,H,W) NCHW ->
+ * a (B*H/4*W/4, 64), columns c*16+kh*4+kw (= weight.view(C0,48) order), columns 48..63 zero. */
+int sm3_stem_patchify(const float* x, float* a, int B, int H, int W, sm3_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * LayerNorm over the channel dim of token rows (LayerNorm2d, convnext_moe.py:30-47; block norm :351).
+ * out_mode 0: y[t] ; out_mode 1: patch-major rows feeding the 2x2/s2 downsample conv (:549-556) as one GEMM.
+ * mean/rstd (T) are saved for the backward (may be NULL).  bwd: dwdb = [dw (C) | db (C)], overwritten;
+ * accumulate_dx != 0 adds into dx. */
+int sm3_layernorm_fwd(const float* x, const float* w, const float* b, float eps, float* y, float* mean, float* rstd,
+                      long T, int C, int out_mode, int H, int W, sm3_stream_t stream);
+int sm3_layernorm_bwd(const float* dy, const float* x, const float* w, const float* mean, const float* rstd,
+                      float* dx, float* dwdb, long T, int C, int out_mode, int H, int W, int accumulate_dx,
+                      sm3_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Depthwise 7x7, padding 3 (ConvNeXtBlock.depthwise_conv, convnext_moe.py:311-312,347) on NHWC tokens.
+ * w49 (49,C) = weight (C,1,7,7) permuted to tap-major; y = conv(x) + bias (+ addend).  The input gradient is the
+ * same kernel with the taps reversed (w49 flipped along dim 0) and addend = the residual branch gradient.
+ * bwd_weight: dw49 (49,C) and dbias (C) overwritten. */
+int sm3_dwconv7_fwd(const float* x, const float* w49, const float* bias, const float* addend, float* y, int B, int H,
+                    int W, int C, sm3_stream_t stream);
+int sm3_dwconv7_bwd_weight(const float* x, const float* du, float* dw49, float* dbias, int B, int H, int W, int C,
+                           sm3_stream_t stream);
+
+/* layer-scale / stochastic-depth backward of a dense block (:368-370): dy = gamma*rs[b]*dout ;
+ * dgamma[c] = sum_t rs[b]*dout[t,c]*y[t,c]  (overwritten) */
+int sm3_scale_bwd_prep(const float* dout, const float* y, const float* gamma, const float* rowscale,
+                       int rows_per_scale, float* dy, float* dgamma, long T, int C, sm3_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * MoE router (CosineTopKGate.forward :99-106 + noisy_top_k_gating :194-223 + _prob_in_top_k :152-174).
+ * hcat (T, ldh) rows = [h = x.Wp^T+bp (P) | raw = x.Wn (E) | pad]; snorm (P,E) = F.normalize(sim_matrix, dim=0);
+ * scale = device scalar exp(min(temperature, ln 100)); noise (T,E) ~ N(0,1) (train) or NULL.
+ * Outputs: top_idx/top_val (T, m=min(k+1,E)) descending; gates (T,k) = softmax(top k); clean (T,E); sigma (T,E)
+ * (train); hnorm (T); partials (ceil(T/256), 2E) = per-block [importance | load] sums (sum over dim 0 = totals). */
+int sm3_moe_router_fwd(const float* hcat, int ldh, int P, const float* snorm, const float* scale, const float* noise,
+                       int T, int E, int k, int train, int32_t* top_idx, float* top_val, float* gates, float* clean,
+                       float* sigma, float* hnorm, float* partials, sm3_stream_t stream);
+/* backward: dgate (T,k) from the combine, dimp/dload (E) from the aux loss.  Writes dhcat (T,ldh) = [dh | draw | 0],
+ * dcn (T,E) = dclean/max(|h|,eps) and ds_part (ceil(T/256)) partial sums of d(scale). */
+int sm3_moe_router_bwd(const float* hcat, int ldh, int P, const float* snorm, const float* scale, const float* noise,
+                       int T, int E, int k, int train, const int32_t* top_idx, const float* top_val,
+                       const float* gates, const float* clean, const float* sigma, const float* hnorm,
+                       const float* dgate, const float* dimp, const float* dload, float* dhcat, float* dcn,
+                       float* ds_part, sm3_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * SparseDispatcher (:250-293) without the host sync: expert-major slot tables from the top-k indices.
+ * offsets (E+1) prefix of slots per expert; slot_token (T*k) token of each slot; token_slot (T,k) slot of each
+ * (token, j).  Slot order inside an expert = (token, j) order (deterministic). */
+size_t sm3_moe_plan_workspace_bytes(int T, int E);
+int sm3_moe_plan(const int32_t* top_idx, int m, int T, int E, int k, int32_t* offsets, int32_t* slot_token,
+                 int32_t* token_slot, void* workspace, size_t workspace_bytes, sm3_stream_t stream);
+/* dispatch (:264-266): xslot[s] = x[slot_token[s]] */
+int sm3_moe_dispatch(const float* x, const int32_t* slot_token, float* xslot, long S, int C, sm3_stream_t stream);
+/* combine (:269-284) fused with layer scale + residual (:368-370):
+ * out[t] = shortcut[t] + gamma*rs[b]*sum_j gates[t,j]*yslot[token_slot[t,j]] */
+int sm3_moe_combine_fwd(const float* yslot, const int32_t* token_slot, const float* gates, const float* shortcut,
+                        const float* gamma, const float* rowscale, int rows_per_scale, float* out, long T, int C,
+                        int k, sm3_stream_t stream);
+int sm3_moe_combine_bwd(const float* dout, const float* yslot, const int32_t* token_slot, const float* gates,
+                        const float* gamma, const float* rowscale, int rows_per_scale, float* dyslot, float* dgate,
+                        float* dgamma, long T, int C, int k, sm3_stream_t stream);
+/* dx[t] (+)= sum_j dxslot[token_slot[t,j]]  (backward of dispatch) */
+int sm3_moe_gather_add(const float* dxslot, const int32_t* token_slot, float* dx, long T, int C, int k,
+                       int accumulate, sm3_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

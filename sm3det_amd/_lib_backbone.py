@@ -26,11 +26,34 @@ class GemmDesc(ctypes.Structure):
 
 def signatures():
     D = ctypes.POINTER(GemmDesc)
+    LL = ctypes.c_long
     return {
         'sm3_gemm_f32_workspace_bytes': (S, [D]),
         'sm3_gemm_f32': (I, [D, P, S, P]),
         'sm3_colsum_f32': (I, [P, I, I, I, P, I, P, P]),
+        'sm3_stem_patchify': (I, [P, P, I, I, I, P]),
+        'sm3_layernorm_fwd': (I, [P, P, P, F, P, P, P, LL, I, I, I, I, P]),
+        'sm3_layernorm_bwd': (I, [P, P, P, P, P, P, P, LL, I, I, I, I, I, P]),
+        'sm3_dwconv7_fwd': (I, [P, P, P, P, P, I, I, I, I, P]),
+        'sm3_dwconv7_bwd_weight': (I, [P, P, P, P, I, I, I, I, P]),
+        'sm3_scale_bwd_prep': (I, [P, P, P, P, I, P, P, LL, I, P]),
+        'sm3_moe_router_fwd': (I, [P, I, I, P, P, P, I, I, I, I, P, P, P, P, P, P, P, P]),
+        'sm3_moe_router_bwd': (I, [P, I, I, P, P, P, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+        'sm3_moe_plan_workspace_bytes': (S, [I, I]),
+        'sm3_moe_plan': (I, [P, I, I, I, I, P, P, P, P, S, P]),
+        'sm3_moe_dispatch': (I, [P, P, P, LL, I, P]),
+        'sm3_moe_combine_fwd': (I, [P, P, P, P, P, P, I, P, LL, I, I, P]),
+        'sm3_moe_combine_bwd': (I, [P, P, P, P, P, P, I, P, P, P, LL, I, I, P]),
+        'sm3_moe_gather_add': (I, [P, P, P, LL, I, I, I, P]),
     }
+
+
+def call(name, *args):
+    """Invoke `sm3_<name>` with tensors converted to device pointers and the current stream appended."""
+    from . import _lib
+    L = _lib.lib()
+    conv = [(_p(a) if (a is None or isinstance(a, torch.Tensor)) else a) for a in args]
+    _lib.check(getattr(L, 'sm3_' + name)(*conv, _lib.stream_ptr()), name)
 
 
 def _p(t):

@@ -1,0 +1,290 @@
+"""Autograd bindings of the backbone kernels (host orchestration only -- every FLOP and byte of activation
+traffic happens in libsm3det_hip.so through the C ABI).
+
+Each ``torch.autograd.Function`` below is one unit of the reference's backbone
+(mmrotate/models/backbones/convnext_moe.py) with a hand-written backward:
+
+* ``linear``           nn.Linear / the stem and downsample convs as patch GEMMs (:533-558, :783-791)
+* ``layer_norm``       LayerNorm2d / block norm (:30-47, :351), optionally writing patch-major rows
+* ``dense_block``      ConvNeXtBlock._inner_forward with a dense FFN (:343-372, :397-405)
+* ``moe_block``        ConvNeXtBlock._inner_forward with MoE_layer (:226-248): gate, noisy top-k, dispatch,
+                       grouped expert GEMMs, combine -- returns (out, importance, load)
+
+Activations are token-major (T, C) fp32.  No host synchronisation happens anywhere in here.
+"""
+import torch
+from torch.autograd import Function
+
+from . import _lib_backbone as LB
+from ._lib import SM3Error
+
+call, gemm, colsum = LB.call, LB.gemm, LB.colsum
+
+
+def _e(*shape, like, dtype=None):
+    return torch.empty(*shape, device=like.device, dtype=dtype or torch.float32)
+
+
+def _chk(t, name):
+    if t.dtype != torch.float32 or not t.is_cuda:
+        raise SM3Error(f'{name}: expected a float32 tensor on the GPU (got {t.dtype} on {t.device}); '
+                       'there is no CPU/eager fallback')
+    return t.contiguous()
+
+
+def _tn(dy, x, M, N, rows, **kw):
+    """dW[M,N] = dy[rows,M]^T @ x[rows,N] (split-K)."""
+    groups = kw.get('num_groups', 1)
+    out = _e(groups, M, N, like=dy) if groups > 1 or kw.get('offsets') is not None else _e(M, N, like=dy)
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    splits = LB.tn_splits(tiles * groups, max(rows // groups, 1))
+    gemm(LB.TN, dy, x, out, M, N, rows, splits=splits, **kw)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ linear
+class _Linear(Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x, w, b = _chk(x, 'x'), _chk(w, 'w'), _chk(b, 'b')
+        M, K = x.shape
+        N = w.shape[0]
+        y = _e(M, N, like=x)
+        gemm(LB.NT, x, w, y, M, N, K, epilogue=LB.EPI_BIAS, bias=b)
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        M, K = x.shape
+        N = w.shape[0]
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _e(M, K, like=x)
+            gemm(LB.NN, dy, w, dx, M, K, N)
+        dw = _tn(dy, x, N, K, M)
+        db = _e(N, like=x)
+        colsum(dy, M, N, db)
+        return dx, dw, db
+
+
+def linear(x, w, b):
+    """y = x @ w^T + b on the fp32 matrix cores; K (= x.shape[1]) must be a multiple of 32."""
+    return _Linear.apply(x, w, b)
+
+
+def stem_patchify(x):
+    """(B,3,H,W) NCHW image -> (B*H/4*W/4, 64) patch rows (no gradient: the image is a leaf input)."""
+    x = _chk(x, 'image')
+    B, Cin, H, W = x.shape
+    if Cin != 3:
+        raise SM3Error('stem_patchify expects 3 input channels')
+    a = _e(B * (H // 4) * (W // 4), 64, like=x)
+    call('stem_patchify', x, a, B, H, W)
+    return a
+
+
+# ------------------------------------------------------------------------------------------------ layer norm
+class _LayerNorm(Function):
+    @staticmethod
+    def forward(ctx, x, w, b, eps, mode, H, W):
+        x, w, b = _chk(x, 'x'), _chk(w, 'w'), _chk(b, 'b')
+        T, C = x.shape
+        y = _e(T // 4, 4 * C, like=x) if mode == 1 else _e(T, C, like=x)
+        mean, rstd = _e(T, like=x), _e(T, like=x)
+        call('layernorm_fwd', x, w, b, float(eps), y, mean, rstd, T, C, mode, H, W)
+        ctx.save_for_backward(x, w, mean, rstd)
+        ctx.meta = (mode, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, mean, rstd = ctx.saved_tensors
+        mode, H, W = ctx.meta
+        T, C = x.shape
+        dx = _e(T, C, like=x)
+        dwdb = _e(2, C, like=x)
+        call('layernorm_bwd', dy.contiguous(), x, w, mean, rstd, dx, dwdb, T, C, mode, H, W, 0)
+        return dx, dwdb[0], dwdb[1], None, None, None, None
+
+
+def layer_norm(x, w, b, eps, patch_major=False, H=0, W=0):
+    return _LayerNorm.apply(x, w, b, eps, 1 if patch_major else 0, H, W)
+
+
+# ------------------------------------------------------------------------------------------------ shared block pieces
+def _dw_ln_forward(x, w49, bdw, lnw, lnb, eps, B, H, W, C):
+    T = B * H * W
+    u = _e(T, C, like=x)
+    call('dwconv7_fwd', x, w49, bdw, None, u, B, H, W, C)
+    xn = _e(T, C, like=x)
+    mean, rstd = _e(T, like=x), _e(T, like=x)
+    call('layernorm_fwd', u, lnw, lnb, float(eps), xn, mean, rstd, T, C, 0, H, W)
+    return u, xn, mean, rstd
+
+
+def _dw_ln_backward(dxn, dout, x, u, w49, lnw, mean, rstd, B, H, W, C):
+    """dxn: grad wrt the LN output; dout: grad wrt the block output (residual branch).  Returns
+    dx, dw49, dbdw, dlnw, dlnb."""
+    T = B * H * W
+    du = _e(T, C, like=x)
+    dwdb = _e(2, C, like=x)
+    call('layernorm_bwd', dxn, u, lnw, mean, rstd, du, dwdb, T, C, 0, H, W, 0)
+    dx = _e(T, C, like=x)
+    call('dwconv7_fwd', du, w49.flip(0).contiguous(), None, dout, dx, B, H, W, C)
+    dw49, dbdw = _e(49, C, like=x), _e(C, like=x)
+    call('dwconv7_bwd_weight', x, du, dw49, dbdw, B, H, W, C)
+    return dx, dw49, dbdw, dwdb[0], dwdb[1]
+
+
+# ------------------------------------------------------------------------------------------------ dense block
+class _DenseBlock(Function):
+    @staticmethod
+    def forward(ctx, x, w49, bdw, lnw, lnb, w1, b1, w2, b2, gamma, rs, eps, B, H, W):
+        x = _chk(x, 'x')
+        T, C = x.shape
+        Hd = w1.shape[0]
+        u, xn, mean, rstd = _dw_ln_forward(x, w49, bdw, lnw, lnb, eps, B, H, W, C)
+        hpre, act = _e(T, Hd, like=x), _e(T, Hd, like=x)
+        gemm(LB.NT, xn, w1, act, T, Hd, C, epilogue=LB.EPI_BIAS_GELU, bias=b1, aux_out=hpre)
+        y, out = _e(T, C, like=x), _e(T, C, like=x)
+        gemm(LB.NT, act, w2, out, T, C, Hd, epilogue=LB.EPI_BIAS_SCALE_RES, bias=b2, aux_in=x, aux_out=y,
+             gamma=gamma, rowscale=rs, rows_per_scale=H * W)
+        ctx.save_for_backward(x, u, mean, rstd, xn, hpre, act, y, w49, lnw, w1, w2, gamma, rs)
+        ctx.meta = (B, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, u, mean, rstd, xn, hpre, act, y, w49, lnw, w1, w2, gamma, rs = ctx.saved_tensors
+        B, H, W = ctx.meta
+        T, C = x.shape
+        Hd = w1.shape[0]
+        dout = dout.contiguous()
+        dy, dgamma = _e(T, C, like=x), _e(C, like=x)
+        call('scale_bwd_prep', dout, y, gamma, rs, H * W, dy, dgamma, T, C)
+        db2 = _e(C, like=x)
+        colsum(dy, T, C, db2)
+        dw2 = _tn(dy, act, C, Hd, T)
+        dh = _e(T, Hd, like=x)
+        gemm(LB.NN, dy, w2, dh, T, Hd, C, epilogue=LB.EPI_GELU_BWD, aux_in=hpre)
+        db1 = _e(Hd, like=x)
+        colsum(dh, T, Hd, db1)
+        dw1 = _tn(dh, xn, Hd, C, T)
+        dxn = dy  # reuse the (T,C) buffer
+        gemm(LB.NN, dh, w1, dxn, T, C, Hd)
+        dx, dw49, dbdw, dlnw, dlnb = _dw_ln_backward(dxn, dout, x, u, w49, lnw, mean, rstd, B, H, W, C)
+        return dx, dw49, dbdw, dlnw, dlnb, dw1, db1, dw2, db2, dgamma, None, None, None, None, None
+
+
+def dense_block(x, w49, bdw, lnw, lnb, w1, b1, w2, b2, gamma, rs, eps, B, H, W):
+    return _DenseBlock.apply(x, w49, bdw, lnw, lnb, w1, b1, w2, b2, gamma, rs, eps, B, H, W)
+
+
+# ------------------------------------------------------------------------------------------------ MoE block
+class _MoEBlock(Function):
+    @staticmethod
+    def forward(ctx, x, w49, bdw, lnw, lnb, wcat, bcat, snorm, scale, w1, b1, w2, b2, gamma, rs, noise, eps, B, H,
+                W, P, k, train):
+        x = _chk(x, 'x')
+        T, C = x.shape
+        E, Hd = w1.shape[0], w1.shape[1]
+        PC = wcat.shape[0]
+        m = min(k + 1, E)
+        S = T * k
+        u, xn, mean, rstd = _dw_ln_forward(x, w49, bdw, lnw, lnb, eps, B, H, W, C)
+        # gate projection (+ noise projection) in one GEMM: hcat = [h | raw | 0]
+        hcat = _e(T, PC, like=x)
+        gemm(LB.NT, xn, wcat, hcat, T, PC, C, epilogue=LB.EPI_BIAS, bias=bcat)
+        top_idx = _e(T, m, like=x, dtype=torch.int32)
+        top_val, gates = _e(T, m, like=x), _e(T, k, like=x)
+        clean, hnorm = _e(T, E, like=x), _e(T, like=x)
+        sigma = _e(T, E, like=x) if train else None
+        nblk = (T + 255) // 256
+        partials = _e(nblk, 2 * E, like=x)
+        call('moe_router_fwd', hcat, PC, P, snorm, scale, noise, T, E, k, int(train), top_idx, top_val, gates,
+             clean, sigma, hnorm, partials)
+        tot = partials.sum(0)
+        importance, load = tot[:E], tot[E:]
+        # dispatch tables (no host sync)
+        offsets = _e(E + 1, like=x, dtype=torch.int32)
+        slot_token = _e(S, like=x, dtype=torch.int32)
+        token_slot = _e(T, k, like=x, dtype=torch.int32)
+        from . import _lib
+        nb = _lib.lib().sm3_moe_plan_workspace_bytes(T, E)
+        ws = _lib.workspace(nb, x.device)
+        call('moe_plan', top_idx, m, T, E, k, offsets, slot_token, token_slot, ws, nb)
+        xslot = _e(S, C, like=x)
+        call('moe_dispatch', xn, slot_token, xslot, S, C)
+        # experts: grouped GEMM pair over the expert-major slots
+        hpre, act = _e(S, Hd, like=x), _e(S, Hd, like=x)
+        gemm(LB.NT, xslot, w1, act, S, Hd, C, epilogue=LB.EPI_BIAS_GELU, bias=b1, aux_out=hpre, offsets=offsets,
+             num_groups=E)
+        yslot = _e(S, C, like=x)
+        gemm(LB.NT, act, w2, yslot, S, C, Hd, epilogue=LB.EPI_BIAS, bias=b2, offsets=offsets, num_groups=E)
+        out = _e(T, C, like=x)
+        call('moe_combine_fwd', yslot, token_slot, gates, x, gamma, rs, H * W, out, T, C, k)
+        ctx.save_for_backward(x, u, mean, rstd, xn, hcat, top_idx, top_val, gates, clean, sigma, hnorm, offsets,
+                              token_slot, xslot, hpre, act, yslot, w49, lnw, wcat, snorm, scale, w1, w2, gamma, rs,
+                              noise)
+        ctx.meta = (B, H, W, P, k, train)
+        ctx.mark_non_differentiable(offsets)
+        return out, importance, load, offsets
+
+    @staticmethod
+    def backward(ctx, dout, dimp, dload, _doff):
+        (x, u, mean, rstd, xn, hcat, top_idx, top_val, gates, clean, sigma, hnorm, offsets, token_slot, xslot, hpre,
+         act, yslot, w49, lnw, wcat, snorm, scale, w1, w2, gamma, rs, noise) = ctx.saved_tensors
+        B, H, W, P, k, train = ctx.meta
+        T, C = x.shape
+        E, Hd = w1.shape[0], w1.shape[1]
+        PC = wcat.shape[0]
+        S = T * k
+        dout = dout.contiguous()
+        dimp = torch.zeros(E, device=x.device) if dimp is None else dimp.contiguous().float()
+        dload = torch.zeros(E, device=x.device) if dload is None else dload.contiguous().float()
+        # combine backward
+        dyslot, dgate, dgamma = _e(S, C, like=x), _e(T, k, like=x), _e(C, like=x)
+        call('moe_combine_bwd', dout, yslot, token_slot, gates, gamma, rs, H * W, dyslot, dgate, dgamma, T, C, k)
+        # experts backward (every expert gets a -- possibly zero -- gradient: DDP-safe)
+        db2 = _e(E, C, like=x)
+        colsum(dyslot, S, C, db2, offsets=offsets, num_groups=E)
+        dw2 = _tn(dyslot, act, C, Hd, S, offsets=offsets, num_groups=E)
+        dh = _e(S, Hd, like=x)
+        gemm(LB.NN, dyslot, w2, dh, S, Hd, C, epilogue=LB.EPI_GELU_BWD, aux_in=hpre, offsets=offsets, num_groups=E)
+        db1 = _e(E, Hd, like=x)
+        colsum(dh, S, Hd, db1, offsets=offsets, num_groups=E)
+        dw1 = _tn(dh, xslot, Hd, C, S, offsets=offsets, num_groups=E)
+        dxslot = dyslot  # reuse
+        gemm(LB.NN, dh, w1, dxslot, S, C, Hd, offsets=offsets, num_groups=E)
+        # router backward
+        nblk = (T + 255) // 256
+        dhcat, dcn, ds_part = _e(T, PC, like=x), _e(T, E, like=x), _e(nblk, like=x)
+        call('moe_router_bwd', hcat, PC, P, snorm, scale, noise, T, E, k, int(train), top_idx, top_val, gates, clean,
+             sigma, hnorm, dgate, dimp, dload, dhcat, dcn, ds_part)
+        dscale = ds_part.sum().reshape(scale.shape)
+        if E % 4 == 0:
+            dsn = _e(P, E, like=x)
+            tiles = (P + 127) // 128
+            gemm(LB.TN, hcat, dcn, dsn, P, E, T, lda=PC, ldb=E, splits=LB.tn_splits(tiles, T))
+        else:  # tiny (P x E) product; E not a multiple of the 16-byte vector width
+            dsn = hcat[:, :P].t() @ dcn
+        dsnorm = dsn * scale
+        dwcat = _tn(dhcat, xn, PC, C, T)
+        dbcat = _e(PC, like=x)
+        colsum(dhcat, T, PC, dbcat)
+        dxn = _e(T, C, like=x)
+        gemm(LB.NN, dhcat, wcat, dxn, T, C, PC)
+        call('moe_gather_add', dxslot, token_slot, dxn, T, C, k, 1)
+        dx, dw49, dbdw, dlnw, dlnb = _dw_ln_backward(dxn, dout, x, u, w49, lnw, mean, rstd, B, H, W, C)
+        return (dx, dw49, dbdw, dlnw, dlnb, dwcat, dbcat, dsnorm, dscale, dw1, db1, dw2, db2, dgamma, None, None,
+                None, None, None, None, None, None, None)
+
+
+def moe_block(x, w49, bdw, lnw, lnb, wcat, bcat, snorm, scale, w1, b1, w2, b2, gamma, rs, noise, eps, B, H, W, P, k,
+              train):
+    """Returns (out (T,C), importance (E), load (E), expert slot offsets (E+1, int32, non-differentiable))."""
+    return _MoEBlock.apply(x, w49, bdw, lnw, lnb, wcat, bcat, snorm, scale, w1, b1, w2, b2, gamma, rs, noise, eps, B,
+                           H, W, P, k, train)

@@ -1,0 +1,1035 @@
+// backbone.hip -- the non-GEMM kernels of the SM3Det grid-level sparse-MoE ConvNeXt backbone on gfx950.
+//
+// Reference semantics (mmrotate/models/backbones/convnext_moe.py): LayerNorm2d :30-47, ConvNeXtBlock :343-372
+// (depthwise 7x7 :347, LN :351, layer scale :368, residual :370), CosineTopKGate :99-106, noisy_top_k_gating
+// :194-223, _prob_in_top_k :152-174, SparseDispatcher :250-293.  All activations are token-major (T, C) float32
+// (= NHWC); HBM-bound kernels read/write 16 B per lane with lanes running over channels (coalesced), reductions
+// stay inside a (sub-)wavefront, and nothing on this path synchronises with the host (the reference's
+// `SparseDispatcher` does `.cpu()` per MoE block, :259).
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ float hsum4(f32x4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }
+
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ============================================================================================== stem patchify
+// x (B,3,H,W) NCHW -> a (B*H/4*W/4, 64): column c*16 + kh*4 + kw for c < 3 (= Conv2d(3,C0,4,4).weight.view(C0,48)
+// order), columns 48..63 zero (K padded to the GEMM's BK multiple).
+__global__ void stem_patchify_kernel(const float* __restrict__ x, float* __restrict__ a, int B, int H, int W) {
+  const int Ho = H / 4, Wo = W / 4;
+  const long total = (long)B * Ho * Wo * 16;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int q = idx & 15;  // c*4 + kh, 12..15 = zero pad
+    const long tok = idx >> 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (q < 12) {
+      const int c = q >> 2, kh = q & 3;
+      const int wo = tok % Wo;
+      const long t2 = tok / Wo;
+      const int ho = t2 % Ho;
+      const int b = t2 / Ho;
+      v = ld4(x + (((long)b * 3 + c) * H + (4 * ho + kh)) * W + 4 * wo);
+    }
+    st4(a + tok * 64 + q * 4, v);
+  }
+}
+
+// ============================================================================================== LayerNorm rows
+// out_mode 0: y row = token; 1: patch-major rows for the 2x2/s2 downsample conv: token (b,h,w) -> row
+// (b,h/2,w/2), column block ((h&1)*2 + (w&1))*C  (so the conv becomes one NT GEMM with K = 4C).
+__device__ __forceinline__ long ln_out_offset(long tok, int C, int mode, int H, int W) {
+  if (mode == 0) return tok * C;
+  const int w = tok % W;
+  const long t2 = tok / W;
+  const int h = t2 % H;
+  const long b = t2 / H;
+  const long row = (b * (H / 2) + (h >> 1)) * (W / 2) + (w >> 1);
+  return row * (4L * C) + (long)(((h & 1) << 1) | (w & 1)) * C;
+}
+
+template <int G, int NV>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ b, float eps,
+                                                           float* __restrict__ y, float* __restrict__ mean_o,
+                                                           float* __restrict__ rstd_o, long T, int C, int mode, int H,
+                                                           int W) {
+  constexpr int TPW = 64 / G;
+  const int lane = threadIdx.x & 63;
+  const int lg = lane % G, tg = lane / G;
+  const long wave = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const long nwaves = (long)gridDim.x * (blockDim.x >> 6);
+  const int nq = C >> 2;
+  for (long t0 = wave * TPW; t0 < T; t0 += nwaves * TPW) {
+    const long tok = t0 + tg;
+    const bool tv = tok < T;
+    f32x4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+      const int q = lg + i * G;
+      v[i] = (tv && q < nq) ? ld4(x + tok * C + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+      s += hsum4(v[i]);
+    }
+    const float mean = group_sum<G>(s) / (float)C;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+      const int q = lg + i * G;
+      if (q < nq) {
+        f32x4 d = v[i] - mean;
+        ss += hsum4(d * d);
+      }
+    }
+    const float var = group_sum<G>(ss) / (float)C;
+    const float rstd = rsqrtf(var + eps);
+    if (!tv) continue;
+    const long ob = ln_out_offset(tok, C, mode, H, W);
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+      const int q = lg + i * G;
+      if (q < nq) st4(y + ob + 4 * q, (v[i] - mean) * rstd * ld4(w + 4 * q) + ld4(b + 4 * q));
+    }
+    if (lg == 0) {
+      if (mean_o) mean_o[tok] = mean;
+      if (rstd_o) rstd_o[tok] = rstd;
+    }
+  }
+}
+
+// backward: dx = rstd * (dyh - mean(dyh) - xh * mean(dyh * xh)), dyh = dy * w ; dw += dy * xh ; db += dy
+// `dy` is read through the same out_mode mapping the forward wrote y with.  dwdb (2C) must be zeroed by the caller.
+template <int G, int NV>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           const float* __restrict__ w,
+                                                           const float* __restrict__ mean_i,
+                                                           const float* __restrict__ rstd_i, float* __restrict__ dx,
+                                                           float* __restrict__ dwdb, long T, int C, int mode, int H,
+                                                           int W, int accumulate_dx) {
+  constexpr int TPW = 64 / G;
+  const int lane = threadIdx.x & 63;
+  const int lg = lane % G, tg = lane / G;
+  const long wave = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const long nwaves = (long)gridDim.x * (blockDim.x >> 6);
+  const int nq = C >> 2;
+  f32x4 aw[NV], ab[NV], wv[NV];
+#pragma unroll
+  for (int i = 0; i < NV; i++) {
+    aw[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    ab[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int q = lg + i * G;
+    wv[i] = (q < nq) ? ld4(w + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  for (long t0 = wave * TPW; t0 < T; t0 += nwaves * TPW) {
+    const long tok = t0 + tg;
+    const bool tv = tok < T;
+    const float mean = tv ? mean_i[tok] : 0.f;
+    const float rstd = tv ? rstd_i[tok] : 0.f;
+    const long ob = tv ? ln_out_offset(tok, C, mode, H, W) : 0;
+    f32x4 xh[NV], g[NV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+      const int q = lg + i * G;
+      if (tv && q < nq) {
+        xh[i] = (ld4(x + tok * C + 4 * q) - mean) * rstd;
+        const f32x4 d = ld4(dy + ob + 4 * q);
+        aw[i] += d * xh[i];
+        ab[i] += d;
+        g[i] = d * wv[i];
+        s1 += hsum4(g[i]);
+        s2 += hsum4(g[i] * xh[i]);
+      } else {
+        xh[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        g[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    const float c1 = group_sum<G>(s1) / (float)C;
+    const float c2 = group_sum<G>(s2) / (float)C;
+    if (!tv) continue;
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+      const int q = lg + i * G;
+      if (q < nq) {
+        f32x4 r = (g[i] - c1 - xh[i] * c2) * rstd;
+        float* o = dx + tok * C + 4 * q;
+        if (accumulate_dx) r += ld4(o);
+        st4(o, r);
+      }
+    }
+  }
+  // fold the TPW token groups of the wave, then one atomic per column per wave
+#pragma unroll
+  for (int i = 0; i < NV; i++) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      float a = aw[i][j], c = ab[i][j];
+      for (int o = G; o < 64; o <<= 1) {
+        a += __shfl_xor(a, o, 64);
+        c += __shfl_xor(c, o, 64);
+      }
+      const int q = lg + i * G;
+      if (tg == 0 && q < nq) {
+        atomicAdd(dwdb + 4 * q + j, a);
+        atomicAdd(dwdb + C + 4 * q + j, c);
+      }
+    }
+  }
+}
+
+// ============================================================================================== depthwise 7x7
+// y[b,h,w,c] = bias[c] + sum_{ky,kx} x[b,h+ky-3,w+kx-3,c] * w49[ky*7+kx][c]  (+ addend[b,h,w,c]), zero padding.
+// Thread = one channel quad x a 2x8 output strip; lanes run over channel quads (16 B each, coalesced); the 8x14
+// input patch is streamed row by row and reused for both output rows from registers.
+constexpr int DW_RY = 2, DW_RX = 8;
+__global__ __launch_bounds__(256) void dwconv7_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w49,
+                                                         const float* __restrict__ bias,
+                                                         const float* __restrict__ addend, float* __restrict__ y,
+                                                         int B, int H, int W, int C, int spb) {
+  const int nq = C >> 2;
+  const int cq = threadIdx.x % nq;
+  const int sl = threadIdx.x / nq;
+  if (sl >= spb) return;
+  const int sw = (W + DW_RX - 1) / DW_RX, sh = (H + DW_RY - 1) / DW_RY;
+  const long strip = (long)blockIdx.x * spb + sl;
+  const long nstrips = (long)B * sh * sw;
+  if (strip >= nstrips) return;
+  const int sx = strip % sw;
+  const long t2 = strip / sw;
+  const int sy = t2 % sh;
+  const int b = t2 / sh;
+  const int ox0 = sx * DW_RX, oy0 = sy * DW_RY;
+  f32x4 acc[DW_RY][DW_RX];
+  const f32x4 bv = bias ? ld4(bias + 4 * cq) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int r = 0; r < DW_RY; r++)
+#pragma unroll
+    for (int c = 0; c < DW_RX; c++) acc[r][c] = bv;
+  const float* xb = x + (long)b * H * W * C + 4 * cq;
+#pragma unroll 1
+  for (int ir = 0; ir < DW_RY + 6; ir++) {
+    const int iy = oy0 - 3 + ir;
+    if (iy < 0 || iy >= H) continue;
+    f32x4 in[DW_RX + 6];
+#pragma unroll
+    for (int c = 0; c < DW_RX + 6; c++) {
+      const int ix = ox0 - 3 + c;
+      in[c] = (ix >= 0 && ix < W) ? ld4(xb + ((long)iy * W + ix) * C) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int r = 0; r < DW_RY; r++) {
+      const int ky = ir - r;
+      if (ky < 0 || ky > 6) continue;
+#pragma unroll
+      for (int kx = 0; kx < 7; kx++) {
+        const f32x4 wv = ld4(w49 + (long)(ky * 7 + kx) * C + 4 * cq);
+#pragma unroll
+        for (int c = 0; c < DW_RX; c++) acc[r][c] += in[c + kx] * wv;
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < DW_RY; r++)
+#pragma unroll
+    for (int c = 0; c < DW_RX; c++) {
+      if (oy0 + r >= H || ox0 + c >= W) continue;
+      const long o = (((long)b * H + oy0 + r) * W + ox0 + c) * C + 4 * cq;
+      f32x4 v = acc[r][c];
+      if (addend) v += ld4(addend + o);
+      st4(y + o, v);
+    }
+}
+
+// weight / bias gradient: dw49[ky*7+kx][c] += sum_p du[p] * x[p + (ky-3, kx-3)], dbias[c] += sum_p du[p].
+// blockIdx.y = ky; each thread owns one channel quad, loops over output strips (1 x 8) accumulating its 7 taps in
+// registers, then the block folds its strips through LDS and issues one atomic per (tap, channel).
+__global__ __launch_bounds__(256) void dwconv7_bwd_weight_kernel(const float* __restrict__ x,
+                                                                const float* __restrict__ du,
+                                                                float* __restrict__ dw49, float* __restrict__ dbias,
+                                                                int B, int H, int W, int C, int spb) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [spb][8][C]
+  const int nq = C >> 2;
+  const int cq = threadIdx.x % nq;
+  const int sl = threadIdx.x / nq;
+  const int ky = blockIdx.y;
+  const int sw = (W + DW_RX - 1) / DW_RX;
+  const long nstrips = (long)B * H * sw;
+  f32x4 aw[7], ab = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 7; k++) aw[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (sl < spb) {
+    for (long strip = (long)blockIdx.x * spb + sl; strip < nstrips; strip += (long)gridDim.x * spb) {
+      const int sx = strip % sw;
+      const long t2 = strip / sw;
+      const int oy = t2 % H;
+      const int b = t2 / H;
+      const int ox0 = sx * DW_RX;
+      const int iy = oy + ky - 3;
+      f32x4 g[DW_RX];
+#pragma unroll
+      for (int c = 0; c < DW_RX; c++) {
+        g[c] = (ox0 + c < W) ? ld4(du + (((long)b * H + oy) * W + ox0 + c) * C + 4 * cq)
+                             : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (ky == 0) ab += g[c];
+      }
+      if (iy < 0 || iy >= H) continue;
+      f32x4 in[DW_RX + 6];
+#pragma unroll
+      for (int c = 0; c < DW_RX + 6; c++) {
+        const int ix = ox0 - 3 + c;
+        in[c] = (ix >= 0 && ix < W) ? ld4(x + (((long)b * H + iy) * W + ix) * C + 4 * cq) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int kx = 0; kx < 7; kx++)
+#pragma unroll
+        for (int c = 0; c < DW_RX; c++) aw[kx] += g[c] * in[c + kx];
+    }
+  }
+  if (sl < spb) {
+#pragma unroll
+    for (int k = 0; k < 7; k++) st4(red + ((long)sl * 8 + k) * C + 4 * cq, aw[k]);
+    st4(red + ((long)sl * 8 + 7) * C + 4 * cq, ab);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 8 * C; i += blockDim.x) {
+    float s = 0.f;
+    for (int j = 0; j < spb; j++) s += red[(long)j * 8 * C + i];
+    const int k = i / C, c = i - k * C;
+    if (k < 7) atomicAdd(dw49 + (long)(ky * 7 + k) * C + c, s);
+    else if (ky == 0) atomicAdd(dbias + c, s);
+  }
+}
+
+// ============================================================================================== layer-scale backward prep
+// dense block: dY = gamma * rs[b] * dOut ; dgamma[c] += rs[b] * dOut[t,c] * Y[t,c]
+template <int G, int NV>
+__global__ __launch_bounds__(256) void scale_bwd_prep_kernel(const float* __restrict__ dout,
+                                                            const float* __restrict__ yv,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ rowscale, int rows_per_scale,
+                                                            float* __restrict__ dy, float* __restrict__ dgamma, long T,
+                                                            int C) {
+  constexpr int TPW = 64 / G;
+  const int lane = threadIdx.x & 63;
+  const int lg = lane % G, tg = lane / G;
+  const long wave = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const long nwaves = (long)gridDim.x * (blockDim.x >> 6);
+  const int nq = C >> 2;
+  f32x4 ag[NV], gv[NV];
+#pragma unroll
+  for (int i = 0; i < NV; i++) {
+    ag[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int q = lg + i * G;
+    gv[i] = (q < nq) ? ld4(gamma + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  for (long t0 = wave * TPW; t0 < T; t0 += nwaves * TPW) {
+    const long tok = t0 + tg;
+    if (tok >= T) continue;
+    const float rs = rowscale ? rowscale[tok / rows_per_scale] : 1.f;
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+      const int q = lg + i * G;
+      if (q < nq) {
+        const f32x4 d = ld4(dout + tok * C + 4 * q) * rs;
+        ag[i] += d * ld4(yv + tok * C + 4 * q);
+        st4(dy + tok * C + 4 * q, d * gv[i]);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NV; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      float a = ag[i][j];
+      for (int o = G; o < 64; o <<= 1) a += __shfl_xor(a, o, 64);
+      const int q = lg + i * G;
+      if (tg == 0 && q < nq) atomicAdd(dgamma + 4 * q + j, a);
+    }
+}
+
+// ============================================================================================== MoE router
+constexpr int ROUTER_TB = 256;  // tokens per block (one thread per token)
+
+__device__ __forceinline__ float normal_cdf(float z) { return 0.5f * (1.0f + erff(z * 0.70710678118654752440f)); }
+__device__ __forceinline__ float normal_pdf(float z) { return 0.39894228040143267794f * __expf(-0.5f * z * z); }
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(__expf(x)); }  // torch threshold 20
+
+// hcat row layout: [h (P) | raw (E) | pad]; snorm = column-normalised sim_matrix (P,E); scale = exp(min(tau, ln 100)).
+// Outputs per token: top_idx/top_val (m = min(k+1,E), descending), gates (k, softmax of the top k), clean (E),
+// sigma (E, train only), hnorm; per-block partial sums [importance (E) | load (E)] to `partials`.
+template <int ET>
+__global__ __launch_bounds__(ROUTER_TB) void moe_router_fwd_kernel(
+    const float* __restrict__ hcat, int ldh, int P, const float* __restrict__ snorm, const float* __restrict__ scale_p,
+    const float* __restrict__ noise, int T, int E, int k, int train, int32_t* __restrict__ top_idx,
+    float* __restrict__ top_val, float* __restrict__ gates, float* __restrict__ clean_o, float* __restrict__ sigma_o,
+    float* __restrict__ hnorm_o, float* __restrict__ partials) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // snorm (P*E) then reduction scratch
+  float* s_s = sm;
+  float* s_red = sm + (long)P * E;  // [2E][ROUTER_TB/64]
+  for (int i = threadIdx.x; i < P * E; i += blockDim.x) s_s[i] = snorm[i];
+  __syncthreads();
+  const int t = blockIdx.x * ROUTER_TB + threadIdx.x;
+  const bool tv = t < T;
+  const int m = min(k + 1, E);
+  float imp[ET], ld[ET];
+#pragma unroll
+  for (int e = 0; e < ET; e++) imp[e] = ld[e] = 0.f;
+  if (tv) {
+    const float* h = hcat + (long)t * ldh;
+    float dot[ET];
+#pragma unroll
+    for (int e = 0; e < ET; e++) dot[e] = 0.f;
+    float nn = 0.f;
+    for (int p = 0; p < P; p += 4) {
+      const f32x4 hv = ld4(h + p);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        nn += hv[j] * hv[j];
+#pragma unroll
+        for (int e = 0; e < ET; e++)
+          if (e < E) dot[e] += hv[j] * s_s[(p + j) * E + e];
+      }
+    }
+    const float hn = sqrtf(nn);
+    const float inv = 1.0f / fmaxf(hn, 1e-12f);  // F.normalize eps
+    const float scale = *scale_p;
+    float logit[ET], cl[ET], sg[ET];
+#pragma unroll
+    for (int e = 0; e < ET; e++) {
+      cl[e] = (e < E) ? dot[e] * inv * scale : -INFINITY;
+      sg[e] = 1.f;
+      logit[e] = cl[e];
+      if (e < E && train) {
+        sg[e] = softplus_f(h[P + e]) + 1e-2f;
+        logit[e] = cl[e] + noise[(long)t * E + e] * sg[e];
+      }
+    }
+    // top-m selection (descending); ties -> lower index, like a stable descending sort
+    float tvv[ET];
+    int tii[ET];
+    unsigned used = 0;
+#pragma unroll
+    for (int j = 0; j < ET; j++) {
+      if (j < m) {
+        float best = -INFINITY;
+        int bi = -1;
+#pragma unroll
+        for (int e = 0; e < ET; e++)
+          if (e < E && !((used >> e) & 1u) && (bi < 0 || logit[e] > best)) {
+            best = logit[e];
+            bi = e;
+          }
+        used |= 1u << bi;
+        tvv[j] = best;
+        tii[j] = bi;
+        top_idx[(long)t * m + j] = bi;
+        top_val[(long)t * m + j] = best;
+      }
+    }
+    // softmax over the top k
+    float gsum = 0.f, gk[ET];
+#pragma unroll
+    for (int j = 0; j < ET; j++)
+      if (j < k) {
+        gk[j] = __expf(tvv[j] - tvv[0]);
+        gsum += gk[j];
+      }
+#pragma unroll
+    for (int j = 0; j < ET; j++)
+      if (j < k) {
+        gk[j] /= gsum;
+        gates[(long)t * k + j] = gk[j];
+#pragma unroll
+        for (int e = 0; e < ET; e++)
+          if (e == tii[j]) imp[e] += gk[j];
+      }
+    const bool smooth = train && (k < E);
+#pragma unroll
+    for (int e = 0; e < ET; e++)
+      if (e < E) {
+        clean_o[(long)t * E + e] = cl[e];
+        if (train) sigma_o[(long)t * E + e] = sg[e];
+        if (smooth) {
+          float vin = 0.f, vout = 0.f;
+#pragma unroll
+          for (int j = 0; j < ET; j++) {
+            if (j == k) vin = tvv[j];
+            if (j == k - 1) vout = tvv[j];
+          }
+          const float thr = (logit[e] > vin) ? vin : vout;  // _prob_in_top_k :159-173
+          ld[e] = normal_cdf((cl[e] - thr) / sg[e]);
+        } else {
+          float gg = 0.f;
+#pragma unroll
+          for (int j = 0; j < ET; j++)
+            if (j < k && tii[j] == e) gg = gk[j];
+          ld[e] = gg > 0.f ? 1.f : 0.f;  // _gates_to_load :149-150
+        }
+      }
+    hnorm_o[t] = hn;
+  }
+  // block partials (deterministic: wave shuffle tree, then fixed-order fold of the 4 waves)
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int e = 0; e < ET; e++) {
+    float a = group_sum<64>(imp[e]);
+    float c = group_sum<64>(ld[e]);
+    if (lane == 0 && e < E) {
+      s_red[e * 4 + wv] = a;
+      s_red[(E + e) * 4 + wv] = c;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 * E) {
+    const float* r = s_red + threadIdx.x * 4;
+    partials[(long)blockIdx.x * 2 * E + threadIdx.x] = (r[0] + r[1]) + (r[2] + r[3]);
+  }
+}
+
+// backward of the router: per token dlogits from (i) the combine (dgate), (ii) the importance term, (iii) the
+// load term (train), then through noise / softplus / cosine normalisation.  Writes
+//   dhcat[t] = [dh (P) | draw (E) | 0...]   (row-major, ld = ldh; the gate GEMMs turn it into dWp, dWn, dx)
+//   dcn[t,e] = dclean[t,e] / max(|h_t|, eps)      (so that dSnorm = scale * h^T . dcn is one TN GEMM)
+//   ds_part[block] = sum_t sum_e dclean[t,e] * clean[t,e] / scale   (d scale)
+template <int ET>
+__global__ __launch_bounds__(ROUTER_TB) void moe_router_bwd_kernel(
+    const float* __restrict__ hcat, int ldh, int P, const float* __restrict__ snorm, const float* __restrict__ scale_p,
+    const float* __restrict__ noise, int T, int E, int k, int train, const int32_t* __restrict__ top_idx,
+    const float* __restrict__ top_val, const float* __restrict__ gates, const float* __restrict__ clean_i,
+    const float* __restrict__ sigma_i, const float* __restrict__ hnorm_i, const float* __restrict__ dgate,
+    const float* __restrict__ dimp, const float* __restrict__ dload, float* __restrict__ dhcat,
+    float* __restrict__ dcn, float* __restrict__ ds_part) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* s_s = sm;                   // snorm P*E
+  float* s_red = sm + (long)P * E;   // [4]
+  for (int i = threadIdx.x; i < P * E; i += blockDim.x) s_s[i] = snorm[i];
+  __syncthreads();
+  const int t = blockIdx.x * ROUTER_TB + threadIdx.x;
+  const int m = min(k + 1, E);
+  float ds_local = 0.f;
+  if (t < T) {
+    const float scale = *scale_p;
+    float dlogit[ET], dclean[ET], dsig[ET];
+#pragma unroll
+    for (int e = 0; e < ET; e++) dlogit[e] = dclean[e] = dsig[e] = 0.f;
+    int tii[ET];
+    float tvv[ET];
+#pragma unroll
+    for (int j = 0; j < ET; j++)
+      if (j < m) {
+        tii[j] = top_idx[(long)t * m + j];
+        tvv[j] = top_val[(long)t * m + j];
+      }
+    // softmax backward
+    float gk[ET], dg[ET], dotg = 0.f;
+#pragma unroll
+    for (int j = 0; j < ET; j++)
+      if (j < k) {
+        gk[j] = gates[(long)t * k + j];
+        dg[j] = dgate[(long)t * k + j] + dimp[tii[j]];
+        dotg += gk[j] * dg[j];
+      }
+#pragma unroll
+    for (int j = 0; j < ET; j++)
+      if (j < k) {
+        const float dv = gk[j] * (dg[j] - dotg);
+#pragma unroll
+        for (int e = 0; e < ET; e++)
+          if (e == tii[j]) dlogit[e] += dv;
+      }
+    const float* h = hcat + (long)t * ldh;
+    const bool smooth = train && (k < E);
+    if (smooth) {
+      float vin = 0.f, vout = 0.f;
+      int iin = -1, iout = -1;
+#pragma unroll
+      for (int j = 0; j < ET; j++) {
+        if (j == k) { vin = tvv[j]; iin = tii[j]; }
+        if (j == k - 1) { vout = tvv[j]; iout = tii[j]; }
+      }
+      float dthr_in = 0.f, dthr_out = 0.f;
+#pragma unroll
+      for (int e = 0; e < ET; e++)
+        if (e < E) {
+          const float cl = clean_i[(long)t * E + e], sg = sigma_i[(long)t * E + e];
+          const float lg = cl + noise[(long)t * E + e] * sg;
+          const bool is_in = lg > vin;
+          const float thr = is_in ? vin : vout;
+          const float z = (cl - thr) / sg;
+          const float q = dload[e] * normal_pdf(z) / sg;
+          dclean[e] += q;
+          dsig[e] -= q * z;
+          if (is_in) dthr_in -= q; else dthr_out -= q;
+        }
+#pragma unroll
+      for (int e = 0; e < ET; e++) {
+        if (e == iin) dlogit[e] += dthr_in;
+        if (e == iout) dlogit[e] += dthr_out;
+      }
+    }
+    float* dh = dhcat + (long)t * ldh;
+#pragma unroll
+    for (int e = 0; e < ET; e++)
+      if (e < E) {
+        dclean[e] += dlogit[e];
+        float draw = 0.f;
+        if (train) {
+          dsig[e] += noise[(long)t * E + e] * dlogit[e];
+          const float r = h[P + e];
+          draw = dsig[e] / (1.0f + __expf(-r));  // d softplus = sigmoid
+        }
+        dh[P + e] = draw;
+      }
+    for (int c = P + E; c < ldh; c++) dh[c] = 0.f;
+    const float hn = hnorm_i[t];
+    const float inv = 1.0f / fmaxf(hn, 1e-12f);
+#pragma unroll
+    for (int e = 0; e < ET; e++)
+      if (e < E) {
+        dcn[(long)t * E + e] = dclean[e] * inv;
+        ds_local += dclean[e] * clean_i[(long)t * E + e];
+      }
+    ds_local /= scale;
+    // dh = (dhh - hh <hh, dhh>) * inv,  dhh = scale * snorm . dclean,  hh = h * inv
+    float proj = 0.f;
+    for (int p = 0; p < P; p++) {
+      float dhh = 0.f;
+#pragma unroll
+      for (int e = 0; e < ET; e++)
+        if (e < E) dhh += s_s[p * E + e] * dclean[e];
+      dhh *= scale;
+      proj += dhh * h[p] * inv;
+    }
+    if (hn < 1e-12f) proj = 0.f;  // clamp region of F.normalize: d/dh (h/eps) = dhh/eps
+    for (int p = 0; p < P; p += 4) {
+      f32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        float dhh = 0.f;
+#pragma unroll
+        for (int e = 0; e < ET; e++)
+          if (e < E) dhh += s_s[(p + j) * E + e] * dclean[e];
+        dhh *= scale;
+        o[j] = (dhh - h[p + j] * inv * proj) * inv;
+      }
+      st4(dh + p, o);
+    }
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const float a = group_sum<64>(ds_local);
+  if (lane == 0) s_red[wv] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) ds_part[blockIdx.x] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+
+// ============================================================================================== MoE plan (dispatch tables)
+// Deterministic expert-major slot assignment without a host sync: slot(t,j) = offsets[e] + rank of (t,j) among the
+// pairs routed to e in (t,j) order.  Three launches: per-block histogram, one-block scan, per-block ranks.
+constexpr int PLAN_TB = 256;
+__global__ __launch_bounds__(PLAN_TB) void moe_hist_kernel(const int32_t* __restrict__ top_idx, int m, int T, int E,
+                                                          int k, int32_t* __restrict__ counts) {
+  extern __shared__ int s_cnt[];  // E
+  for (int i = threadIdx.x; i < E; i += blockDim.x) s_cnt[i] = 0;
+  __syncthreads();
+  const int t = blockIdx.x * PLAN_TB + threadIdx.x;
+  if (t < T)
+    for (int j = 0; j < k; j++) atomicAdd(&s_cnt[top_idx[(long)t * m + j]], 1);
+  __syncthreads();
+  for (int i = threadIdx.x; i < E; i += blockDim.x) counts[(long)blockIdx.x * E + i] = s_cnt[i];
+}
+// counts (nblk,E) -> base (nblk,E) exclusive over blocks + expert offsets; offsets (E+1)
+__global__ void moe_scan_kernel(const int32_t* __restrict__ counts, int nblk, int E, int32_t* __restrict__ base,
+                                int32_t* __restrict__ offsets) {
+  extern __shared__ int s_tot[];  // E+1
+  const int e = threadIdx.x;
+  int tot = 0;
+  if (e < E)
+    for (int b = 0; b < nblk; b++) tot += counts[(long)b * E + e];
+  if (e < E) s_tot[e] = tot;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int i = 0; i < E; i++) {
+      const int c = s_tot[i];
+      s_tot[i] = run;
+      offsets[i] = run;
+      run += c;
+    }
+    offsets[E] = run;
+  }
+  __syncthreads();
+  if (e < E) {
+    int run = s_tot[e];
+    for (int b = 0; b < nblk; b++) {
+      base[(long)b * E + e] = run;
+      run += counts[(long)b * E + e];
+    }
+  }
+}
+__global__ __launch_bounds__(PLAN_TB) void moe_rank_kernel(const int32_t* __restrict__ top_idx, int m, int T, int E,
+                                                          int k, const int32_t* __restrict__ base,
+                                                          int32_t* __restrict__ slot_token,
+                                                          int32_t* __restrict__ token_slot) {
+  __shared__ int s_wave[PLAN_TB / 64];
+  const int t = blockIdx.x * PLAN_TB + threadIdx.x;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int e = 0; e < E; e++) {
+    // number of this thread's (t,j) pairs routed to e (0 or 1: top-k indices are distinct), and which j
+    int jj = -1;
+    if (t < T)
+      for (int j = 0; j < k; j++)
+        if (top_idx[(long)t * m + j] == e) jj = j;
+    const unsigned long long bal = __ballot(jj >= 0);
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wave[wv] = __popcll(bal);
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wv; w++) woff += s_wave[w];
+    if (jj >= 0) {
+      const int slot = base[(long)blockIdx.x * E + e] + woff + before;
+      slot_token[slot] = t;
+      token_slot[(long)t * k + jj] = slot;
+    }
+    __syncthreads();
+  }
+}
+
+// Xslot[s,:] = X[slot_token[s],:]
+__global__ void moe_dispatch_kernel(const float* __restrict__ x, const int32_t* __restrict__ slot_token,
+                                    float* __restrict__ xs, long S, int C) {
+  const int nq = C >> 2;
+  const long total = S * nq;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const long s = idx / nq;
+    const int q = idx - s * nq;
+    st4(xs + s * C + 4 * q, ld4(x + (long)slot_token[s] * C + 4 * q));
+  }
+}
+
+// out[t,:] = shortcut[t,:] + gamma * rs[b] * sum_j gates[t,j] * Yslot[token_slot[t,j],:]     (combine :269-284, :368-370)
+__global__ void moe_combine_fwd_kernel(const float* __restrict__ yslot, const int32_t* __restrict__ token_slot,
+                                       const float* __restrict__ gates, const float* __restrict__ shortcut,
+                                       const float* __restrict__ gamma, const float* __restrict__ rowscale,
+                                       int rows_per_scale, float* __restrict__ out, long T, int C, int k) {
+  const int nq = C >> 2;
+  const long total = T * nq;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const long t = idx / nq;
+    const int q = idx - t * nq;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < k; j++) {
+      const float g = gates[t * k + j];
+      acc += ld4(yslot + (long)token_slot[t * k + j] * C + 4 * q) * g;
+    }
+    float sc = rowscale ? rowscale[t / rows_per_scale] : 1.f;
+    st4(out + t * C + 4 * q, ld4(shortcut + t * C + 4 * q) + ld4(gamma + 4 * q) * sc * acc);
+  }
+}
+
+// backward of the combine: d = gamma * rs * dOut[t] ; dYslot[slot_j] = g_j * d ; dgate[t,j] = <d, Yslot[slot_j]> ;
+// dgamma[c] += rs * dOut[t,c] * sum_j g_j Yslot[slot_j][c]
+template <int G, int NV>
+__global__ __launch_bounds__(256) void moe_combine_bwd_kernel(
+    const float* __restrict__ dout, const float* __restrict__ yslot, const int32_t* __restrict__ token_slot,
+    const float* __restrict__ gates, const float* __restrict__ gamma, const float* __restrict__ rowscale,
+    int rows_per_scale, float* __restrict__ dyslot, float* __restrict__ dgate, float* __restrict__ dgamma, long T,
+    int C, int k) {
+  constexpr int TPW = 64 / G;
+  const int lane = threadIdx.x & 63;
+  const int lg = lane % G, tg = lane / G;
+  const long wave = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const long nwaves = (long)gridDim.x * (blockDim.x >> 6);
+  const int nq = C >> 2;
+  f32x4 ag[NV], gv[NV];
+#pragma unroll
+  for (int i = 0; i < NV; i++) {
+    ag[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int q = lg + i * G;
+    gv[i] = (q < nq) ? ld4(gamma + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  for (long t0 = wave * TPW; t0 < T; t0 += nwaves * TPW) {
+    const long tok = t0 + tg;
+    const bool tv = tok < T;
+    const float rs = (tv && rowscale) ? rowscale[tok / rows_per_scale] : 1.f;
+    f32x4 d[NV], ym[NV];
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+      const int q = lg + i * G;
+      d[i] = (tv && q < nq) ? ld4(dout + tok * C + 4 * q) * rs : f32x4{0.f, 0.f, 0.f, 0.f};
+      ym[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int j = 0; j < k; j++) {
+      const float g = tv ? gates[tok * k + j] : 0.f;
+      const long sl = tv ? token_slot[tok * k + j] : 0;
+      float dot = 0.f;
+#pragma unroll
+      for (int i = 0; i < NV; i++) {
+        const int q = lg + i * G;
+        if (tv && q < nq) {
+          const f32x4 yv = ld4(yslot + sl * C + 4 * q);
+          const f32x4 dd = d[i] * gv[i];
+          dot += hsum4(dd * yv);
+          ym[i] += yv * g;
+          st4(dyslot + sl * C + 4 * q, dd * g);
+        }
+      }
+      dot = group_sum<G>(dot);
+      if (tv && lg == 0) dgate[tok * k + j] = dot;
+    }
+#pragma unroll
+    for (int i = 0; i < NV; i++) ag[i] += d[i] * ym[i];
+  }
+#pragma unroll
+  for (int i = 0; i < NV; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      float a = ag[i][j];
+      for (int o = G; o < 64; o <<= 1) a += __shfl_xor(a, o, 64);
+      const int q = lg + i * G;
+      if (tg == 0 && q < nq) atomicAdd(dgamma + 4 * q + j, a);
+    }
+}
+
+// dx[t,:] (+)= sum_j dXslot[token_slot[t,j],:]
+__global__ void moe_gather_add_kernel(const float* __restrict__ dxslot, const int32_t* __restrict__ token_slot,
+                                      float* __restrict__ dx, long T, int C, int k, int accumulate) {
+  const int nq = C >> 2;
+  const long total = T * nq;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const long t = idx / nq;
+    const int q = idx - t * nq;
+    f32x4 acc = accumulate ? ld4(dx + t * C + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < k; j++) acc += ld4(dxslot + (long)token_slot[t * k + j] * C + 4 * q);
+    st4(dx + t * C + 4 * q, acc);
+  }
+}
+
+// blocks of 4 waves for a row kernel that handles 64/G tokens per wave-iteration (grid-stride beyond 4096 blocks)
+inline int row_blocks(long T, int G) {
+  const long waves = (T * G + 63) / 64;
+  long b = (waves + 3) / 4;
+  if (b > 4096) b = 4096;
+  return (int)(b < 1 ? 1 : b);
+}
+inline int ew_blocks(long work, int threads = 256) {
+  long b = (work + threads - 1) / threads;
+  if (b > 256L * 16) b = 256L * 16;
+  return (int)(b < 1 ? 1 : b);
+}
+
+// (G, NV) dispatch for the row kernels: lanes per token and float4s per lane
+#define SM3_ROW_DISPATCH(C, CALL)                                   \
+  do {                                                              \
+    const int nq_ = (C) >> 2;                                       \
+    if (nq_ <= 16) { CALL(16, 1); }                                 \
+    else if (nq_ <= 32) { CALL(32, 1); }                            \
+    else if (nq_ <= 64) { CALL(64, 1); }                            \
+    else if (nq_ <= 128) { CALL(64, 2); }                           \
+    else if (nq_ <= 192) { CALL(64, 3); }                           \
+    else if (nq_ <= 256) { CALL(64, 4); }                           \
+    else if (nq_ <= 512) { CALL(64, 8); }                           \
+    else return SM3_ERR_UNSUPPORTED;                                \
+  } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int sm3_stem_patchify(const float* x, float* a, int B, int H, int W, sm3_stream_t stream) {
+  if (!x || !a || B <= 0 || H <= 0 || W <= 0 || (H & 3) || (W & 3)) return SM3_ERR_INVALID_ARG;
+  const long total = (long)B * (H / 4) * (W / 4) * 16;
+  stem_patchify_kernel<<<ew_blocks(total), 256, 0, (hipStream_t)stream>>>(x, a, B, H, W);
+  return launch_status();
+}
+
+int sm3_layernorm_fwd(const float* x, const float* w, const float* b, float eps, float* y, float* mean, float* rstd,
+                      long T, int C, int out_mode, int H, int W, sm3_stream_t stream) {
+  if (!x || !w || !b || !y || T < 0 || C <= 0 || (C & 3)) return SM3_ERR_INVALID_ARG;
+  if (out_mode == 1 && ((H & 1) || (W & 1))) return SM3_ERR_INVALID_ARG;
+  if (T == 0) return SM3_OK;
+  hipStream_t st = (hipStream_t)stream;
+#define CALL(G, NV)                                                                                        \
+  layernorm_fwd_kernel<G, NV><<<row_blocks(T, G), 256, 0, st>>>(x, w, b, eps, y, mean, rstd, T, C, out_mode, H, W)
+  SM3_ROW_DISPATCH(C, CALL);
+#undef CALL
+  return launch_status();
+}
+
+int sm3_layernorm_bwd(const float* dy, const float* x, const float* w, const float* mean, const float* rstd,
+                      float* dx, float* dwdb, long T, int C, int out_mode, int H, int W, int accumulate_dx,
+                      sm3_stream_t stream) {
+  if (!dy || !x || !w || !mean || !rstd || !dx || !dwdb || T < 0 || C <= 0 || (C & 3)) return SM3_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  (void)hipMemsetAsync(dwdb, 0, sizeof(float) * 2 * C, st);
+  if (T == 0) return launch_status();
+#define CALL(G, NV)                                                                                         \
+  layernorm_bwd_kernel<G, NV><<<512, 256, 0, st>>>(dy, x, w, mean, rstd, dx, dwdb, T, C, out_mode, H, W, accumulate_dx)
+  SM3_ROW_DISPATCH(C, CALL);
+#undef CALL
+  return launch_status();
+}
+
+int sm3_dwconv7_fwd(const float* x, const float* w49, const float* bias, const float* addend, float* y, int B, int H,
+                    int W, int C, sm3_stream_t stream) {
+  if (!x || !w49 || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || C > 1024) return SM3_ERR_INVALID_ARG;
+  const int nq = C / 4;
+  const int spb = 256 / nq > 0 ? 256 / nq : 1;
+  const long nstrips = (long)B * ((H + DW_RY - 1) / DW_RY) * ((W + DW_RX - 1) / DW_RX);
+  const int blocks = (int)((nstrips + spb - 1) / spb);
+  dwconv7_fwd_kernel<<<blocks, nq * spb, 0, (hipStream_t)stream>>>(x, w49, bias, addend, y, B, H, W, C, spb);
+  return launch_status();
+}
+
+int sm3_dwconv7_bwd_weight(const float* x, const float* du, float* dw49, float* dbias, int B, int H, int W, int C,
+                           sm3_stream_t stream) {
+  if (!x || !du || !dw49 || !dbias || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || C > 1024)
+    return SM3_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  (void)hipMemsetAsync(dw49, 0, sizeof(float) * 49 * C, st);
+  (void)hipMemsetAsync(dbias, 0, sizeof(float) * C, st);
+  const int nq = C / 4;
+  const int spb = 256 / nq > 0 ? 256 / nq : 1;
+  const long nstrips = (long)B * H * ((W + DW_RX - 1) / DW_RX);
+  long blocks = (nstrips + spb - 1) / spb;
+  if (blocks > 160) blocks = 160;  // x 7 tap rows ~ 4 blocks per CU; each block loops over strips
+  dim3 grid((int)blocks, 7);
+  const size_t lds = (size_t)spb * 8 * C * sizeof(float);
+  dwconv7_bwd_weight_kernel<<<grid, nq * spb, lds, st>>>(x, du, dw49, dbias, B, H, W, C, spb);
+  return launch_status();
+}
+
+int sm3_scale_bwd_prep(const float* dout, const float* y, const float* gamma, const float* rowscale,
+                       int rows_per_scale, float* dy, float* dgamma, long T, int C, sm3_stream_t stream) {
+  if (!dout || !y || !gamma || !dy || !dgamma || T < 0 || C <= 0 || (C & 3)) return SM3_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  (void)hipMemsetAsync(dgamma, 0, sizeof(float) * C, st);
+  if (T == 0) return launch_status();
+  if (rows_per_scale <= 0) rows_per_scale = 1;
+#define CALL(G, NV) \
+  scale_bwd_prep_kernel<G, NV><<<512, 256, 0, st>>>(dout, y, gamma, rowscale, rows_per_scale, dy, dgamma, T, C)
+  SM3_ROW_DISPATCH(C, CALL);
+#undef CALL
+  return launch_status();
+}
+
+int sm3_moe_router_fwd(const float* hcat, int ldh, int P, const float* snorm, const float* scale, const float* noise,
+                       int T, int E, int k, int train, int32_t* top_idx, float* top_val, float* gates, float* clean,
+                       float* sigma, float* hnorm, float* partials, sm3_stream_t stream) {
+  if (!hcat || !snorm || !scale || !top_idx || !top_val || !gates || !clean || !hnorm || !partials)
+    return SM3_ERR_INVALID_ARG;
+  if (T <= 0 || E < 1 || E > 32 || k < 1 || k > E || (P & 3) || P + E > ldh) return SM3_ERR_INVALID_ARG;
+  if (train && (!noise || !sigma)) return SM3_ERR_INVALID_ARG;
+  const int nblk = (T + ROUTER_TB - 1) / ROUTER_TB;
+  const size_t lds = ((size_t)P * E + 2 * E * 4) * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+#define CALL(ET)                                                                                                    \
+  moe_router_fwd_kernel<ET><<<nblk, ROUTER_TB, lds, st>>>(hcat, ldh, P, snorm, scale, noise, T, E, k, train, top_idx, \
+                                                          top_val, gates, clean, sigma, hnorm, partials)
+  if (E <= 4) CALL(4);
+  else if (E <= 8) CALL(8);
+  else if (E <= 16) CALL(16);
+  else CALL(32);
+#undef CALL
+  return launch_status();
+}
+
+int sm3_moe_router_bwd(const float* hcat, int ldh, int P, const float* snorm, const float* scale, const float* noise,
+                       int T, int E, int k, int train, const int32_t* top_idx, const float* top_val,
+                       const float* gates, const float* clean, const float* sigma, const float* hnorm,
+                       const float* dgate, const float* dimp, const float* dload, float* dhcat, float* dcn,
+                       float* ds_part, sm3_stream_t stream) {
+  if (!hcat || !snorm || !scale || !top_idx || !top_val || !gates || !clean || !hnorm || !dgate || !dimp || !dload ||
+      !dhcat || !dcn || !ds_part)
+    return SM3_ERR_INVALID_ARG;
+  if (T <= 0 || E < 1 || E > 32 || k < 1 || k > E || (P & 3) || P + E > ldh) return SM3_ERR_INVALID_ARG;
+  if (train && (!noise || !sigma)) return SM3_ERR_INVALID_ARG;
+  const int nblk = (T + ROUTER_TB - 1) / ROUTER_TB;
+  const size_t lds = ((size_t)P * E + 4) * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+#define CALL(ET)                                                                                                     \
+  moe_router_bwd_kernel<ET><<<nblk, ROUTER_TB, lds, st>>>(hcat, ldh, P, snorm, scale, noise, T, E, k, train, top_idx,  \
+                                                          top_val, gates, clean, sigma, hnorm, dgate, dimp, dload,   \
+                                                          dhcat, dcn, ds_part)
+  if (E <= 4) CALL(4);
+  else if (E <= 8) CALL(8);
+  else if (E <= 16) CALL(16);
+  else CALL(32);
+#undef CALL
+  return launch_status();
+}
+
+size_t sm3_moe_plan_workspace_bytes(int T, int E) {
+  const int nblk = (T + PLAN_TB - 1) / PLAN_TB;
+  return (size_t)2 * nblk * E * sizeof(int32_t);
+}
+
+int sm3_moe_plan(const int32_t* top_idx, int m, int T, int E, int k, int32_t* offsets, int32_t* slot_token,
+                 int32_t* token_slot, void* workspace, size_t workspace_bytes, sm3_stream_t stream) {
+  if (!top_idx || !offsets || !slot_token || !token_slot || !workspace) return SM3_ERR_INVALID_ARG;
+  if (T <= 0 || E < 1 || E > 1024 || k < 1 || k > m) return SM3_ERR_INVALID_ARG;
+  if (workspace_bytes < sm3_moe_plan_workspace_bytes(T, E)) return SM3_ERR_WORKSPACE;
+  const int nblk = (T + PLAN_TB - 1) / PLAN_TB;
+  int32_t* counts = (int32_t*)workspace;
+  int32_t* base = counts + (size_t)nblk * E;
+  hipStream_t st = (hipStream_t)stream;
+  moe_hist_kernel<<<nblk, PLAN_TB, E * sizeof(int), st>>>(top_idx, m, T, E, k, counts);
+  const int sthreads = ((E + 63) / 64) * 64;
+  moe_scan_kernel<<<1, sthreads, (E + 1) * sizeof(int), st>>>(counts, nblk, E, base, offsets);
+  moe_rank_kernel<<<nblk, PLAN_TB, 0, st>>>(top_idx, m, T, E, k, base, slot_token, token_slot);
+  return launch_status();
+}
+
+int sm3_moe_dispatch(const float* x, const int32_t* slot_token, float* xslot, long S, int C, sm3_stream_t stream) {
+  if (!x || !slot_token || !xslot || S < 0 || C <= 0 || (C & 3)) return SM3_ERR_INVALID_ARG;
+  if (S == 0) return SM3_OK;
+  moe_dispatch_kernel<<<ew_blocks(S * (C / 4)), 256, 0, (hipStream_t)stream>>>(x, slot_token, xslot, S, C);
+  return launch_status();
+}
+
+int sm3_moe_combine_fwd(const float* yslot, const int32_t* token_slot, const float* gates, const float* shortcut,
+                        const float* gamma, const float* rowscale, int rows_per_scale, float* out, long T, int C,
+                        int k, sm3_stream_t stream) {
+  if (!yslot || !token_slot || !gates || !shortcut || !gamma || !out || T <= 0 || C <= 0 || (C & 3) || k < 1)
+    return SM3_ERR_INVALID_ARG;
+  if (rows_per_scale <= 0) rows_per_scale = 1;
+  moe_combine_fwd_kernel<<<ew_blocks(T * (C / 4)), 256, 0, (hipStream_t)stream>>>(
+      yslot, token_slot, gates, shortcut, gamma, rowscale, rows_per_scale, out, T, C, k);
+  return launch_status();
+}
+
+int sm3_moe_combine_bwd(const float* dout, const float* yslot, const int32_t* token_slot, const float* gates,
+                        const float* gamma, const float* rowscale, int rows_per_scale, float* dyslot, float* dgate,
+                        float* dgamma, long T, int C, int k, sm3_stream_t stream) {
+  if (!dout || !yslot || !token_slot || !gates || !gamma || !dyslot || !dgate || !dgamma || T <= 0 || C <= 0 ||
+      (C & 3) || k < 1)
+    return SM3_ERR_INVALID_ARG;
+  if (rows_per_scale <= 0) rows_per_scale = 1;
+  hipStream_t st = (hipStream_t)stream;
+  (void)hipMemsetAsync(dgamma, 0, sizeof(float) * C, st);
+#define CALL(G, NV)                                                                                                \
+  moe_combine_bwd_kernel<G, NV><<<512, 256, 0, st>>>(dout, yslot, token_slot, gates, gamma, rowscale, rows_per_scale, \
+                                                     dyslot, dgate, dgamma, T, C, k)
+  SM3_ROW_DISPATCH(C, CALL);
+#undef CALL
+  return launch_status();
+}
+
+int sm3_moe_gather_add(const float* dxslot, const int32_t* token_slot, float* dx, long T, int C, int k,
+                       int accumulate, sm3_stream_t stream) {
+  if (!dxslot || !token_slot || !dx || T <= 0 || C <= 0 || (C & 3) || k < 1) return SM3_ERR_INVALID_ARG;
+  moe_gather_add_kernel<<<ew_blocks(T * (C / 4)), 256, 0, (hipStream_t)stream>>>(dxslot, token_slot, dx, T, C, k,
+                                                                                accumulate);
+  return launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,65 @@
+"""CPU tier (no kernels run): registry surface, constructor kwargs and the state_dict key schema of the backbone
+mirror must equal the reference's (fixture keys come from the reference module itself)."""
+import pytest
+import torch
+
+from tests.moe_common import load_fixture
+
+
+@pytest.mark.parametrize('name', ['moe_e4k2', 'moe_e8k3'])
+def test_state_dict_schema_equals_reference(name):
+    from sm3det_amd.convnext_moe import ConvNeXt_moe_MultiInput
+    fx = load_fixture(name)
+    net = ConvNeXt_moe_MultiInput(**fx['cfg'])
+    mine = net.state_dict()
+    assert set(mine.keys()) == set(fx['state_dict'].keys())
+    for k, v in fx['state_dict'].items():
+        assert tuple(mine[k].shape) == tuple(v.shape), k
+    net.load_state_dict(fx['state_dict'], strict=True)
+    again = net.state_dict()
+    for k, v in fx['state_dict'].items():
+        assert torch.equal(again[k], v), k
+    # fused expert storage really holds the per-expert tensors
+    for n, m in net.named_modules():
+        if m.__class__.__name__ == 'MoE_layer':
+            assert torch.equal(m.w1[1], fx['state_dict'][f'{n}.experts.1.pointwise_conv1.weight'])
+
+
+def test_registry_builds_main_sm3det_backbone_cfg():
+    from sm3det_amd.registry import ROTATED_BACKBONES
+    import sm3det_amd.convnext_moe  # noqa: F401  (registers the classes)
+    cfg = dict(type='ConvNeXt_moe_MultiInput', MoE_Block_inds=[[], [0, 2], [i * 2 for i in range(5)], [0, 2]],
+               datasets=None, num_experts=8, top_k=2, arch='tiny', drop_path_rate=0.1,
+               init_cfg=dict(type='Pretrained', prefix='backbone', checkpoint='../data/pretrained/convnext-tiny.pth'))
+    net = ROTATED_BACKBONES.build(cfg)  # local_configs/main_SM3Det.py:13-21
+    n_params = sum(p.numel() for p in net.parameters())
+    assert abs(n_params / 1e6 - 140.28) < 0.01  # 140.28 M
+    n_moe = sum(1 for m in net.modules() if m.__class__.__name__ == 'MoE_layer')
+    assert n_moe == 9
+    assert 'ConvNeXt_moe' in ROTATED_BACKBONES and len(ROTATED_BACKBONES) >= 2
+
+
+def test_pretrained_key_remap_clones_dense_ffn_into_experts():
+    from sm3det_amd.convnext_moe import ConvNeXt_moe_MultiInput
+    net = ConvNeXt_moe_MultiInput(arch=dict(depths=[1, 1, 1, 1], channels=[32, 32, 32, 32]),
+                                  MoE_Block_inds=[[], [0], [], []], num_experts=4, top_k=2)
+    ck = {'backbone.downsample_layers.0.0.weight': torch.randn(32, 3, 4, 4),
+          'backbone.downsample_layers.0.1.weight': torch.randn(32),
+          'backbone.stages.1.0.pointwise_conv1.weight': torch.randn(128, 32),
+          'backbone.stages.0.0.pointwise_conv1.weight': torch.randn(128, 32),
+          'head.fc.weight': torch.randn(3)}
+    sd = net.remap_pretrained_state_dict(ck)
+    assert 'dataset_stems.single.weight' in sd and 'downsample_layers.0.0.weight' in sd
+    assert all(f'stages.1.0.ffn.experts.{e}.pointwise_conv1.weight' in sd for e in range(4))
+    assert 'stages.0.0.ffn.pointwise_conv1.weight' in sd and not any(k.startswith('head') for k in sd)
+    res = net.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys
+    assert torch.equal(net.stages[1][0].ffn.w1[3], ck['backbone.stages.1.0.pointwise_conv1.weight'])
+
+
+def test_unsupported_options_raise():
+    from sm3det_amd.convnext_moe import ConvNeXt_moe
+    with pytest.raises(NotImplementedError):
+        ConvNeXt_moe(arch='tiny', gate='linear', MoE_Block_inds=[[], [0], [], []])
+    with pytest.raises(NotImplementedError):
+        ConvNeXt_moe(arch='tiny', use_grn=True)

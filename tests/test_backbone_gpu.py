@@ -1,0 +1,257 @@
+"""GPU tier: the MI355X backbone (sm3det_amd.convnext_moe -> libsm3det_hip.so through the C ABI) against
+ (a) the committed fixtures produced by the REFERENCE module (tests/golden/moe_*.pt),
+ (b) the CPU oracle (oracle/moe_oracle.py) at sizes it finishes in seconds,
+ (c) plain PyTorch fp32/fp64 references of the individual kernels.
+
+Tolerances: MoE/conv fp32 forward 1e-4 rel, backward 1e-3 rel (f32 FMA chains on the matrix
+cores vs MKL summation order; fp32 atomics in a few column reductions)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.moe_common import load_fixture, loss_of, oracle_kwargs, rel_err
+
+pytestmark = pytest.mark.gpu
+
+FWD_TOL, BWD_TOL = 1e-4, 1e-3
+
+
+def _build(cfg, sd):
+    from sm3det_amd.convnext_moe import ConvNeXt_moe_MultiInput
+    net = ConvNeXt_moe_MultiInput(**cfg)
+    missing, unexpected = net.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    return net.cuda()
+
+
+def _ref_key_grads(net):
+    """parameter gradients under the reference key schema (fused expert tensors split per expert)."""
+    out = {}
+    for n, p in net.named_parameters():
+        if p.grad is None:
+            continue
+        leaf = n.rsplit('.', 1)[-1]
+        if leaf in ('w1', 'b1', 'w2', 'b2') and '.ffn.' in n:
+            ref = {'w1': 'pointwise_conv1.weight', 'b1': 'pointwise_conv1.bias', 'w2': 'pointwise_conv2.weight',
+                   'b2': 'pointwise_conv2.bias'}[leaf]
+            for e in range(p.shape[0]):
+                out[f'{n[:-len(leaf)]}experts.{e}.{ref}'] = p.grad[e]
+        else:
+            out[n] = p.grad
+    return out
+
+
+@pytest.mark.parametrize('name', ['moe_e4k2', 'moe_e8k3'])
+def test_eval_forward_matches_reference_fixture(name):
+    fx = load_fixture(name)
+    net = _build(fx['cfg'], fx['state_dict']).eval()
+    with torch.no_grad():
+        outs, gl = net(fx['x'].cuda(), ['single'])
+    assert len(outs) == 4
+    for o, r in zip(outs, fx['eval']['outs']):
+        assert tuple(o.shape) == tuple(r.shape)
+        assert rel_err(o, r) < FWD_TOL, rel_err(o, r)
+    assert rel_err(gl, fx['eval']['gate_loss']) < FWD_TOL
+
+
+@pytest.mark.parametrize('name', ['moe_e4k2', 'moe_e8k3'])
+def test_train_forward_backward_matches_reference_fixture(name):
+    fx = load_fixture(name)
+    net = _build(fx['cfg'], fx['state_dict']).train()
+    noise = [n.cuda() for n in fx['noise']]
+    drop = [d.cuda() for d in fx['drop_scale']]
+    outs, gl = net(fx['x'].cuda(), ['single'], noise=noise, drop_scale=drop)
+    for o, r in zip(outs, fx['train']['outs']):
+        assert rel_err(o, r) < FWD_TOL, rel_err(o, r)
+    assert rel_err(gl, fx['train']['gate_loss']) < FWD_TOL
+    loss_of(outs, gl).backward()
+    grads = _ref_key_grads(net)
+    worst = (0.0, None)
+    for k, g in fx['train']['grads'].items():
+        assert k in grads, f'no gradient produced for {k}'
+        e = rel_err(grads[k], g)
+        if e > worst[0]:
+            worst = (e, k)
+        assert e < BWD_TOL, (k, e)
+    print(f'\n{name}: {len(fx["train"]["grads"])} parameter gradients checked, worst rel err {worst[0]:.2e} at {worst[1]}')
+    # every expert parameter received a gradient (DDP contract), including experts with few/no tokens
+    for n, p in net.named_parameters():
+        assert p.grad is not None, n
+
+
+def test_tiny_e8t2_vs_cpu_oracle_eval_and_train():
+    """main_SM3Det.py backbone layout (ConvNeXt-T, 8 experts top-2, MoE in stages 1-3) on a 128x128 crop."""
+    from oracle import moe_oracle as MO
+    from sm3det_amd.convnext_moe import ConvNeXt_moe_MultiInput
+    torch.manual_seed(7)
+    cfg = dict(arch='tiny', MoE_Block_inds=[[], [0, 2], [0, 2, 4, 6, 8], [0, 2]], num_experts=8, top_k=2,
+               drop_path_rate=0.1)
+    net = ConvNeXt_moe_MultiInput(**cfg)
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for n, p in net.named_parameters():
+            if n.endswith('gamma'):
+                p.copy_(torch.empty_like(p).uniform_(0.5, 1.5, generator=g))
+            elif 'w_noise' in n:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.3)
+            elif 'sim_matrix' in n:
+                p.copy_(torch.randn(p.shape, generator=g))
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    x = torch.randn(2, 3, 128, 128, generator=g)
+    net = net.cuda().eval()
+    with torch.no_grad():
+        outs, gl = net([x[:1].cuda(), x[1:].cuda()], ['sar', 'rgb'])  # two modalities concatenated (:800)
+        ro, rg = MO.backbone_forward(x, sd, arch='tiny', moe_block_inds=cfg['MoE_Block_inds'], num_experts=8, top_k=2)
+    for o, r in zip(outs, ro):
+        assert rel_err(o, r) < FWD_TOL, rel_err(o, r)
+    assert rel_err(gl, rg) < FWD_TOL
+    # train mode with injected randomness, gradients of a few representative parameters vs oracle autograd
+    net.train()
+    blocks = [b for st in net.stages for b in st]
+    drop = [torch.tensor([1.0, 0.0]) / 1.0 if i % 5 == 4 else torch.ones(2) for i in range(len(blocks))]
+    toks = []
+    H = W = 32
+    for i, st in enumerate(net.stages):
+        if i > 0:
+            H, W = H // 2, W // 2
+        for b in st:
+            if b.MoE_cfg is not None:
+                toks.append(2 * H * W)
+    noise = [torch.randn(t, 8, generator=g) for t in toks]
+    outs, gl = net(x.cuda(), ['single'], noise=[n.cuda() for n in noise], drop_scale=[d.cuda() for d in drop])
+    loss_of(outs, gl).backward()
+    p = {k: v.clone().requires_grad_(v.is_floating_point() and not k.endswith(('.mean', '.std')))
+         for k, v in sd.items()}
+    ro, rg = MO.backbone_forward(x, p, arch='tiny', moe_block_inds=cfg['MoE_Block_inds'], num_experts=8, top_k=2,
+                                 train=True, noise=noise, drop_scale=drop)
+    for o, r in zip(outs, ro):
+        assert rel_err(o, r) < FWD_TOL
+    loss_of(ro, rg).backward()
+    grads = _ref_key_grads(net)
+    n_checked = 0
+    for k, v in p.items():
+        if v.grad is None:
+            continue
+        assert rel_err(grads[k], v.grad) < BWD_TOL, (k, rel_err(grads[k], v.grad))
+        n_checked += 1
+    assert n_checked > 300
+
+
+def test_no_moe_returns_plain_tuple():
+    from sm3det_amd.convnext_moe import ConvNeXt_moe_MultiInput
+    net = ConvNeXt_moe_MultiInput(arch='tiny').cuda().eval()
+    with torch.no_grad():
+        outs = net(torch.randn(1, 3, 64, 64).cuda(), ['single'])
+    assert isinstance(outs, tuple) and len(outs) == 4 and tuple(outs[3].shape) == (1, 768, 2, 2)
+
+
+def test_cpu_input_is_rejected():
+    from sm3det_amd.convnext_moe import ConvNeXt_moe_MultiInput
+    net = ConvNeXt_moe_MultiInput(arch='tiny')
+    with pytest.raises(RuntimeError):
+        net(torch.randn(1, 3, 64, 64), ['single'])
+
+
+# ------------------------------------------------------------------------------------------ kernel unit tests
+@pytest.mark.parametrize('C', [32, 96, 128, 192, 384, 768, 1024])
+def test_layernorm_fwd_bwd(C):
+    from sm3det_amd import backbone_ops as ops
+    T = 1000
+    x = torch.randn(T, C, device='cuda', requires_grad=True)
+    w = torch.rand(C, device='cuda', requires_grad=True) + 0.5
+    w = w.detach().requires_grad_(True)
+    b = torch.randn(C, device='cuda', requires_grad=True)
+    y = ops.layer_norm(x, w, b, 1e-6)
+    go = torch.randn_like(y)
+    y.backward(go)
+    xr, wr, br = (t.detach().double().requires_grad_(True) for t in (x, w, b))
+    yr = F.layer_norm(xr, (C,), wr, br, 1e-6)
+    yr.backward(go.double())
+    assert rel_err(y, yr) < 1e-5
+    assert rel_err(x.grad, xr.grad) < 1e-4 and rel_err(w.grad, wr.grad) < 1e-4 and rel_err(b.grad, br.grad) < 1e-4
+
+
+def test_layernorm_patch_major_is_the_downsample_im2col():
+    from sm3det_amd import backbone_ops as ops
+    B, H, W, C, Co = 2, 8, 12, 32, 64
+    x = torch.randn(B * H * W, C, device='cuda', requires_grad=True)
+    lw, lb = torch.rand(C, device='cuda') + 0.5, torch.randn(C, device='cuda')
+    cw = torch.randn(Co, C, 2, 2, device='cuda', requires_grad=True)
+    cb = torch.randn(Co, device='cuda', requires_grad=True)
+    pm = ops.layer_norm(x, lw, lb, 1e-6, patch_major=True, H=H, W=W)
+    y = ops.linear(pm, cw.permute(0, 2, 3, 1).reshape(Co, 4 * C), cb)  # (B*H/2*W/2, Co)
+    go = torch.randn_like(y)
+    y.backward(go)
+    xr = x.detach().double().requires_grad_(True)
+    cwr, cbr = cw.detach().double().requires_grad_(True), cb.detach().double().requires_grad_(True)
+    xn = F.layer_norm(xr, (C,), lw.double(), lb.double(), 1e-6).view(B, H, W, C).permute(0, 3, 1, 2)
+    yr = F.conv2d(xn, cwr, cbr, stride=2).permute(0, 2, 3, 1).reshape(-1, Co)
+    yr.backward(go.double())
+    assert rel_err(y, yr) < 1e-5
+    assert rel_err(x.grad, xr.grad) < 1e-4 and rel_err(cw.grad, cwr.grad) < 1e-4 and rel_err(cb.grad, cbr.grad) < 1e-4
+
+
+@pytest.mark.parametrize('B,H,W,C', [(2, 16, 16, 96), (1, 8, 24, 192), (1, 8, 8, 768), (2, 32, 32, 32)])
+def test_dwconv7_fwd_and_grads(B, H, W, C):
+    from sm3det_amd import _lib_backbone as LB
+    x = torch.randn(B, H, W, C, device='cuda')
+    w = torch.randn(C, 1, 7, 7, device='cuda') * 0.2
+    b = torch.randn(C, device='cuda')
+    w49 = w.view(C, 49).t().contiguous()
+    y = torch.empty_like(x)
+    LB.call('dwconv7_fwd', x, w49, b, None, y, B, H, W, C)
+    xr = x.double().permute(0, 3, 1, 2).requires_grad_(True)
+    wr, br = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    yr = F.conv2d(xr, wr, br, padding=3, groups=C)
+    assert rel_err(y, yr.permute(0, 2, 3, 1)) < 1e-5
+    go = torch.randn_like(y)
+    yr.backward(go.double().permute(0, 3, 1, 2))
+    res = torch.randn_like(x)
+    dx = torch.empty_like(x)
+    LB.call('dwconv7_fwd', go, w49.flip(0).contiguous(), None, res, dx, B, H, W, C)
+    assert rel_err(dx, xr.grad.permute(0, 2, 3, 1) + res.double()) < 1e-5
+    dw49, db = torch.empty(49, C, device='cuda'), torch.empty(C, device='cuda')
+    LB.call('dwconv7_bwd_weight', x, go, dw49, db, B, H, W, C)
+    assert rel_err(dw49.t().reshape(C, 1, 7, 7), wr.grad) < 1e-4
+    assert rel_err(db, br.grad) < 1e-4
+
+
+def test_stem_patchify_linear_equals_conv():
+    from sm3det_amd import backbone_ops as ops
+    x = torch.randn(2, 3, 64, 96, device='cuda')
+    w = torch.randn(96, 3, 4, 4, device='cuda', requires_grad=True)
+    b = torch.randn(96, device='cuda', requires_grad=True)
+    y = ops.linear(ops.stem_patchify(x), F.pad(w.reshape(96, 48), (0, 16)), b)
+    go = torch.randn_like(y)
+    y.backward(go)
+    wr, br = w.detach().double().requires_grad_(True), b.detach().double().requires_grad_(True)
+    yr = F.conv2d(x.double(), wr, br, stride=4).permute(0, 2, 3, 1).reshape(-1, 96)
+    yr.backward(go.double())
+    assert rel_err(y, yr) < 1e-5
+    assert rel_err(w.grad, wr.grad) < 1e-4 and rel_err(b.grad, br.grad) < 1e-4
+
+
+def test_moe_plan_tables_are_a_valid_expert_major_permutation():
+    from sm3det_amd import _lib, _lib_backbone as LB
+    T, E, k = 5000, 8, 2
+    m = k + 1
+    g = torch.Generator().manual_seed(0)
+    top = torch.stack([torch.randperm(E, generator=g)[:m] for _ in range(T)]).to(torch.int32).cuda()
+    offsets = torch.empty(E + 1, dtype=torch.int32, device='cuda')
+    slot_token = torch.empty(T * k, dtype=torch.int32, device='cuda')
+    token_slot = torch.empty(T, k, dtype=torch.int32, device='cuda')
+    nb = _lib.lib().sm3_moe_plan_workspace_bytes(T, E)
+    ws = _lib.workspace(nb, top.device)
+    LB.call('moe_plan', top, m, T, E, k, offsets, slot_token, token_slot, ws, nb)
+    counts = torch.bincount(top[:, :k].reshape(-1).long(), minlength=E).cpu()
+    off = offsets.cpu().long()
+    assert off[0] == 0 and off[-1] == T * k and torch.equal(off[1:] - off[:-1], counts)
+    st, ts = slot_token.cpu().long(), token_slot.cpu().long()
+    assert torch.equal(torch.sort(ts.reshape(-1))[0], torch.arange(T * k))  # bijection
+    for e in range(E):
+        seg = st[off[e]:off[e + 1]]
+        assert torch.all(seg[1:] > seg[:-1])  # token order inside an expert: deterministic
+        assert torch.all((top[:, :k].cpu()[seg] == e).any(1))
+    for j in range(k):
+        assert torch.equal(st[ts[:, j]], torch.arange(T))
