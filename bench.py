@@ -1,0 +1,247 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the SM3Det hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]            (N=1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W                  (N>1, one rank per GPU over RCCL)
+
+Metric (BASELINE.json): train imgs/sec, SM3Det ConvNeXt-T e8t2 @1024^2, bs2/GPU.
+Workload timed here (config.workload): one TRAINING STEP of the hot path = the `main_SM3Det.py` backbone
+(ConvNeXt_moe_MultiInput, ConvNeXt-T, 8 experts top-2, MoE in stages 1-3: 9 MoE + 9 dense blocks, drop_path 0.1,
+noisy gating) forward + backward in fp32 on a synthetic (2,3,1024,1024) batch per GPU, gradient all-reduce across
+ranks (bucketed, overlapped with backward) and a fused AdamW step.  The detector's FPN/heads (mmdet glue, SURVEY.md
+8(f) "next" rows) are NOT part of the timed step; the rotated-detection operators of hot path (b) are reported as
+per-op timings in `ops_us`, outside `value`.
+
+Printed JSON line (rank 0): the contract fields + `roofline` (dominant kernel = fp32 MFMA GEMM family, per-launch
+HIP events on the launch stream) + `cpu_baseline` (the CPU oracle timed on this host, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MI355X_FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+BACKBONE_CFG = dict(arch='tiny', MoE_Block_inds=[[], [0, 2], [0, 2, 4, 6, 8], [0, 2]], num_experts=8, top_k=2,
+                    drop_path_rate=0.1)  # local_configs/main_SM3Det.py:13-21
+BATCH, RES = 2, 1024
+
+
+def build_model():
+    from sm3det_amd.convnext_moe import ConvNeXt_moe_MultiInput
+    torch.manual_seed(0)
+    net = ConvNeXt_moe_MultiInput(**BACKBONE_CFG)
+    with torch.no_grad():  # layer scale 1e-6 would hide the FFN/MoE branch numerically; use O(1) like a trained net
+        for n, p in net.named_parameters():
+            if n.endswith('gamma'):
+                p.fill_(1.0)
+    return net
+
+
+def loss_fn(outs, gate_loss, proj):
+    loss = gate_loss
+    for o, r in zip(outs, proj):
+        loss = loss + (o * r).sum() * 1e-4
+    return loss
+
+
+def cpu_baseline():
+    """The CPU oracle (oracle/moe_oracle.py, a restatement of the reference module) doing the SAME step
+    (fwd+bwd, fp32, same layout) once on this host's cores."""
+    from oracle import moe_oracle as MO
+    torch.manual_seed(0)
+    net = build_model()
+    p = {k: v.detach().clone().requires_grad_(v.is_floating_point() and not k.endswith(('.mean', '.std')))
+         for k, v in net.state_dict().items()}
+    g = torch.Generator().manual_seed(0)
+    kw = dict(arch='tiny', moe_block_inds=BACKBONE_CFG['MoE_Block_inds'], num_experts=8, top_k=2, train=True)
+
+    def run(b, res):
+        x = torch.randn(b, 3, res, res, generator=g)
+        toks, H = [], res // 4
+        for i, inds in enumerate(BACKBONE_CFG['MoE_Block_inds']):
+            if i > 0:
+                H //= 2
+            toks += [b * H * H] * len(inds)
+        noise = [torch.randn(t, 8, generator=g) for t in toks]
+        t0 = time.perf_counter()
+        outs, gl = MO.backbone_forward(x, p, noise=noise, **kw)
+        (sum((o * o).mean() for o in outs) + gl).backward()
+        return time.perf_counter() - t0
+
+    run(1, 128)  # warm-up (allocator, MKL threads)
+    b, res = 1, 512
+    dt = run(b, res)
+    imgs_1024 = b * (res / RES) ** 2
+    return dict(value=imgs_1024 / dt, unit='imgs/sec', cores=torch.get_num_threads(), kind='port',
+                sample=f'1 training step (fwd+bwd) of the CPU oracle on {b}x3x{res}x{res} ({dt:.1f} s), '
+                       f'scaled by pixel count to 1024^2 images')
+
+
+def ops_microbench():
+    """per-op timings (microseconds) of hot path (b) at the SURVEY.md 8(d) shapes."""
+    import numpy as np
+    from sm3det_amd import mmcv_ops as ops
+    from tests import synth
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+
+    def timeit(fn, n=10):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e6
+
+    out = {}
+    b1, b2 = dev(synth.rotated_boxes(2000, 0)), dev(synth.rotated_boxes(512, 1))
+    out['box_iou_rotated_2000x512'] = timeit(lambda: ops.box_iou_rotated(b1, b2))
+    d, s = dev(synth.rotated_boxes(2000, 2, cluster=True)), dev(synth.unique_scores(2000, 3))
+    out['nms_rotated_2000'] = timeit(lambda: ops.nms_rotated(d, s, 0.1))
+    hb, hs = dev(synth.hboxes(8768, 4, cluster=True)), dev(synth.unique_scores(8768, 5))
+    out['nms_8768'] = timeit(lambda: ops.nms(hb, hs, iou_threshold=0.8))
+    x = torch.randn(1, 256, 256, 256, device='cuda', requires_grad=True)
+    rois = dev(synth.rois_for_level(512, 6, batch=1, extent=1024.0))
+    layer = ops.RoIAlignRotated(output_size=7, spatial_scale=0.25, sampling_ratio=2, clockwise=True)
+    out['roi_align_rotated_fwd_512x256x7x7'] = timeit(lambda: layer(x, rois))
+    y = layer(x, rois)
+    go = torch.randn_like(y)
+    out['roi_align_rotated_bwd_512x256x7x7'] = timeit(lambda: torch.autograd.grad(y, x, go, retain_graph=True))
+    return {k: round(v, 1) for k, v in out.items()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-ops', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    torch.cuda.set_device(local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world,
+                                device_id=torch.device('cuda', local_rank))
+
+    from sm3det_amd import _lib, _lib_backbone as LB
+    from sm3det_amd.data_parallel import BucketedGradReducer
+    _lib.lib()  # fail loudly if the HIP extension is missing
+
+    net = build_model().cuda().train()
+    params = [p for p in net.parameters() if p.requires_grad]
+    reducer = BucketedGradReducer(params, bucket_mb=64.0)
+    reducer.broadcast_parameters(0)
+    opt = torch.optim.AdamW(params, lr=1e-4, betas=(0.9, 0.999), weight_decay=0.05, fused=True)
+
+    g = torch.Generator(device='cpu').manual_seed(rank)  # rank r draws its own synthetic shard
+    x = torch.randn(BATCH, 3, RES, RES, generator=g).cuda()
+    proj = None
+
+    def step():
+        nonlocal proj
+        reducer.zero_grad()
+        outs, gl = net(x, ['single'])
+        if proj is None:
+            gp = torch.Generator(device='cpu').manual_seed(1000 + rank)
+            proj = [torch.randn(o.shape, generator=gp).cuda().contiguous(memory_format=torch.channels_last)
+                    for o in outs]
+        loss = loss_fn(outs, gl, proj)
+        loss.backward()
+        reducer.finalize()
+        opt.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device='cuda', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = world * BATCH * args.steps / dt
+
+    # ---- roofline of the dominant kernel: one more identical step with HIP events around every launch ---------
+    roofline = None
+    kernels = {}
+    if rank == 0:
+        LB.PROFILE = []
+        step()
+        torch.cuda.synchronize()
+        prof, LB.PROFILE = LB.PROFILE, None
+        for name, flops, nbytes, e0, e1 in prof:
+            k = kernels.setdefault(name, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+            k['launches'] += 1
+            k['ms'] += e0.elapsed_time(e1)
+            k['flops'] += flops
+            k['bytes'] += nbytes
+        gem = [v for n, v in kernels.items() if n.startswith('gemm_f32')]
+        g_ms = sum(v['ms'] for v in gem)
+        g_fl = sum(v['flops'] for v in gem)
+        g_n = sum(v['launches'] for v in gem)
+        achieved = g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
+        roofline = dict(bound='mfma', kernel='gemm_f32_kernel (NT/NN/TN, fp32 v_mfma_f32_32x32x2_f32)',
+                        achieved=round(achieved, 2), peak=MI355X_FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
+                        frac=round(achieved / MI355X_FP32_MFMA_PEAK_TFLOPS, 4), traffic=None,
+                        launches_per_step=g_n, avg_launch_us=round(g_ms / max(g_n, 1) * 1e3, 2),
+                        algorithmic_gflop_per_step=round(g_fl / 1e9, 1),
+                        gemm_ms_per_step=round(g_ms, 3),
+                        other_kernels_ms_per_step=round(sum(v['ms'] for n, v in kernels.items()
+                                                            if not n.startswith('gemm_f32')), 3))
+
+    result = None
+    if rank == 0:
+        result = {
+            'metric': 'train imgs/sec SM3Det ConvNeXt-T e8t2 @1024^2 bs2/GPU (hot path: MoE backbone train step)',
+            'value': round(value, 3), 'unit': 'imgs/sec', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'main_SM3Det.py backbone (ConvNeXt_moe_MultiInput tiny, 8 experts top-2, 9 MoE + 9 '
+                                   'dense blocks) fwd+bwd + bucketed grad all-reduce + fused AdamW; synthetic '
+                                   f'randn({BATCH},3,{RES},{RES}) per GPU, random-init weights; FPN/heads excluded',
+                       'global_batch': world * BATCH, 'resolution': RES, 'parallelism': f'dp{world}',
+                       'grad_buckets': reducer.num_buckets},
+            'loss': float(loss),
+            'roofline': roofline,
+            'kernels_ms_per_step': {n: round(v['ms'], 3) for n, v in sorted(kernels.items(), key=lambda kv: -kv[1]['ms'])},
+        }
+        if world == 1 and not args.no_ops:
+            result['ops_us'] = ops_microbench()
+        if world == 1 and not args.no_cpu_baseline:
+            result['cpu_baseline'] = cpu_baseline()
+        else:
+            result['cpu_baseline'] = None
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -48,12 +48,37 @@ def signatures():
     }
 
 
-def call(name, *args):
+# Per-launch profiling hook (bench.py): when PROFILE is a list, every C-ABI call is bracketed by HIP events recorded
+# on the stream the kernels are launched on, and (name, algorithmic flops, algorithmic bytes, ev0, ev1) is appended.
+PROFILE = None
+
+
+class _Prof:
+    def __init__(self, name, flops=0.0, nbytes=0.0):
+        self.rec = PROFILE is not None
+        if self.rec:
+            self.item = [name, float(flops), float(nbytes), torch.cuda.Event(enable_timing=True),
+                         torch.cuda.Event(enable_timing=True)]
+
+    def __enter__(self):
+        if self.rec:
+            self.item[3].record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.rec:
+            self.item[4].record()
+            PROFILE.append(tuple(self.item))
+        return False
+
+
+def call(name, *args, flops=0.0, nbytes=0.0):
     """Invoke `sm3_<name>` with tensors converted to device pointers and the current stream appended."""
     from . import _lib
     L = _lib.lib()
     conv = [(_p(a) if (a is None or isinstance(a, torch.Tensor)) else a) for a in args]
-    _lib.check(getattr(L, 'sm3_' + name)(*conv, _lib.stream_ptr()), name)
+    with _Prof(name, flops, nbytes):
+        _lib.check(getattr(L, 'sm3_' + name)(*conv, _lib.stream_ptr()), name)
 
 
 def _p(t):
@@ -95,14 +120,17 @@ def gemm(mode, A, B, C, M, N, K, *, epilogue=EPI_NONE, bias=None, aux_in=None, a
     if mode == TN:
         nbytes = L.sm3_gemm_f32_workspace_bytes(ctypes.byref(d))
         ws = _lib.workspace(nbytes, C.device)
-    _lib.check(L.sm3_gemm_f32(ctypes.byref(d), _p(ws), nbytes, _lib.stream_ptr()), 'gemm_f32')
+    rows = K if mode == TN else M
+    with _Prof('gemm_f32_' + ('nt', 'nn', 'tn')[mode], 2.0 * rows * N * (M if mode == TN else K)):
+        _lib.check(L.sm3_gemm_f32(ctypes.byref(d), _p(ws), nbytes, _lib.stream_ptr()), 'gemm_f32')
 
 
 def colsum(x, M, N, out, offsets=None, num_groups=1, ld=None):
     from . import _lib
     L = _lib.lib()
-    _lib.check(L.sm3_colsum_f32(_p(x), ld or N, M, N, _p(offsets), num_groups, _p(out), _lib.stream_ptr()),
-               'colsum_f32')
+    with _Prof('colsum_f32', M * N, 4.0 * M * N):
+        _lib.check(L.sm3_colsum_f32(_p(x), ld or N, M, N, _p(offsets), num_groups, _p(out), _lib.stream_ptr()),
+                   'colsum_f32')
 
 
 def tn_splits(tiles, rows, target_blocks=1024):

@@ -1,0 +1,125 @@
+"""Data-parallel gradient exchange for the hot path: one process per GPU, RCCL over xGMI (torch.distributed backend
+"nccl" IS RCCL on ROCm), bucketed all-reduce overlapped with backward.
+
+What it replaces: the reference wraps the detector in ``MMDistributedDataParallel`` (mmcv/mmcv/parallel/
+distributed.py:13-87 -> torch DDP's C++ reducer, 25 MiB buckets, mmrotate/apis/train.py:53-57) and then issues
+~15 blocking scalar all-reduces per step for the log vars.  Here:
+
+* gradients live in a few large flat buckets (``p.grad`` are views into them), sized for xGMI: the 8-GPU mesh is
+  point-to-point (7 links x ~153 GB/s per GPU), so a ring collective is per-link bound and small messages are
+  latency-bound -- default 64 MiB buckets (~1.7 ms each at one-link ring speed) give ~9 collectives for the 140 M
+  parameter backbone instead of DDP's ~23;
+* buckets are filled in reverse parameter order (= the order backward produces gradients) and each one is
+  all-reduced asynchronously the moment its last gradient has been accumulated, on RCCL's own stream, overlapping
+  the remaining backward kernels;
+* ``finalize()`` waits for the outstanding collectives and applies the 1/world_size mean in one pass per bucket;
+* ``allreduce_scalars()`` fuses any number of logging scalars into ONE small all-reduce.
+
+The class is backend-agnostic (it only uses ``torch.distributed`` collectives), so the world_size-2 CPU tests run it
+over ``gloo``.  MoE routing is rank-local (all experts replicated, no all-to-all), as in the reference.
+"""
+import torch
+import torch.distributed as dist
+
+
+class BucketedGradReducer:
+    def __init__(self, params, bucket_mb=64.0, process_group=None):
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError('no trainable parameters')
+        cap = int(bucket_mb * 1024 * 1024)
+        # reverse order: the last layers' gradients are ready first
+        self.buckets = []  # dicts: flat, params, pending, handle
+        cur, cur_bytes = [], 0
+        for p in reversed(self.params):
+            nbytes = p.numel() * p.element_size()
+            if cur and (cur_bytes + nbytes > cap or cur[0].dtype != p.dtype or cur[0].device != p.device):
+                self._close(cur)
+                cur, cur_bytes = [], 0
+            cur.append(p)
+            cur_bytes += nbytes
+        if cur:
+            self._close(cur)
+        self._index = {}
+        for bi, b in enumerate(self.buckets):
+            for p in b['params']:
+                self._index[p] = bi
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+        self._armed = False
+
+    def _close(self, plist):
+        total = sum(p.numel() for p in plist)
+        flat = torch.zeros(total, dtype=plist[0].dtype, device=plist[0].device)
+        off = 0
+        for p in plist:
+            n = p.numel()
+            p.grad = flat[off:off + n].view_as(p)  # gradient-as-bucket-view
+            off += n
+        self.buckets.append(dict(flat=flat, params=plist, pending=len(plist), handle=None))
+
+    # ------------------------------------------------------------------------------------------------ step API
+    def zero_grad(self):
+        """Call instead of optimizer.zero_grad(set_to_none=True): keeps the bucket views, zeroes the flats."""
+        for b in self.buckets:
+            b['flat'].zero_()
+            b['pending'] = len(b['params'])
+            b['handle'] = None
+        off_check = self.buckets[0]['params'][0]
+        if off_check.grad is None or off_check.grad.data_ptr() != self.buckets[0]['flat'].data_ptr():
+            self._rebind()
+        self._armed = True
+
+    def _rebind(self):
+        for b in self.buckets:
+            off = 0
+            for p in b['params']:
+                n = p.numel()
+                p.grad = b['flat'][off:off + n].view_as(p)
+                off += n
+
+    def _on_grad(self, p):
+        if not self._armed:
+            return
+        b = self.buckets[self._index[p]]
+        b['pending'] -= 1
+        if b['pending'] == 0 and self.world > 1:
+            b['handle'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def finalize(self):
+        """Wait for the in-flight collectives (launching any whose parameters never produced a gradient) and turn
+        the sums into means."""
+        if self.world > 1:
+            for b in self.buckets:
+                if b['handle'] is None:  # some parameter got no gradient this step: reduce the zeros too
+                    b['handle'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            for b in self.buckets:
+                b['handle'].wait()
+                b['flat'].div_(self.world)
+                b['handle'] = None
+        self._armed = False
+
+    def allreduce_scalars(self, values):
+        """mean of a list of 0-d tensors over the ranks with ONE collective (replaces the reference's one
+        all-reduce + .item() per log var)."""
+        t = torch.stack([v.detach().float().reshape(()) for v in values])
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            t /= self.world
+        return t
+
+    def broadcast_parameters(self, src=0):
+        """rank-0 parameters/buffers to everyone (torch DDP does this at construction)."""
+        if self.world > 1:
+            for p in self.params:
+                dist.broadcast(p.data, src=src, group=self.group)
+
+    def remove_hooks(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+    @property
+    def num_buckets(self):
+        return len(self.buckets)
