@@ -117,9 +117,10 @@ int sm3_roi_align_rotated_backward(const float* grad_output, const float* rois, 
 #define SM3_GEMM_TN 2
 #define SM3_EPI_NONE 0           /* C = acc */
 #define SM3_EPI_BIAS 1           /* C = acc + bias[n] */
-#define SM3_EPI_BIAS_GELU 2      /* aux_out = acc + bias ; C = gelu_erf(aux_out)              (FFN first linear) */
+#define SM3_EPI_BIAS_GELU 2      /* h = acc + bias ; C = gelu_erf(h) ; aux_out = gelu_erf'(h) (FFN first linear) */
 #define SM3_EPI_BIAS_SCALE_RES 3 /* aux_out = y = acc + bias ; C = aux_in + gamma[n]*rowscale[m/rows_per_scale]*y */
-#define SM3_EPI_GELU_BWD 4       /* C = acc * gelu_erf'(aux_in)                               (dgrad through GELU) */
+#define SM3_EPI_GELU_BWD 4       /* C = acc * aux_in (aux_in = saved gelu'); optional colsum_out[g][n] = column sums of C
+                                    per group = the first linear's bias gradient (needs workspace)               */
 typedef struct sm3_gemm_desc {
   int32_t mode, epilogue;
   const float* A;
@@ -138,6 +139,7 @@ typedef struct sm3_gemm_desc {
   const float* rowscale;
   int32_t rows_per_scale;
   int32_t ld_aux;
+  float* colsum_out; /* EPI_GELU_BWD only, may be NULL */
 } sm3_gemm_desc;
 size_t sm3_gemm_f32_workspace_bytes(const sm3_gemm_desc* desc);
 int sm3_gemm_f32(const sm3_gemm_desc* desc, void* workspace, size_t workspace_bytes, sm3_stream_t stream);
@@ -157,9 +159,11 @@ int sm3_stem_patchify(const float* x, float* a, int B, int H, int W, sm3_stream_
  * accumulate_dx != 0 adds into dx. */
 int sm3_layernorm_fwd(const float* x, const float* w, const float* b, float eps, float* y, float* mean, float* rstd,
                       long T, int C, int out_mode, int H, int W, sm3_stream_t stream);
+/* scratch for the column reductions of layernorm_bwd / scale_bwd_prep / moe_combine_bwd (per-block partials) */
+size_t sm3_row_reduce_workspace_bytes(int C);
 int sm3_layernorm_bwd(const float* dy, const float* x, const float* w, const float* mean, const float* rstd,
                       float* dx, float* dwdb, long T, int C, int out_mode, int H, int W, int accumulate_dx,
-                      sm3_stream_t stream);
+                      void* workspace, size_t workspace_bytes, sm3_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Depthwise 7x7, padding 3 (ConvNeXtBlock.depthwise_conv, convnext_moe.py:311-312,347) on NHWC tokens.
@@ -172,9 +176,10 @@ int sm3_dwconv7_bwd_weight(const float* x, const float* du, float* dw49, float* 
                            sm3_stream_t stream);
 
 /* layer-scale / stochastic-depth backward of a dense block (:368-370): dy = gamma*rs[b]*dout ;
- * dgamma[c] = sum_t rs[b]*dout[t,c]*y[t,c]  (overwritten) */
+ * dgamma_db (2C, overwritten) = [ dgamma[c] = sum_t rs[b]*dout[t,c]*y[t,c] | db2[c] = sum_t dy[t,c] ] */
 int sm3_scale_bwd_prep(const float* dout, const float* y, const float* gamma, const float* rowscale,
-                       int rows_per_scale, float* dy, float* dgamma, long T, int C, sm3_stream_t stream);
+                       int rows_per_scale, float* dy, float* dgamma_db, long T, int C, void* workspace,
+                       size_t workspace_bytes, sm3_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * MoE router (CosineTopKGate.forward :99-106 + noisy_top_k_gating :194-223 + _prob_in_top_k :152-174).
@@ -209,7 +214,8 @@ int sm3_moe_combine_fwd(const float* yslot, const int32_t* token_slot, const flo
                         int k, sm3_stream_t stream);
 int sm3_moe_combine_bwd(const float* dout, const float* yslot, const int32_t* token_slot, const float* gates,
                         const float* gamma, const float* rowscale, int rows_per_scale, float* dyslot, float* dgate,
-                        float* dgamma, long T, int C, int k, sm3_stream_t stream);
+                        float* dgamma, long T, int C, int k, void* workspace, size_t workspace_bytes,
+                        sm3_stream_t stream);
 /* dx[t] (+)= sum_j dxslot[token_slot[t,j]]  (backward of dispatch) */
 int sm3_moe_gather_add(const float* dxslot, const int32_t* token_slot, float* dx, long T, int C, int k,
                        int accumulate, sm3_stream_t stream);

@@ -21,6 +21,7 @@ class GemmDesc(ctypes.Structure):
         ('stride_b', ctypes.c_int64), ('stride_bias', ctypes.c_int64),
         ('bias', P), ('aux_in', P), ('aux_out', P), ('gamma', P), ('rowscale', P),
         ('rows_per_scale', ctypes.c_int32), ('ld_aux', ctypes.c_int32),
+        ('colsum_out', P),
     ]
 
 
@@ -33,17 +34,18 @@ def signatures():
         'sm3_colsum_f32': (I, [P, I, I, I, P, I, P, P]),
         'sm3_stem_patchify': (I, [P, P, I, I, I, P]),
         'sm3_layernorm_fwd': (I, [P, P, P, F, P, P, P, LL, I, I, I, I, P]),
-        'sm3_layernorm_bwd': (I, [P, P, P, P, P, P, P, LL, I, I, I, I, I, P]),
+        'sm3_row_reduce_workspace_bytes': (S, [I]),
+        'sm3_layernorm_bwd': (I, [P, P, P, P, P, P, P, LL, I, I, I, I, I, P, S, P]),
         'sm3_dwconv7_fwd': (I, [P, P, P, P, P, I, I, I, I, P]),
         'sm3_dwconv7_bwd_weight': (I, [P, P, P, P, I, I, I, I, P]),
-        'sm3_scale_bwd_prep': (I, [P, P, P, P, I, P, P, LL, I, P]),
+        'sm3_scale_bwd_prep': (I, [P, P, P, P, I, P, P, LL, I, P, S, P]),
         'sm3_moe_router_fwd': (I, [P, I, I, P, P, P, I, I, I, I, P, P, P, P, P, P, P, P]),
         'sm3_moe_router_bwd': (I, [P, I, I, P, P, P, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P]),
         'sm3_moe_plan_workspace_bytes': (S, [I, I]),
         'sm3_moe_plan': (I, [P, I, I, I, I, P, P, P, P, S, P]),
         'sm3_moe_dispatch': (I, [P, P, P, LL, I, P]),
         'sm3_moe_combine_fwd': (I, [P, P, P, P, P, P, I, P, LL, I, I, P]),
-        'sm3_moe_combine_bwd': (I, [P, P, P, P, P, P, I, P, P, P, LL, I, I, P]),
+        'sm3_moe_combine_bwd': (I, [P, P, P, P, P, P, I, P, P, P, LL, I, I, P, S, P]),
         'sm3_moe_gather_add': (I, [P, P, P, LL, I, I, I, P]),
     }
 
@@ -87,7 +89,7 @@ def _p(t):
 
 def gemm(mode, A, B, C, M, N, K, *, epilogue=EPI_NONE, bias=None, aux_in=None, aux_out=None, gamma=None,
          rowscale=None, rows_per_scale=1, offsets=None, num_groups=1, splits=1, lda=None, ldb=None, ldc=None,
-         ld_aux=None):
+         ld_aux=None, colsum_out=None):
     """Enqueue one GEMM of the family on torch's current stream.  All tensors fp32, on the current device."""
     from . import _lib
     L = _lib.lib()
@@ -115,9 +117,10 @@ def gemm(mode, A, B, C, M, N, K, *, epilogue=EPI_NONE, bias=None, aux_in=None, a
     d.bias, d.aux_in, d.aux_out, d.gamma, d.rowscale = _p(bias), _p(aux_in), _p(aux_out), _p(gamma), _p(rowscale)
     d.rows_per_scale = rows_per_scale
     d.ld_aux = ld_aux or N
+    d.colsum_out = _p(colsum_out)
     ws = None
     nbytes = 0
-    if mode == TN:
+    if mode == TN or colsum_out is not None:
         nbytes = L.sm3_gemm_f32_workspace_bytes(ctypes.byref(d))
         ws = _lib.workspace(nbytes, C.device)
     rows = K if mode == TN else M
@@ -138,3 +141,10 @@ def tn_splits(tiles, rows, target_blocks=1024):
     s = max(1, target_blocks // max(tiles, 1))
     s = min(s, max(1, rows // 256))
     return int(s)
+
+
+def row_ws(C, like):
+    """scratch for the per-block column partials of the row kernels"""
+    from . import _lib
+    nb = _lib.lib().sm3_row_reduce_workspace_bytes(C)
+    return _lib.workspace(nb, like.device), nb

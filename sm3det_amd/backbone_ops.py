@@ -106,7 +106,8 @@ class _LayerNorm(Function):
         T, C = x.shape
         dx = _e(T, C, like=x)
         dwdb = _e(2, C, like=x)
-        call('layernorm_bwd', dy.contiguous(), x, w, mean, rstd, dx, dwdb, T, C, mode, H, W, 0)
+        ws, nb = LB.row_ws(C, x)
+        call('layernorm_bwd', dy.contiguous(), x, w, mean, rstd, dx, dwdb, T, C, mode, H, W, 0, ws, nb)
         return dx, dwdb[0], dwdb[1], None, None, None, None
 
 
@@ -131,7 +132,8 @@ def _dw_ln_backward(dxn, dout, x, u, w49, lnw, mean, rstd, B, H, W, C):
     T = B * H * W
     du = _e(T, C, like=x)
     dwdb = _e(2, C, like=x)
-    call('layernorm_bwd', dxn, u, lnw, mean, rstd, du, dwdb, T, C, 0, H, W, 0)
+    ws, nb = LB.row_ws(C, x)
+    call('layernorm_bwd', dxn, u, lnw, mean, rstd, du, dwdb, T, C, 0, H, W, 0, ws, nb)
     dx = _e(T, C, like=x)
     call('dwconv7_fwd', du, w49.flip(0).contiguous(), None, dout, dx, B, H, W, C)
     dw49, dbdw = _e(49, C, like=x), _e(C, like=x)
@@ -148,7 +150,7 @@ class _DenseBlock(Function):
         Hd = w1.shape[0]
         u, xn, mean, rstd = _dw_ln_forward(x, w49, bdw, lnw, lnb, eps, B, H, W, C)
         hpre, act = _e(T, Hd, like=x), _e(T, Hd, like=x)
-        gemm(LB.NT, xn, w1, act, T, Hd, C, epilogue=LB.EPI_BIAS_GELU, bias=b1, aux_out=hpre)
+        gemm(LB.NT, xn, w1, act, T, Hd, C, epilogue=LB.EPI_BIAS_GELU, bias=b1, aux_out=hpre)  # hpre := gelu'(h)
         y, out = _e(T, C, like=x), _e(T, C, like=x)
         gemm(LB.NT, act, w2, out, T, C, Hd, epilogue=LB.EPI_BIAS_SCALE_RES, bias=b2, aux_in=x, aux_out=y,
              gamma=gamma, rowscale=rs, rows_per_scale=H * W)
@@ -163,15 +165,13 @@ class _DenseBlock(Function):
         T, C = x.shape
         Hd = w1.shape[0]
         dout = dout.contiguous()
-        dy, dgamma = _e(T, C, like=x), _e(C, like=x)
-        call('scale_bwd_prep', dout, y, gamma, rs, H * W, dy, dgamma, T, C)
-        db2 = _e(C, like=x)
-        colsum(dy, T, C, db2)
+        dy, dgdb = _e(T, C, like=x), _e(2, C, like=x)
+        ws, nb = LB.row_ws(C, x)
+        call('scale_bwd_prep', dout, y, gamma, rs, H * W, dy, dgdb, T, C, ws, nb)
+        dgamma, db2 = dgdb[0], dgdb[1]
         dw2 = _tn(dy, act, C, Hd, T)
-        dh = _e(T, Hd, like=x)
-        gemm(LB.NN, dy, w2, dh, T, Hd, C, epilogue=LB.EPI_GELU_BWD, aux_in=hpre)
-        db1 = _e(Hd, like=x)
-        colsum(dh, T, Hd, db1)
+        dh, db1 = _e(T, Hd, like=x), _e(Hd, like=x)
+        gemm(LB.NN, dy, w2, dh, T, Hd, C, epilogue=LB.EPI_GELU_BWD, aux_in=hpre, colsum_out=db1)
         dw1 = _tn(dh, xn, Hd, C, T)
         dxn = dy  # reuse the (T,C) buffer
         gemm(LB.NN, dh, w1, dxn, T, C, Hd)
@@ -247,15 +247,16 @@ class _MoEBlock(Function):
         dload = torch.zeros(E, device=x.device) if dload is None else dload.contiguous().float()
         # combine backward
         dyslot, dgate, dgamma = _e(S, C, like=x), _e(T, k, like=x), _e(C, like=x)
-        call('moe_combine_bwd', dout, yslot, token_slot, gates, gamma, rs, H * W, dyslot, dgate, dgamma, T, C, k)
+        ws, nb = LB.row_ws(C, x)
+        call('moe_combine_bwd', dout, yslot, token_slot, gates, gamma, rs, H * W, dyslot, dgate, dgamma, T, C, k, ws,
+             nb)
         # experts backward (every expert gets a -- possibly zero -- gradient: DDP-safe)
         db2 = _e(E, C, like=x)
         colsum(dyslot, S, C, db2, offsets=offsets, num_groups=E)
         dw2 = _tn(dyslot, act, C, Hd, S, offsets=offsets, num_groups=E)
-        dh = _e(S, Hd, like=x)
-        gemm(LB.NN, dyslot, w2, dh, S, Hd, C, epilogue=LB.EPI_GELU_BWD, aux_in=hpre, offsets=offsets, num_groups=E)
-        db1 = _e(E, Hd, like=x)
-        colsum(dh, S, Hd, db1, offsets=offsets, num_groups=E)
+        dh, db1 = _e(S, Hd, like=x), _e(E, Hd, like=x)
+        gemm(LB.NN, dyslot, w2, dh, S, Hd, C, epilogue=LB.EPI_GELU_BWD, aux_in=hpre, offsets=offsets, num_groups=E,
+             colsum_out=db1)
         dw1 = _tn(dh, xslot, Hd, C, S, offsets=offsets, num_groups=E)
         dxslot = dyslot  # reuse
         gemm(LB.NN, dh, w1, dxslot, S, C, Hd, offsets=offsets, num_groups=E)

@@ -45,6 +45,57 @@ __global__ void stem_patchify_kernel(const float* __restrict__ x, float* __restr
   }
 }
 
+
+// ---- column reductions of the row kernels ------------------------------------------------------------------------
+// Each lane accumulates NSETS x NV float4 column partials over the tokens it visited.  They are folded across the
+// wave's token groups (shuffles), across the block's 4 waves (LDS) and written to partials[block][set][C]; a second
+// tiny kernel sums over blocks.  No atomics: contended same-address L2 atomics cost ~200 us per launch here.
+constexpr int ROW_MAX_BLOCKS = 512;
+template <int G, int NV, int NSETS>
+__device__ __forceinline__ void block_colsum_store(f32x4 (&acc)[NSETS][NV], float* __restrict__ partials, int C) {
+  extern __shared__ __attribute__((aligned(16))) float s_red[];  // [4][NSETS][C]
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lg = lane % G, tg = lane / G;
+  const int nq = C >> 2;
+#pragma unroll
+  for (int s = 0; s < NSETS; s++)
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+      f32x4 v = acc[s][i];
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        for (int o = G; o < 64; o <<= 1) v[j] += __shfl_xor(v[j], o, 64);
+      const int q = lg + i * G;
+      if (tg == 0 && q < nq) st4(s_red + ((long)wv * NSETS + s) * C + 4 * q, v);
+    }
+  __syncthreads();
+  for (int i = threadIdx.x; i < NSETS * C; i += blockDim.x) {
+    const float t = (s_red[i] + s_red[(long)NSETS * C + i]) + (s_red[2L * NSETS * C + i] + s_red[3L * NSETS * C + i]);
+    partials[(long)blockIdx.x * NSETS * C + i] = t;
+  }
+}
+// out[c] = sum_b partials[b][c]; block = 64 columns x 4 row lanes, rows strided by 4 with 4 independent loads in flight
+__global__ __launch_bounds__(256) void partials_reduce_kernel(const float* __restrict__ partials, int nblocks,
+                                                             int ncols, float* __restrict__ out) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < ncols) {
+    int b = rl;
+    for (; b + 12 < nblocks; b += 16) {
+      s0 += partials[(long)b * ncols + c];
+      s1 += partials[(long)(b + 4) * ncols + c];
+      s2 += partials[(long)(b + 8) * ncols + c];
+      s3 += partials[(long)(b + 12) * ncols + c];
+    }
+    for (; b < nblocks; b += 4) s0 += partials[(long)b * ncols + c];
+  }
+  red[rl][cl] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (rl == 0 && c < ncols) out[c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+}
+
 // ============================================================================================== LayerNorm rows
 // out_mode 0: y row = token; 1: patch-major rows for the 2x2/s2 downsample conv: token (b,h,w) -> row
 // (b,h/2,w/2), column block ((h&1)*2 + (w&1))*C  (so the conv becomes one NT GEMM with K = 4C).
@@ -114,19 +165,19 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                            const float* __restrict__ w,
                                                            const float* __restrict__ mean_i,
                                                            const float* __restrict__ rstd_i, float* __restrict__ dx,
-                                                           float* __restrict__ dwdb, long T, int C, int mode, int H,
-                                                           int W, int accumulate_dx) {
+                                                           float* __restrict__ partials, long T, int C, int mode,
+                                                           int H, int W, int accumulate_dx) {
   constexpr int TPW = 64 / G;
   const int lane = threadIdx.x & 63;
   const int lg = lane % G, tg = lane / G;
   const long wave = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const long nwaves = (long)gridDim.x * (blockDim.x >> 6);
   const int nq = C >> 2;
-  f32x4 aw[NV], ab[NV], wv[NV];
+  f32x4 acc[2][NV], wv[NV];
 #pragma unroll
   for (int i = 0; i < NV; i++) {
-    aw[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    ab[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc[0][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc[1][i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int q = lg + i * G;
     wv[i] = (q < nq) ? ld4(w + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
@@ -144,8 +195,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
       if (tv && q < nq) {
         xh[i] = (ld4(x + tok * C + 4 * q) - mean) * rstd;
         const f32x4 d = ld4(dy + ob + 4 * q);
-        aw[i] += d * xh[i];
-        ab[i] += d;
+        acc[0][i] += d * xh[i];
+        acc[1][i] += d;
         g[i] = d * wv[i];
         s1 += hsum4(g[i]);
         s2 += hsum4(g[i] * xh[i]);
@@ -168,23 +219,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
       }
     }
   }
-  // fold the TPW token groups of the wave, then one atomic per column per wave
-#pragma unroll
-  for (int i = 0; i < NV; i++) {
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      float a = aw[i][j], c = ab[i][j];
-      for (int o = G; o < 64; o <<= 1) {
-        a += __shfl_xor(a, o, 64);
-        c += __shfl_xor(c, o, 64);
-      }
-      const int q = lg + i * G;
-      if (tg == 0 && q < nq) {
-        atomicAdd(dwdb + 4 * q + j, a);
-        atomicAdd(dwdb + C + 4 * q + j, c);
-      }
-    }
-  }
+  block_colsum_store<G, NV, 2>(acc, partials, C);
 }
 
 // ============================================================================================== depthwise 7x7
@@ -311,13 +346,13 @@ __global__ __launch_bounds__(256) void dwconv7_bwd_weight_kernel(const float* __
 }
 
 // ============================================================================================== layer-scale backward prep
-// dense block: dY = gamma * rs[b] * dOut ; dgamma[c] += rs[b] * dOut[t,c] * Y[t,c]
+// dense block: dY = gamma * rs[b] * dOut ; dgamma[c] = sum_t rs[b] * dOut[t,c] * Y[t,c] ; db2[c] = sum_t dY[t,c]
 template <int G, int NV>
 __global__ __launch_bounds__(256) void scale_bwd_prep_kernel(const float* __restrict__ dout,
                                                             const float* __restrict__ yv,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ rowscale, int rows_per_scale,
-                                                            float* __restrict__ dy, float* __restrict__ dgamma, long T,
+                                                            float* __restrict__ dy, float* __restrict__ partials, long T,
                                                             int C) {
   constexpr int TPW = 64 / G;
   const int lane = threadIdx.x & 63;
@@ -325,10 +360,11 @@ __global__ __launch_bounds__(256) void scale_bwd_prep_kernel(const float* __rest
   const long wave = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const long nwaves = (long)gridDim.x * (blockDim.x >> 6);
   const int nq = C >> 2;
-  f32x4 ag[NV], gv[NV];
+  f32x4 acc[2][NV], gv[NV];
 #pragma unroll
   for (int i = 0; i < NV; i++) {
-    ag[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc[0][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc[1][i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int q = lg + i * G;
     gv[i] = (q < nq) ? ld4(gamma + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
@@ -341,20 +377,14 @@ __global__ __launch_bounds__(256) void scale_bwd_prep_kernel(const float* __rest
       const int q = lg + i * G;
       if (q < nq) {
         const f32x4 d = ld4(dout + tok * C + 4 * q) * rs;
-        ag[i] += d * ld4(yv + tok * C + 4 * q);
-        st4(dy + tok * C + 4 * q, d * gv[i]);
+        acc[0][i] += d * ld4(yv + tok * C + 4 * q);
+        const f32x4 o = d * gv[i];
+        acc[1][i] += o;
+        st4(dy + tok * C + 4 * q, o);
       }
     }
   }
-#pragma unroll
-  for (int i = 0; i < NV; i++)
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      float a = ag[i][j];
-      for (int o = G; o < 64; o <<= 1) a += __shfl_xor(a, o, 64);
-      const int q = lg + i * G;
-      if (tg == 0 && q < nq) atomicAdd(dgamma + 4 * q + j, a);
-    }
+  block_colsum_store<G, NV, 2>(acc, partials, C);
 }
 
 // ============================================================================================== MoE router
@@ -742,7 +772,7 @@ template <int G, int NV>
 __global__ __launch_bounds__(256) void moe_combine_bwd_kernel(
     const float* __restrict__ dout, const float* __restrict__ yslot, const int32_t* __restrict__ token_slot,
     const float* __restrict__ gates, const float* __restrict__ gamma, const float* __restrict__ rowscale,
-    int rows_per_scale, float* __restrict__ dyslot, float* __restrict__ dgate, float* __restrict__ dgamma, long T,
+    int rows_per_scale, float* __restrict__ dyslot, float* __restrict__ dgate, float* __restrict__ partials, long T,
     int C, int k) {
   constexpr int TPW = 64 / G;
   const int lane = threadIdx.x & 63;
@@ -750,10 +780,10 @@ __global__ __launch_bounds__(256) void moe_combine_bwd_kernel(
   const long wave = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const long nwaves = (long)gridDim.x * (blockDim.x >> 6);
   const int nq = C >> 2;
-  f32x4 ag[NV], gv[NV];
+  f32x4 acc[1][NV], gv[NV];
 #pragma unroll
   for (int i = 0; i < NV; i++) {
-    ag[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc[0][i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int q = lg + i * G;
     gv[i] = (q < nq) ? ld4(gamma + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
@@ -787,17 +817,9 @@ __global__ __launch_bounds__(256) void moe_combine_bwd_kernel(
       if (tv && lg == 0) dgate[tok * k + j] = dot;
     }
 #pragma unroll
-    for (int i = 0; i < NV; i++) ag[i] += d[i] * ym[i];
+    for (int i = 0; i < NV; i++) acc[0][i] += d[i] * ym[i];
   }
-#pragma unroll
-  for (int i = 0; i < NV; i++)
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      float a = ag[i][j];
-      for (int o = G; o < 64; o <<= 1) a += __shfl_xor(a, o, 64);
-      const int q = lg + i * G;
-      if (tg == 0 && q < nq) atomicAdd(dgamma + 4 * q + j, a);
-    }
+  block_colsum_store<G, NV, 1>(acc, partials, C);
 }
 
 // dx[t,:] (+)= sum_j dXslot[token_slot[t,j],:]
@@ -820,6 +842,10 @@ inline int row_blocks(long T, int G) {
   long b = (waves + 3) / 4;
   if (b > 4096) b = 4096;
   return (int)(b < 1 ? 1 : b);
+}
+inline int row_blocks_capped(long T, int G) {
+  const int b = row_blocks(T, G);
+  return b > ROW_MAX_BLOCKS ? ROW_MAX_BLOCKS : b;
 }
 inline int ew_blocks(long work, int threads = 256) {
   long b = (work + threads - 1) / threads;
@@ -865,17 +891,24 @@ int sm3_layernorm_fwd(const float* x, const float* w, const float* b, float eps,
   return launch_status();
 }
 
+size_t sm3_row_reduce_workspace_bytes(int C) { return (size_t)ROW_MAX_BLOCKS * 2 * (C > 0 ? C : 1) * sizeof(float); }
+
 int sm3_layernorm_bwd(const float* dy, const float* x, const float* w, const float* mean, const float* rstd,
                       float* dx, float* dwdb, long T, int C, int out_mode, int H, int W, int accumulate_dx,
-                      sm3_stream_t stream) {
-  if (!dy || !x || !w || !mean || !rstd || !dx || !dwdb || T < 0 || C <= 0 || (C & 3)) return SM3_ERR_INVALID_ARG;
+                      void* workspace, size_t workspace_bytes, sm3_stream_t stream) {
+  if (!dy || !x || !w || !mean || !rstd || !dx || !dwdb || !workspace || T <= 0 || C <= 0 || (C & 3))
+    return SM3_ERR_INVALID_ARG;
+  if (workspace_bytes < sm3_row_reduce_workspace_bytes(C)) return SM3_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  (void)hipMemsetAsync(dwdb, 0, sizeof(float) * 2 * C, st);
-  if (T == 0) return launch_status();
-#define CALL(G, NV)                                                                                         \
-  layernorm_bwd_kernel<G, NV><<<512, 256, 0, st>>>(dy, x, w, mean, rstd, dx, dwdb, T, C, out_mode, H, W, accumulate_dx)
+  float* part = (float*)workspace;
+  int nb = 1;
+  const size_t lds = (size_t)4 * 2 * C * sizeof(float);
+#define CALL(G, NV)                                                                                                 \
+  nb = row_blocks_capped(T, G);                                                                                     \
+  layernorm_bwd_kernel<G, NV><<<nb, 256, lds, st>>>(dy, x, w, mean, rstd, dx, part, T, C, out_mode, H, W, accumulate_dx)
   SM3_ROW_DISPATCH(C, CALL);
 #undef CALL
+  partials_reduce_kernel<<<(2 * C + 63) / 64, 256, 0, st>>>(part, nb, 2 * C, dwdb);
   return launch_status();
 }
 
@@ -909,16 +942,22 @@ int sm3_dwconv7_bwd_weight(const float* x, const float* du, float* dw49, float* 
 }
 
 int sm3_scale_bwd_prep(const float* dout, const float* y, const float* gamma, const float* rowscale,
-                       int rows_per_scale, float* dy, float* dgamma, long T, int C, sm3_stream_t stream) {
-  if (!dout || !y || !gamma || !dy || !dgamma || T < 0 || C <= 0 || (C & 3)) return SM3_ERR_INVALID_ARG;
+                       int rows_per_scale, float* dy, float* dgamma_db, long T, int C, void* workspace,
+                       size_t workspace_bytes, sm3_stream_t stream) {
+  if (!dout || !y || !gamma || !dy || !dgamma_db || !workspace || T <= 0 || C <= 0 || (C & 3))
+    return SM3_ERR_INVALID_ARG;
+  if (workspace_bytes < sm3_row_reduce_workspace_bytes(C)) return SM3_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  (void)hipMemsetAsync(dgamma, 0, sizeof(float) * C, st);
-  if (T == 0) return launch_status();
   if (rows_per_scale <= 0) rows_per_scale = 1;
-#define CALL(G, NV) \
-  scale_bwd_prep_kernel<G, NV><<<512, 256, 0, st>>>(dout, y, gamma, rowscale, rows_per_scale, dy, dgamma, T, C)
+  float* part = (float*)workspace;
+  int nb = 1;
+  const size_t lds = (size_t)4 * 2 * C * sizeof(float);
+#define CALL(G, NV)                 \
+  nb = row_blocks_capped(T, G);     \
+  scale_bwd_prep_kernel<G, NV><<<nb, 256, lds, st>>>(dout, y, gamma, rowscale, rows_per_scale, dy, part, T, C)
   SM3_ROW_DISPATCH(C, CALL);
 #undef CALL
+  partials_reduce_kernel<<<(2 * C + 63) / 64, 256, 0, st>>>(part, nb, 2 * C, dgamma_db);
   return launch_status();
 }
 
@@ -1009,18 +1048,24 @@ int sm3_moe_combine_fwd(const float* yslot, const int32_t* token_slot, const flo
 
 int sm3_moe_combine_bwd(const float* dout, const float* yslot, const int32_t* token_slot, const float* gates,
                         const float* gamma, const float* rowscale, int rows_per_scale, float* dyslot, float* dgate,
-                        float* dgamma, long T, int C, int k, sm3_stream_t stream) {
-  if (!dout || !yslot || !token_slot || !gates || !gamma || !dyslot || !dgate || !dgamma || T <= 0 || C <= 0 ||
-      (C & 3) || k < 1)
+                        float* dgamma, long T, int C, int k, void* workspace, size_t workspace_bytes,
+                        sm3_stream_t stream) {
+  if (!dout || !yslot || !token_slot || !gates || !gamma || !dyslot || !dgate || !dgamma || !workspace || T <= 0 ||
+      C <= 0 || (C & 3) || k < 1)
     return SM3_ERR_INVALID_ARG;
+  if (workspace_bytes < sm3_row_reduce_workspace_bytes(C)) return SM3_ERR_WORKSPACE;
   if (rows_per_scale <= 0) rows_per_scale = 1;
   hipStream_t st = (hipStream_t)stream;
-  (void)hipMemsetAsync(dgamma, 0, sizeof(float) * C, st);
-#define CALL(G, NV)                                                                                                \
-  moe_combine_bwd_kernel<G, NV><<<512, 256, 0, st>>>(dout, yslot, token_slot, gates, gamma, rowscale, rows_per_scale, \
-                                                     dyslot, dgate, dgamma, T, C, k)
+  float* part = (float*)workspace;
+  int nb = 1;
+  const size_t lds = (size_t)4 * C * sizeof(float);
+#define CALL(G, NV)                                                                                                 \
+  nb = row_blocks_capped(T, G);                                                                                     \
+  moe_combine_bwd_kernel<G, NV><<<nb, 256, lds, st>>>(dout, yslot, token_slot, gates, gamma, rowscale, rows_per_scale, \
+                                                      dyslot, dgate, part, T, C, k)
   SM3_ROW_DISPATCH(C, CALL);
 #undef CALL
+  partials_reduce_kernel<<<(C + 63) / 64, 256, 0, st>>>(part, nb, C, dgamma);
   return launch_status();
 }
 

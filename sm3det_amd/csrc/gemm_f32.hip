@@ -47,19 +47,22 @@ struct GemmParams {
   int splits;       // TN: split-K factor per group
   // epilogue operands
   const float* bias;      // [N] (per group)
-  const float* aux_in;    // EPI_GELU_BWD: hpre[M,N];  EPI_BIAS_SCALE_RES: residual[M,N]
-  float* aux_out;         // EPI_BIAS_GELU: hpre[M,N]; EPI_BIAS_SCALE_RES: y[M,N]
+  const float* aux_in;    // EPI_GELU_BWD: gelu'(h)[M,N];  EPI_BIAS_SCALE_RES: residual[M,N]
+  float* aux_out;         // EPI_BIAS_GELU: gelu'(h)[M,N]; EPI_BIAS_SCALE_RES: y[M,N]
+  float* colpart;         // EPI_GELU_BWD: per-row-tile column sums [row tiles][N] (bias gradient partials) or NULL
   const float* gamma;     // [N] layer scale
   const float* rowscale;  // [M / rows_per_scale] (stochastic-depth keep/keep_prob per image) or NULL
   int rows_per_scale;
   int ld_aux;
 };
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-__device__ __forceinline__ float gelu_erf_grad(float x) {
-  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
-  return cdf + x * pdf;
+// GELU(erf) and its derivative share the erf: y = h*Phi(h), y' = Phi(h) + h*phi(h).  The forward epilogue stores y'
+// so the backward epilogue is a single multiply (no transcendental on the dgrad critical path).
+__device__ __forceinline__ void gelu_erf_both(float h, float& y, float& dy) {
+  const float cdf = 0.5f * (1.0f + erff(h * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * h * h);
+  y = h * cdf;
+  dy = cdf + h * pdf;
 }
 
 // EPI codes (must match include/sm3det_hip.h)
@@ -271,6 +274,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(GemmParams p) {
   const float* bias = (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_SCALE_RES)
                           ? p.bias + (long)g * p.strideBias
                           : nullptr;
+  float csum[2] = {0.f, 0.f};
 #pragma unroll
   for (int j = 0; j < 2; j++) {
     const int col = n0 + wn0 + 32 * j + l31;
@@ -291,9 +295,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(GemmParams p) {
         } else if (EPI == EPI_BIAS) {
           Cg[ci] = v + bv;
         } else if (EPI == EPI_BIAS_GELU) {
-          const float h = v + bv;
-          p.aux_out[(long)row * p.ld_aux + col] = h;
-          Cg[ci] = gelu_erf(h);
+          float y, dy;
+          gelu_erf_both(v + bv, y, dy);
+          p.aux_out[(long)row * p.ld_aux + col] = dy;
+          Cg[ci] = y;
         } else if (EPI == EPI_BIAS_SCALE_RES) {
           const float y = v + bv;
           p.aux_out[(long)row * p.ld_aux + col] = y;
@@ -301,11 +306,55 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(GemmParams p) {
           if (p.rowscale) sc *= p.rowscale[row / p.rows_per_scale];
           Cg[ci] = p.aux_in[(long)row * p.ld_aux + col] + sc * y;
         } else if (EPI == EPI_GELU_BWD) {
-          Cg[ci] = v * gelu_erf_grad(p.aux_in[(long)row * p.ld_aux + col]);
+          const float o = v * p.aux_in[(long)row * p.ld_aux + col];
+          Cg[ci] = o;
+          csum[j] += o;
         }
       }
     }
   }
+  if (EPI == EPI_GELU_BWD) {
+    if (p.colpart) {  // uniform branch: column sums of this 128-row tile -> colpart[tile_m][n]
+      float* red = smem;  // k-loop ended with a barrier: LDS is free. [2 row-halves][BN]
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        float v = csum[j] + __shfl_xor(csum[j], 32, 64);
+        if (lh == 0) red[(wave >> 1) * BN + wn0 + 32 * j + l31] = v;
+      }
+      __syncthreads();
+      if (tid < BN && n0 + tid < p.N) p.colpart[(long)tile_m * p.N + n0 + tid] = red[tid] + red[BN + tid];
+    }
+  }
+}
+
+// colpart [row tiles][N] -> out[g][n]: sum the tiles that belong to group g (same tile->group map as the GEMM).
+// block = 64 columns x 4 tile lanes
+__global__ __launch_bounds__(256) void tile_colsum_reduce_kernel(const float* __restrict__ colpart, int N, int M,
+                                                                const int32_t* __restrict__ offsets,
+                                                                int num_groups, float* __restrict__ out) {
+  __shared__ float red[4][64];
+  const int g = blockIdx.y;
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + cl;
+  int t0 = 0, t1 = (M + BM - 1) / BM;
+  if (offsets) {
+    int base = 0;
+    for (int gg = 0; gg < g; gg++) base += (offsets[gg + 1] - offsets[gg] + BM - 1) / BM;
+    t0 = base;
+    t1 = base + (offsets[g + 1] - offsets[g] + BM - 1) / BM;
+  }
+  float s0 = 0.f, s1 = 0.f;
+  if (n < N) {
+    int t = t0 + rl;
+    for (; t + 4 < t1; t += 8) {
+      s0 += colpart[(long)t * N + n];
+      s1 += colpart[(long)(t + 4) * N + n];
+    }
+    for (; t < t1; t += 4) s0 += colpart[(long)t * N + n];
+  }
+  red[rl][cl] = s0 + s1;
+  __syncthreads();
+  if (rl == 0 && n < N) out[(long)g * N + n] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
 }
 
 // Sum the split-K partials of a TN GEMM: out[g][i] = sum_s ws[(g*splits+s)][i]
@@ -323,32 +372,36 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, float* __rest
 }
 
 // Column sums over row segments (bias gradients): out[g][n] += sum_{r in seg g} X[r][n]; `out` is zeroed by the
-// caller (memset node on the same stream); row chunks are combined with fp32 L2 atomics.
-constexpr int COLSUM_SPLITS = 64;
+// caller (memset on the same stream).  Block = 16 column quads (64 columns, 16 B per lane) x 16 row lanes; row
+// chunks are combined with fp32 L2 atomics (<= COLSUM_SPLITS adds per address).
+constexpr int COLSUM_SPLITS = 128;
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int ld, int N,
-                                                    const int32_t* __restrict__ offsets, int M,
+                                                    const int32_t* __restrict__ offsets, int M, int splits,
                                                     float* __restrict__ out) {
-  // grid: (ceil(N/64), COLSUM_SPLITS, groups); block 256 = 64 columns x 4 row lanes
   const int g = blockIdx.z;
   int r0 = 0, r1 = M;
   if (offsets) {
     r0 = offsets[g];
     r1 = offsets[g + 1];
   }
-  const int chunk = (r1 - r0 + COLSUM_SPLITS - 1) / COLSUM_SPLITS;
+  const int chunk = (r1 - r0 + splits - 1) / splits;
   r0 += blockIdx.y * chunk;
   r1 = min(r1, r0 + chunk);
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int rl = threadIdx.x >> 6;
-  float s = 0.f;
+  const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 64 + 4 * cq;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
   if (c < N)
-    for (int r = r0 + rl; r < r1; r += 4) s += X[(long)r * ld + c];
-  __shared__ float red[4][64];
-  red[rl][threadIdx.x & 63] = s;
+    for (int r = r0 + rl; r < r1; r += 16) s += *reinterpret_cast<const f32x4*>(X + (long)r * ld + c);
+  __shared__ f32x4 red[16][16];
+  red[rl][cq] = s;
   __syncthreads();
-  if (rl == 0 && c < N && r0 < r1) {
-    const float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-    atomicAdd(out + (long)g * N + c, t);
+  if (threadIdx.x < 64 && r0 < r1) {
+    const int q = threadIdx.x >> 2, e = threadIdx.x & 3;
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; i++) t += red[i][q][e];
+    const int col = blockIdx.x * 64 + threadIdx.x;
+    if (col < N) atomicAdd(out + (long)g * N + col, t);
   }
 }
 
@@ -374,7 +427,14 @@ int launch_mode(const GemmParams& p, int epi, dim3 grid, hipStream_t st) {
 extern "C" {
 
 size_t sm3_gemm_f32_workspace_bytes(const sm3_gemm_desc* d) {
-  if (!d || d->mode != MODE_TN) return 0;
+  if (!d) return 0;
+  if (d->mode != MODE_TN) {
+    if (d->epilogue == EPI_GELU_BWD && d->colsum_out) {
+      const int ntm = (d->M + BM - 1) / BM + (d->group_offsets ? (d->num_groups > 0 ? d->num_groups : 1) : 0);
+      return (size_t)ntm * d->N * sizeof(float);
+    }
+    return 0;
+  }
   const int groups = d->num_groups > 0 ? d->num_groups : 1;
   const int splits = d->splits > 0 ? d->splits : 1;
   return (size_t)groups * splits * d->M * d->N * sizeof(float);
@@ -400,6 +460,7 @@ int sm3_gemm_f32(const sm3_gemm_desc* d, void* workspace, size_t workspace_bytes
   p.gamma = d->gamma; p.rowscale = d->rowscale;
   p.rows_per_scale = d->rows_per_scale > 0 ? d->rows_per_scale : 1;
   p.ld_aux = d->ld_aux;
+  p.colpart = nullptr;
   const int ntn = (d->N + BN - 1) / BN;
   if (d->mode == MODE_TN) {
     if (d->epilogue != EPI_NONE) return SM3_ERR_INVALID_ARG;
@@ -422,20 +483,35 @@ int sm3_gemm_f32(const sm3_gemm_desc* d, void* workspace, size_t workspace_bytes
   // ragged groups: at most ceil(M/BM) + G row tiles exist; surplus blocks exit
   const int ntm = (d->M + BM - 1) / BM + (d->group_offsets ? p.num_groups : 0);
   dim3 grid(ntn * ntm, 1, 1);
+  const bool want_colsum = (d->epilogue == EPI_GELU_BWD && d->colsum_out);
+  if (want_colsum) {
+    if (!workspace || workspace_bytes < (size_t)ntm * d->N * sizeof(float)) return SM3_ERR_WORKSPACE;
+    p.colpart = (float*)workspace;
+  }
   int rc;
   if (d->mode == MODE_NT) rc = launch_mode<MODE_NT>(p, d->epilogue, grid, st);
   else if (d->mode == MODE_NN) rc = launch_mode<MODE_NN>(p, d->epilogue, grid, st);
   else return SM3_ERR_INVALID_ARG;
-  return rc ? rc : launch_status();
+  if (rc) return rc;
+  if (want_colsum) {
+    dim3 rg((d->N + 63) / 64, p.num_groups);
+    tile_colsum_reduce_kernel<<<rg, 256, 0, st>>>(p.colpart, d->N, d->M, d->group_offsets, p.num_groups,
+                                                 d->colsum_out);
+  }
+  return launch_status();
 }
 
 int sm3_colsum_f32(const float* x, int ld, int m, int n, const int32_t* group_offsets, int num_groups, float* out,
                    sm3_stream_t stream) {
   if (n <= 0 || m < 0 || !x || !out) return SM3_ERR_INVALID_ARG;
   const int groups = group_offsets ? num_groups : 1;
-  dim3 grid((n + 63) / 64, COLSUM_SPLITS, groups);
+  const int rows_per_group = m / groups > 0 ? m / groups : 1;
+  int splits = rows_per_group / 256;
+  if (splits < 1) splits = 1;
+  if (splits > COLSUM_SPLITS) splits = COLSUM_SPLITS;
+  dim3 grid((n + 63) / 64, splits, groups);
   (void)hipMemsetAsync(out, 0, sizeof(float) * (size_t)groups * n, (hipStream_t)stream);
-  colsum_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, ld, n, group_offsets, m, out);
+  colsum_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, ld, n, group_offsets, m, splits, out);
   return launch_status();
 }
 

@@ -71,9 +71,11 @@ def test_epilogues():
     hpre = torch.empty(M, N, device='cuda')
     act = torch.empty(M, N, device='cuda')
     LB.gemm(LB.NT, A, B, act, M, N, K, epilogue=LB.EPI_BIAS_GELU, bias=bias, aux_out=hpre)
-    h64 = A.double() @ B.double().t() + bias.double()
-    _close(hpre, h64)
-    _close(act, torch.nn.functional.gelu(h64), tol=2e-4)
+    h64 = (A.double() @ B.double().t() + bias.double()).requires_grad_(True)
+    a64 = torch.nn.functional.gelu(h64)
+    a64.sum().backward()
+    _close(act, a64.detach(), tol=2e-4)
+    _close(hpre, h64.grad, tol=2e-4)  # aux_out = gelu'(h)
     # scale + residual (+ per-image stochastic-depth scale)
     M2, N2, K2 = 512, 96, 384
     A2, B2, b2 = _rand(M2, K2, seed=11), _rand(N2, K2, seed=12) * 0.1, _rand(N2, seed=13)
@@ -90,10 +92,11 @@ def test_epilogues():
     # dgrad through GELU
     dY, W = _rand(M, K, seed=16), _rand(K, N, seed=17) * 0.2
     dH = torch.empty(M, N, device='cuda')
-    LB.gemm(LB.NN, dY, W, dH, M, N, K, epilogue=LB.EPI_GELU_BWD, aux_in=hpre)
-    h = hpre.double().requires_grad_(True)
-    torch.nn.functional.gelu(h).backward(dY.double() @ W.double())
-    _close(dH, h.grad, tol=2e-4)
+    db = torch.empty(N, device='cuda')
+    LB.gemm(LB.NN, dY, W, dH, M, N, K, epilogue=LB.EPI_GELU_BWD, aux_in=hpre, colsum_out=db)
+    ref = (dY.double() @ W.double()) * h64.grad
+    _close(dH, ref, tol=2e-4)
+    _close(db, ref.sum(0), tol=2e-4)
 
 
 @pytest.mark.parametrize('E,counts', [(8, [300, 0, 129, 1, 128, 500, 64, 7]), (16, [40] * 16), (4, [0, 0, 0, 1000])])
@@ -110,7 +113,16 @@ def test_grouped(E, counts):
     LB.gemm(LB.NT, X, W1, act, S, Hd, C_, epilogue=LB.EPI_BIAS_GELU, bias=b1, aux_out=hpre, offsets=offs,
             num_groups=E)
     ref = torch.cat([X[offs[e]:offs[e + 1]].double() @ W1[e].double().t() + b1[e].double() for e in range(E)])
-    _close(hpre, ref)
+    _close(act, torch.nn.functional.gelu(ref), tol=2e-4)
+    # grouped dgrad through GELU with fused per-expert bias gradient
+    dY = _rand(S, C_, seed=24)
+    W2 = _rand(E, C_, Hd, seed=25) * 0.1
+    dHg, dbg = torch.zeros(S, Hd, device='cuda'), torch.full((E, Hd), float('nan'), device='cuda')
+    LB.gemm(LB.NN, dY, W2, dHg, S, Hd, C_, epilogue=LB.EPI_GELU_BWD, aux_in=hpre, offsets=offs, num_groups=E,
+            colsum_out=dbg)
+    refg = torch.cat([dY[offs[e]:offs[e + 1]].double() @ W2[e].double() for e in range(E)]) * hpre.double()
+    _close(dHg, refg)
+    _close(dbg, torch.stack([refg[offs[e]:offs[e + 1]].sum(0) for e in range(E)]))
     # grouped dgrad NN: dX = dH @ W1  (W1[e] is (Hd,C) = K x N)
     dH = _rand(S, Hd, seed=23)
     dX = torch.zeros(S, C_, device='cuda')
