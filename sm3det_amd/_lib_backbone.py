@@ -53,6 +53,7 @@ def signatures():
 # Per-launch profiling hook (bench.py): when PROFILE is a list, every C-ABI call is bracketed by HIP events recorded
 # on the stream the kernels are launched on, and (name, algorithmic flops, algorithmic bytes, ev0, ev1) is appended.
 PROFILE = None
+PROFILE_SHAPES = False
 
 
 class _Prof:
@@ -124,7 +125,10 @@ def gemm(mode, A, B, C, M, N, K, *, epilogue=EPI_NONE, bias=None, aux_in=None, a
         nbytes = L.sm3_gemm_f32_workspace_bytes(ctypes.byref(d))
         ws = _lib.workspace(nbytes, C.device)
     rows = K if mode == TN else M
-    with _Prof('gemm_f32_' + ('nt', 'nn', 'tn')[mode], 2.0 * rows * N * (M if mode == TN else K)):
+    tag = 'gemm_f32_' + ('nt', 'nn', 'tn')[mode]
+    if PROFILE is not None and PROFILE_SHAPES:
+        tag += f' {M}x{N}x{K} g{num_groups} e{epilogue} s{splits}'
+    with _Prof(tag, 2.0 * rows * N * (M if mode == TN else K)):
         _lib.check(L.sm3_gemm_f32(ctypes.byref(d), _p(ws), nbytes, _lib.stream_ptr()), 'gemm_f32')
 
 
