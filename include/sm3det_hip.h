@@ -220,6 +220,22 @@ int sm3_moe_combine_bwd(const float* dout, const float* yslot, const int32_t* to
 int sm3_moe_gather_add(const float* dxslot, const int32_t* token_slot, float* dx, long T, int C, int k,
                        int accumulate, sm3_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * DeformConv2d sampling kernels (the device half of deform_conv_{forward,backward_input,backward_parameters},
+ * pybind.cpp:38-57,501-522; semantics of pytorch/cpu/deform_conv.cpp:114-290).  Reference layouts: im
+ * (imgs,C,H,W), offset (imgs, dg*2*kh*kw, Ho, Wo), col (C*kh*kw, ld_col) with ld_col >= imgs*Ho*Wo.  The
+ * per-group GEMMs around them use sm3_gemm_f32 (host: sm3det_amd/deform_conv_host.py). col2im accumulates into
+ * grad_im with fp32 atomics (grad_im zero-filled by the caller, mmcv/ops/deform_conv.py:127). */
+int sm3_deform_im2col(const float* im, const float* offset, float* col, int channels, int height, int width, int kh,
+                      int kw, int pad_h, int pad_w, int stride_h, int stride_w, int dil_h, int dil_w, int imgs,
+                      int deformable_group, long ld_col, sm3_stream_t stream);
+int sm3_deform_col2im(const float* col, const float* offset, float* grad_im, int channels, int height, int width,
+                      int kh, int kw, int pad_h, int pad_w, int stride_h, int stride_w, int dil_h, int dil_w, int imgs,
+                      int deformable_group, long ld_col, sm3_stream_t stream);
+int sm3_deform_col2im_coord(const float* col, const float* im, const float* offset, float* grad_offset, int channels,
+                            int height, int width, int kh, int kw, int pad_h, int pad_w, int stride_h, int stride_w,
+                            int dil_h, int dil_w, int imgs, int deformable_group, long ld_col, sm3_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

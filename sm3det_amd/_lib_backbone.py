@@ -47,6 +47,9 @@ def signatures():
         'sm3_moe_combine_fwd': (I, [P, P, P, P, P, P, I, P, LL, I, I, P]),
         'sm3_moe_combine_bwd': (I, [P, P, P, P, P, P, I, P, P, P, LL, I, I, P, S, P]),
         'sm3_moe_gather_add': (I, [P, P, P, LL, I, I, I, P]),
+        'sm3_deform_im2col': (I, [P, P, P] + [I] * 13 + [LL, P]),
+        'sm3_deform_col2im': (I, [P, P, P] + [I] * 13 + [LL, P]),
+        'sm3_deform_col2im_coord': (I, [P, P, P, P] + [I] * 13 + [LL, P]),
     }
 
 

@@ -1,0 +1,251 @@
+// deform_conv.hip -- DeformConv2d sampling kernels for gfx950 (the three device pieces of the reference op;
+// the per-group GEMMs around them run on gemm_f32.hip, orchestrated by sm3det_amd/deform_conv_host.py).
+//
+// Semantics follow the reference's CPU path (paths relative to /root/reference/mmcv/mmcv/ops/csrc):
+//   pytorch/cpu/deform_conv.cpp:5-38   deformable_im2col_bilinear_cpu
+//   :40-63                              get_gradient_weight_cpu
+//   :65-112                             get_coordinate_weight_cpu
+//   :114-164 / :166-219 / :221-290      deformable_im2col / col2im / col2im_coord kernels
+// Layouts are the reference's: data_im (parallel_imgs, C, H, W) NCHW; data_offset (parallel_imgs,
+// dg*2*kh*kw, Ho, Wo); data_col (C*kh*kw, parallel_imgs, Ho, Wo) with leading dimension `ld_col` (>= parallel_imgs
+// *Ho*Wo, padded by the host so the column matrix can feed the float4-vectorised GEMM directly).
+// Built with -ffp-contract=off like the other detection ops (CPU-exact rounding of the bilinear weights).
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float im2col_bilinear(const float* __restrict__ in, int data_width, int height, int width,
+                                                 float h, float w) {
+  if (h <= -1 || height <= h || w <= -1 || width <= w) return 0;
+  int h_low = (int)floorf(h);
+  int w_low = (int)floorf(w);
+  int h_high = h_low + 1;
+  int w_high = w_low + 1;
+  float lh = h - h_low;
+  float lw = w - w_low;
+  float hh = 1 - lh, hw = 1 - lw;
+  float v1 = 0;
+  if (h_low >= 0 && w_low >= 0) v1 = in[h_low * data_width + w_low];
+  float v2 = 0;
+  if (h_low >= 0 && w_high <= width - 1) v2 = in[h_low * data_width + w_high];
+  float v3 = 0;
+  if (h_high <= height - 1 && w_low >= 0) v3 = in[h_high * data_width + w_low];
+  float v4 = 0;
+  if (h_high <= height - 1 && w_high <= width - 1) v4 = in[h_high * data_width + w_high];
+  float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+  return (w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4);
+}
+
+__device__ __forceinline__ float gradient_weight(float argmax_h, float argmax_w, int h, int w, int height, int width) {
+  if (argmax_h <= -1 || argmax_h >= height || argmax_w <= -1 || argmax_w >= width) return 0;
+  int hl = (int)floorf(argmax_h), wl = (int)floorf(argmax_w);
+  int hh = hl + 1, wh = wl + 1;
+  float weight = 0;
+  if (h == hl && w == wl) weight = (h + 1 - argmax_h) * (w + 1 - argmax_w);
+  if (h == hl && w == wh) weight = (h + 1 - argmax_h) * (argmax_w + 1 - w);
+  if (h == hh && w == wl) weight = (argmax_h + 1 - h) * (w + 1 - argmax_w);
+  if (h == hh && w == wh) weight = (argmax_h + 1 - h) * (argmax_w + 1 - w);
+  return weight;
+}
+
+__device__ __forceinline__ float coordinate_weight(float argmax_h, float argmax_w, int height, int width,
+                                                   const float* __restrict__ im, int data_width, int bp_dir) {
+  if (argmax_h <= -1 || argmax_h >= height || argmax_w <= -1 || argmax_w >= width) return 0;
+  int hl = (int)floorf(argmax_h), wl = (int)floorf(argmax_w);
+  int hh = hl + 1, wh = wl + 1;
+  float weight = 0;
+  if (bp_dir == 0) {
+    if (hl >= 0 && wl >= 0) weight += -1 * (wl + 1 - argmax_w) * im[hl * data_width + wl];
+    if (hl >= 0 && wh <= width - 1) weight += -1 * (argmax_w - wl) * im[hl * data_width + wh];
+    if (hh <= height - 1 && wl >= 0) weight += (wl + 1 - argmax_w) * im[hh * data_width + wl];
+    if (hh <= height - 1 && wh <= width - 1) weight += (argmax_w - wl) * im[hh * data_width + wh];
+  } else if (bp_dir == 1) {
+    if (hl >= 0 && wl >= 0) weight += -1 * (hl + 1 - argmax_h) * im[hl * data_width + wl];
+    if (hl >= 0 && wh <= width - 1) weight += (hl + 1 - argmax_h) * im[hl * data_width + wh];
+    if (hh <= height - 1 && wl >= 0) weight += -1 * (argmax_h - hl) * im[hh * data_width + wl];
+    if (hh <= height - 1 && wh <= width - 1) weight += (argmax_h - hl) * im[hh * data_width + wh];
+  }
+  return weight;
+}
+
+struct DcnGeom {
+  int channels, height, width, kh, kw, pad_h, pad_w, stride_h, stride_w, dil_h, dil_w, imgs, dg, ho, wo;
+  long ld_col;
+};
+
+// one thread per (c_im, b, h_col, w_col): writes the kh*kw column entries of that input channel
+__global__ __launch_bounds__(256) void deform_im2col_kernel(long n, const float* __restrict__ im,
+                                                           const float* __restrict__ off, DcnGeom g,
+                                                           float* __restrict__ col) {
+  const int cpdg = g.channels / g.dg;
+  for (long index = (long)blockIdx.x * blockDim.x + threadIdx.x; index < n; index += (long)gridDim.x * blockDim.x) {
+    const int w_col = index % g.wo;
+    const int h_col = (index / g.wo) % g.ho;
+    const int b_col = (index / g.wo / g.ho) % g.imgs;
+    const int c_im = (index / g.wo / g.ho) / g.imgs;
+    const int c_col = c_im * g.kh * g.kw;
+    const int dgi = c_im / cpdg;
+    const int h_in = h_col * g.stride_h - g.pad_h;
+    const int w_in = w_col * g.stride_w - g.pad_w;
+    float* cp = col + (long)c_col * g.ld_col + ((long)b_col * g.ho + h_col) * g.wo + w_col;
+    const float* ip = im + ((long)b_col * g.channels + c_im) * g.height * g.width;
+    const float* op = off + ((long)b_col * g.dg + dgi) * 2 * g.kh * g.kw * g.ho * g.wo;
+    for (int i = 0; i < g.kh; ++i)
+      for (int j = 0; j < g.kw; ++j) {
+        const long oh = ((long)(2 * (i * g.kw + j)) * g.ho + h_col) * g.wo + w_col;
+        const long ow = ((long)(2 * (i * g.kw + j) + 1) * g.ho + h_col) * g.wo + w_col;
+        const float offset_h = op[oh], offset_w = op[ow];
+        float val = 0.f;
+        const float h_im = h_in + i * g.dil_h + offset_h;
+        const float w_im = w_in + j * g.dil_w + offset_w;
+        if (h_im > -1 && w_im > -1 && h_im < g.height && w_im < g.width)
+          val = im2col_bilinear(ip, g.width, g.height, g.width, h_im, w_im);
+        *cp = val;
+        cp += g.ld_col;
+      }
+  }
+}
+
+// one thread per column entry (c, i, j, b, h_out, w_out): scatters into grad_im with fp32 atomics
+__global__ __launch_bounds__(256) void deform_col2im_kernel(long n, const float* __restrict__ col,
+                                                           const float* __restrict__ off, DcnGeom g,
+                                                           float* __restrict__ grad_im) {
+  const int cpdg = g.channels / g.dg;
+  const long per_row = (long)g.imgs * g.ho * g.wo;
+  for (long index = (long)blockIdx.x * blockDim.x + threadIdx.x; index < n; index += (long)gridDim.x * blockDim.x) {
+    const long row = index / per_row;  // c*kh*kw + i*kw + j
+    const long rem = index - row * per_row;
+    const int j = row % g.kw;
+    const int i = (row / g.kw) % g.kh;
+    const int c = row / g.kw / g.kh;
+    const int dgi = c / cpdg;
+    const int w_out = rem % g.wo;
+    const int h_out = (rem / g.wo) % g.ho;
+    const int b = rem / g.wo / g.ho;
+    const int w_in = w_out * g.stride_w - g.pad_w;
+    const int h_in = h_out * g.stride_h - g.pad_h;
+    const float* op = off + ((long)b * g.dg + dgi) * 2 * g.kh * g.kw * g.ho * g.wo;
+    const float offset_h = op[((long)(2 * (i * g.kw + j)) * g.ho + h_out) * g.wo + w_out];
+    const float offset_w = op[((long)(2 * (i * g.kw + j) + 1) * g.ho + h_out) * g.wo + w_out];
+    const float cur_inv_h = h_in + i * g.dil_h + offset_h;
+    const float cur_inv_w = w_in + j * g.dil_w + offset_w;
+    const float top = col[row * g.ld_col + rem];
+    const int cur_h = (int)cur_inv_h;
+    const int cur_w = (int)cur_inv_w;
+    for (int dy = -2; dy <= 2; dy++)
+      for (int dx = -2; dx <= 2; dx++) {
+        if (cur_h + dy >= 0 && cur_h + dy < g.height && cur_w + dx >= 0 && cur_w + dx < g.width &&
+            fabsf(cur_inv_h - (cur_h + dy)) < 1 && fabsf(cur_inv_w - (cur_w + dx)) < 1) {
+          const long pos = (((long)b * g.channels + c) * g.height + cur_h + dy) * g.width + cur_w + dx;
+          const float weight = gradient_weight(cur_inv_h, cur_inv_w, cur_h + dy, cur_w + dx, g.height, g.width);
+          atomicAdd(grad_im + pos, weight * top);
+        }
+      }
+  }
+}
+
+// one thread per offset element (b, c_off, h, w): gathers over the channels of its deformable group
+__global__ __launch_bounds__(256) void deform_col2im_coord_kernel(long n, const float* __restrict__ col,
+                                                                 const float* __restrict__ im,
+                                                                 const float* __restrict__ off, DcnGeom g,
+                                                                 float* __restrict__ grad_off) {
+  const int offset_channels = 2 * g.kh * g.kw * g.dg;
+  const int cpdg_col = g.channels * g.kh * g.kw / g.dg;  // column rows per deformable group
+  for (long index = (long)blockIdx.x * blockDim.x + threadIdx.x; index < n; index += (long)gridDim.x * blockDim.x) {
+    float val = 0;
+    const int w = index % g.wo;
+    const int h = (index / g.wo) % g.ho;
+    const int c = (index / g.wo / g.ho) % offset_channels;
+    const int b = (index / g.wo / g.ho) / offset_channels;
+    const int dgi = c / (2 * g.kh * g.kw);
+    const int col_step = g.kh * g.kw;
+    int cnt = 0;
+    const float* colp = col + (long)dgi * cpdg_col * g.ld_col;
+    const float* imp = im + ((long)b * g.dg + dgi) * (cpdg_col / g.kh / g.kw) * g.height * g.width;
+    const float* op = off + ((long)b * g.dg + dgi) * 2 * g.kh * g.kw * g.ho * g.wo;
+    const int offset_c = c - dgi * 2 * g.kh * g.kw;
+    for (int col_c = (offset_c / 2); col_c < cpdg_col; col_c += col_step) {
+      const long col_pos = (long)col_c * g.ld_col + ((long)b * g.ho + h) * g.wo + w;
+      const int bp_dir = offset_c % 2;
+      const int j = col_c % g.kw;
+      const int i = (col_c / g.kw) % g.kh;
+      const int w_in = w * g.stride_w - g.pad_w;
+      const int h_in = h * g.stride_h - g.pad_h;
+      const float offset_h = op[((long)(2 * (i * g.kw + j)) * g.ho + h) * g.wo + w];
+      const float offset_w = op[((long)(2 * (i * g.kw + j) + 1) * g.ho + h) * g.wo + w];
+      float inv_h = h_in + i * g.dil_h + offset_h;
+      float inv_w = w_in + j * g.dil_w + offset_w;
+      if (inv_h <= -1 || inv_w <= -1 || inv_h >= g.height || inv_w >= g.width) inv_h = inv_w = -2;
+      const float weight = coordinate_weight(inv_h, inv_w, g.height, g.width, imp + (long)cnt * g.height * g.width,
+                                             g.width, bp_dir);
+      val += weight * colp[col_pos];
+      cnt += 1;
+    }
+    grad_off[index] = val;
+  }
+}
+
+inline int blocks_for(long n) {
+  long b = (n + 255) / 256;
+  if (b > 256L * 32) b = 256L * 32;
+  return (int)(b < 1 ? 1 : b);
+}
+
+inline bool make_geom(DcnGeom& g, int channels, int height, int width, int kh, int kw, int pad_h, int pad_w,
+                      int stride_h, int stride_w, int dil_h, int dil_w, int imgs, int dg, long ld_col) {
+  if (channels <= 0 || height <= 0 || width <= 0 || kh <= 0 || kw <= 0 || stride_h <= 0 || stride_w <= 0 ||
+      dil_h <= 0 || dil_w <= 0 || imgs <= 0 || dg <= 0 || channels % dg)
+    return false;
+  g.channels = channels; g.height = height; g.width = width; g.kh = kh; g.kw = kw;
+  g.pad_h = pad_h; g.pad_w = pad_w; g.stride_h = stride_h; g.stride_w = stride_w; g.dil_h = dil_h; g.dil_w = dil_w;
+  g.imgs = imgs; g.dg = dg;
+  g.ho = (height + 2 * pad_h - (dil_h * (kh - 1) + 1)) / stride_h + 1;
+  g.wo = (width + 2 * pad_w - (dil_w * (kw - 1) + 1)) / stride_w + 1;
+  g.ld_col = ld_col;
+  return g.ho > 0 && g.wo > 0 && ld_col >= (long)imgs * g.ho * g.wo;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sm3_deform_im2col(const float* im, const float* offset, float* col, int channels, int height, int width, int kh,
+                      int kw, int pad_h, int pad_w, int stride_h, int stride_w, int dil_h, int dil_w, int imgs,
+                      int deformable_group, long ld_col, sm3_stream_t stream) {
+  DcnGeom g;
+  if (!im || !offset || !col ||
+      !make_geom(g, channels, height, width, kh, kw, pad_h, pad_w, stride_h, stride_w, dil_h, dil_w, imgs,
+                 deformable_group, ld_col))
+    return SM3_ERR_INVALID_ARG;
+  const long n = (long)channels * g.ho * g.wo * imgs;
+  deform_im2col_kernel<<<blocks_for(n), 256, 0, (hipStream_t)stream>>>(n, im, offset, g, col);
+  return launch_status();
+}
+
+int sm3_deform_col2im(const float* col, const float* offset, float* grad_im, int channels, int height, int width,
+                      int kh, int kw, int pad_h, int pad_w, int stride_h, int stride_w, int dil_h, int dil_w, int imgs,
+                      int deformable_group, long ld_col, sm3_stream_t stream) {
+  DcnGeom g;
+  if (!col || !offset || !grad_im ||
+      !make_geom(g, channels, height, width, kh, kw, pad_h, pad_w, stride_h, stride_w, dil_h, dil_w, imgs,
+                 deformable_group, ld_col))
+    return SM3_ERR_INVALID_ARG;
+  const long n = (long)channels * kh * kw * g.ho * g.wo * imgs;
+  deform_col2im_kernel<<<blocks_for(n), 256, 0, (hipStream_t)stream>>>(n, col, offset, g, grad_im);
+  return launch_status();
+}
+
+int sm3_deform_col2im_coord(const float* col, const float* im, const float* offset, float* grad_offset, int channels,
+                            int height, int width, int kh, int kw, int pad_h, int pad_w, int stride_h, int stride_w,
+                            int dil_h, int dil_w, int imgs, int deformable_group, long ld_col, sm3_stream_t stream) {
+  DcnGeom g;
+  if (!col || !im || !offset || !grad_offset ||
+      !make_geom(g, channels, height, width, kh, kw, pad_h, pad_w, stride_h, stride_w, dil_h, dil_w, imgs,
+                 deformable_group, ld_col))
+    return SM3_ERR_INVALID_ARG;
+  const long n = (long)g.ho * g.wo * 2 * kh * kw * deformable_group * imgs;
+  deform_col2im_coord_kernel<<<blocks_for(n), 256, 0, (hipStream_t)stream>>>(n, col, im, offset, g, grad_offset);
+  return launch_status();
+}
+
+}  // extern "C"
