@@ -174,26 +174,41 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # The whole step is sync-free (routing tables are built on the device), so at N=1 it is captured once into a
-    # hipGraph and replayed: ~600 launches per step would otherwise leave the GPU idle ~15 % of the time behind the
-    # Python/ctypes launch path.  (N>1 stays eager this round: the RCCL collectives are issued from autograd hooks.)
-    use_graph = (not args.no_graph) and world == 1
+    # The whole step is sync-free (routing tables are built on the device), so it is captured once into hipGraphs and
+    # replayed: ~600 launches per step would otherwise leave the GPU idle ~15 % of the time behind the Python/ctypes
+    # launch path.  N=1: one graph (zero-grad, forward, backward, AdamW).  N>1: graph A = zero-grad + forward +
+    # backward into the flat gradient buckets, then the RCCL all-reduces of the buckets (eager, back to back on RCCL's
+    # stream), then graph B = AdamW.  (`--no-graph` runs eagerly with the all-reduces overlapped with backward.)
+    use_graph = not args.no_graph
     run = step
     graph_loss = None
     if use_graph:
+        reducer.overlap = False
+
+        def fwd_bwd():
+            reducer.zero_grad()
+            outs, gl = net(x, ['single'])
+            l = loss_fn(outs, gl, proj)
+            l.backward()
+            return l
+
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(2):
                 step()
         torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            graph_loss = step()
+        fence()
+        g_fb, g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_fb):
+            graph_loss = fwd_bwd()
+        with torch.cuda.graph(g_opt, pool=g_fb.pool()):
+            opt.step()
 
         def run():
-            graph.replay()
+            g_fb.replay()
+            reducer.finalize()  # world 1: no-op; world > 1: bucketed all-reduce + mean
+            g_opt.replay()
             return graph_loss
 
     for _ in range(args.warmup):

@@ -19,6 +19,8 @@
 // floats of row k, lanes 32-63 of row k+1 -- exactly the A[i][k]/B[k][j] fragment of the 32x32x2 instruction),
 // register-prefetched double-buffered LDS (one barrier per k-step), XCD-aware block remap so the N-tiles that
 // share an A row-panel land on one XCD's L2.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -27,8 +29,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int MODE_NT = 0, MODE_NN = 1, MODE_TN = 2;
-constexpr int BM = 128, BN = 128, BK = 32;
-constexpr int LD_T = BM + 1;  // leading dim of a tile written transposed (k-contiguous source): conflict-free b32 writes
+constexpr int BM = 128, BN = 128;
+constexpr int BK_MAX = 32;
+// leading dim of a tile written transposed (k-contiguous source), chosen so the 4-byte scatter writes of one
+// half-wave hit 32 distinct banks: BK=32 -> 8 k-quads x 4 rows need LD = 1 (mod 8); BK=16 -> 4 k-quads x 8 rows need 2.
+template <int BK> struct LdT { static constexpr int v = (BK == 32) ? BM + 1 : BM + 2; };
 constexpr int LD_D = BM + 4;  // leading dim of a tile written directly (k-major source): 16-B aligned rows
 constexpr int NTHREADS = 256;
 
@@ -68,9 +73,12 @@ __device__ __forceinline__ void gelu_erf_both(float h, float& y, float& dy) {
 // EPI codes (must match include/sm3det_hip.h)
 constexpr int EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_BIAS_SCALE_RES = 3, EPI_GELU_BWD = 4;
 
-template <int MODE, int EPI>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(GemmParams p) {
-  // both operand regions are sized for the wider leading dimension (LD_D); 2 stages each: 67.6 KB -> 2 blocks/CU
+template <int MODE, int EPI, int BK>
+__global__ __launch_bounds__(NTHREADS, (BK == 32 ? 2 : 4)) void gemm_f32_kernel(GemmParams p) {
+  constexpr int LD_T = LdT<BK>::v;
+  constexpr int NLD = BK / 8;  // global->LDS passes per operand tile
+  // both operand regions are sized for the wider leading dimension (LD_D); 2 stages each:
+  // BK=32: 67.6 KB -> 2 blocks/CU;  BK=16: 33.8 KB -> 4 blocks/CU (more prologue/epilogue overlap for short-K GEMMs)
   __shared__ __attribute__((aligned(16))) float smem[4 * BK * LD_D];
   // A tile uses LD_T when its source is k-contiguous (NT, NN), LD_D when k-major (TN).
   // B tile uses LD_T when its source is k-contiguous (NT),     LD_D when k-major (NN, TN).
@@ -149,18 +157,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(GemmParams p) {
 
   // ---- loaders ----------------------------------------------------------------------------------------------
   // transposed loader: source rows are k-contiguous: thread -> (row r + 32 i, k quad kq)
-  const int t_kq = tid & 7, t_r = tid >> 3;
+  const int t_kq = tid % (BK / 4), t_r = tid / (BK / 4);
+  constexpr int T_ROWS = NTHREADS / (BK / 4);  // rows covered per pass of the transposed loader
   // direct loader: source is k-major: thread -> (k row kk + 8 i, column quad nq)
   const int d_nq = tid & 31, d_kk = tid >> 5;
 
-  f32x4 ra[4], rb[4];
+  f32x4 ra[NLD], rb[NLD];
   const int nk = (MODE == MODE_TN) ? (max(row_end - row0, 0) + BK - 1) / BK : p.K / BK;
 
   auto load_tiles = [&](int kt) {
     if (MODE == MODE_TN) {
       const int kbase = row0 + kt * BK;
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
+      for (int i = 0; i < NLD; i++) {
         const int kr = kbase + d_kk + 8 * i;
         const int mcol = m0 + 4 * d_nq;
         const int ncol = n0 + 4 * d_nq;
@@ -175,23 +184,23 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(GemmParams p) {
     } else {
       const int k0 = kt * BK;
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const int r = row0 + t_r + 32 * i;
+      for (int i = 0; i < NLD; i++) {
+        const int r = row0 + t_r + T_ROWS * i;
         f32x4 va = {0.f, 0.f, 0.f, 0.f};
         if (r < row_end) va = *reinterpret_cast<const f32x4*>(Ag + (long)r * p.lda + k0 + 4 * t_kq);
         ra[i] = va;
       }
       if (MODE == MODE_NT) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-          const int n = n0 + t_r + 32 * i;
+        for (int i = 0; i < NLD; i++) {
+          const int n = n0 + t_r + T_ROWS * i;
           f32x4 vb = {0.f, 0.f, 0.f, 0.f};
           if (n < p.N) vb = *reinterpret_cast<const f32x4*>(Bg + (long)n * p.ldb + k0 + 4 * t_kq);
           rb[i] = vb;
         }
       } else {
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < NLD; i++) {
           const int kr = k0 + d_kk + 8 * i;
           const int ncol = n0 + 4 * d_nq;
           f32x4 vb = {0.f, 0.f, 0.f, 0.f};
@@ -206,23 +215,23 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(GemmParams p) {
     float* b_s = Bs + buf * BK * LDB_S;
     if (A_TRANS) {
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
+      for (int i = 0; i < NLD; i++) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) a_s[(4 * t_kq + j) * LDA_S + t_r + 32 * i] = ra[i][j];
+        for (int j = 0; j < 4; j++) a_s[(4 * t_kq + j) * LDA_S + t_r + T_ROWS * i] = ra[i][j];
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < 4; i++) *reinterpret_cast<f32x4*>(a_s + (d_kk + 8 * i) * LDA_S + 4 * d_nq) = ra[i];
+      for (int i = 0; i < NLD; i++) *reinterpret_cast<f32x4*>(a_s + (d_kk + 8 * i) * LDA_S + 4 * d_nq) = ra[i];
     }
     if (B_TRANS) {
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
+      for (int i = 0; i < NLD; i++) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) b_s[(4 * t_kq + j) * LDB_S + t_r + 32 * i] = rb[i][j];
+        for (int j = 0; j < 4; j++) b_s[(4 * t_kq + j) * LDB_S + t_r + T_ROWS * i] = rb[i][j];
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < 4; i++) *reinterpret_cast<f32x4*>(b_s + (d_kk + 8 * i) * LDB_S + 4 * d_nq) = rb[i];
+      for (int i = 0; i < NLD; i++) *reinterpret_cast<f32x4*>(b_s + (d_kk + 8 * i) * LDB_S + 4 * d_nq) = rb[i];
     }
   };
 
@@ -244,24 +253,36 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(GemmParams p) {
     if (kt + 1 < nk) load_tiles(kt + 1);
     const float* a_s = As + buf * BK * LDA_S + wm0 + l31;
     const float* b_s = Bs + buf * BK * LDB_S + wn0 + l31;
+    // software-pipelined fragment reads: the ds_reads of k-pair kk+1 are issued BEFORE the four MFMAs of k-pair kk
+    // (256 cycles of matrix work cover the ~100-cycle LDS latency; hipcc otherwise waits lgkmcnt(0) right before use)
+    float a0 = a_s[lh * LDA_S], a1 = a_s[lh * LDA_S + 32];
+    float b0 = b_s[lh * LDB_S], b1 = b_s[lh * LDB_S + 32];
 #pragma unroll
     for (int kk = 0; kk < BK / 2; kk++) {
-      const int krow = 2 * kk + lh;
-      const float a0 = a_s[krow * LDA_S];
-      const float a1 = a_s[krow * LDA_S + 32];
-      const float b0 = b_s[krow * LDB_S];
-      const float b1 = b_s[krow * LDB_S + 32];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
+      if (kk + 1 < BK / 2) {
+        const int krow = 2 * (kk + 1) + lh;
+        na0 = a_s[krow * LDA_S];
+        na1 = a_s[krow * LDA_S + 32];
+        nb0 = b_s[krow * LDB_S];
+        nb1 = b_s[krow * LDB_S + 32];
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep the prefetch reads above this k-pair's MFMAs
+      // operands swapped on purpose: D = (B fragment) x (A fragment) = the TRANSPOSED 32x32 tile, so that each lane
+      // ends up with 4 consecutive output COLUMNS of one row -> 16-byte epilogue loads/stores
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0, a0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1, a0, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0, a1, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1, a1, acc[1][1], 0, 0, 0);
+      a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (kt + 1 < nk) store_tiles(buf ^ 1);
     __syncthreads();
   }
 
   // ---- epilogue ---------------------------------------------------------------------------------------------
-  // acc[i][j][r]: row = wm0 + 32 i + (r&3) + 8 (r>>2) + 4 lh ; col = wn0 + 32 j + l31
+  // acc[i][j][4q + e]: row = wm0 + 32 i + l31 ; col = wn0 + 32 j + 8 q + 4 lh + e   (e = 0..3 contiguous)
   float* __restrict__ Cg = p.C;
   long c_base = 0;
   int m_lim;
@@ -274,55 +295,73 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f32_kernel(GemmParams p) {
   const float* bias = (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_SCALE_RES)
                           ? p.bias + (long)g * p.strideBias
                           : nullptr;
-  float csum[2] = {0.f, 0.f};
+  f32x4 csum[2][4];
+  if (EPI == EPI_GELU_BWD) {
 #pragma unroll
-  for (int j = 0; j < 2; j++) {
-    const int col = n0 + wn0 + 32 * j + l31;
-    if (col >= p.N) continue;
-    float bv = 0.f, gm = 0.f;
-    if (bias) bv = bias[col];
-    if (EPI == EPI_BIAS_SCALE_RES) gm = p.gamma[col];
+    for (int j = 0; j < 2; j++)
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
+      for (int q = 0; q < 4; q++) csum[j][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int row = m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (row >= m_lim) continue;
-        float v = acc[i][j][r];
-        const long ci = c_base + (long)row * p.ldc + col;
+  for (int i = 0; i < 2; i++) {
+    const int row = m0 + wm0 + 32 * i + l31;
+    if (row >= m_lim) continue;
+    float rsc = 1.f;
+    if (EPI == EPI_BIAS_SCALE_RES && p.rowscale) rsc = p.rowscale[row / p.rows_per_scale];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int col = n0 + wn0 + 32 * j + 8 * q + 4 * lh;
+        if (col >= p.N) continue;
+        f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+        float* cp = Cg + c_base + (long)row * p.ldc + col;
+        const long ai = (long)row * p.ld_aux + col;
         if (EPI == EPI_NONE) {
-          Cg[ci] = v;
+          *reinterpret_cast<f32x4*>(cp) = v;
         } else if (EPI == EPI_BIAS) {
-          Cg[ci] = v + bv;
+          *reinterpret_cast<f32x4*>(cp) = v + *reinterpret_cast<const f32x4*>(bias + col);
         } else if (EPI == EPI_BIAS_GELU) {
-          float y, dy;
-          gelu_erf_both(v + bv, y, dy);
-          p.aux_out[(long)row * p.ld_aux + col] = dy;
-          Cg[ci] = y;
+          const f32x4 h = v + *reinterpret_cast<const f32x4*>(bias + col);
+          f32x4 y, dy;
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            float ye, de;
+            gelu_erf_both(h[e], ye, de);
+            y[e] = ye;
+            dy[e] = de;
+          }
+          *reinterpret_cast<f32x4*>(p.aux_out + ai) = dy;
+          *reinterpret_cast<f32x4*>(cp) = y;
         } else if (EPI == EPI_BIAS_SCALE_RES) {
-          const float y = v + bv;
-          p.aux_out[(long)row * p.ld_aux + col] = y;
-          float sc = gm;
-          if (p.rowscale) sc *= p.rowscale[row / p.rows_per_scale];
-          Cg[ci] = p.aux_in[(long)row * p.ld_aux + col] + sc * y;
+          const f32x4 y = v + *reinterpret_cast<const f32x4*>(bias + col);
+          *reinterpret_cast<f32x4*>(p.aux_out + ai) = y;
+          const f32x4 sc = *reinterpret_cast<const f32x4*>(p.gamma + col) * rsc;
+          *reinterpret_cast<f32x4*>(cp) = *reinterpret_cast<const f32x4*>(p.aux_in + ai) + sc * y;
         } else if (EPI == EPI_GELU_BWD) {
-          const float o = v * p.aux_in[(long)row * p.ld_aux + col];
-          Cg[ci] = o;
-          csum[j] += o;
+          const f32x4 o = v * *reinterpret_cast<const f32x4*>(p.aux_in + ai);
+          *reinterpret_cast<f32x4*>(cp) = o;
+          csum[j][q] += o;
         }
       }
     }
   }
   if (EPI == EPI_GELU_BWD) {
     if (p.colpart) {  // uniform branch: column sums of this 128-row tile -> colpart[tile_m][n]
-      float* red = smem;  // k-loop ended with a barrier: LDS is free. [2 row-halves][BN]
+      constexpr int LDR = BN + 4;
+      float* red = smem;  // the k-loop ended with a barrier: LDS is free.  [64 = 2 wave rows x 32 lanes][LDR]
 #pragma unroll
-      for (int j = 0; j < 2; j++) {
-        float v = csum[j] + __shfl_xor(csum[j], 32, 64);
-        if (lh == 0) red[(wave >> 1) * BN + wn0 + 32 * j + l31] = v;
-      }
+      for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+          *reinterpret_cast<f32x4*>(red + ((wave >> 1) * 32 + l31) * LDR + wn0 + 32 * j + 8 * q + 4 * lh) = csum[j][q];
       __syncthreads();
-      if (tid < BN && n0 + tid < p.N) p.colpart[(long)tile_m * p.N + n0 + tid] = red[tid] + red[BN + tid];
+      if (tid < BN && n0 + tid < p.N) {
+        float t = 0.f;
+#pragma unroll 8
+        for (int r = 0; r < 64; r++) t += red[r * LDR + tid];
+        p.colpart[(long)tile_m * p.N + n0 + tid] = t;
+      }
     }
   }
 }
@@ -405,11 +444,11 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
   }
 }
 
-template <int MODE>
+template <int MODE, int BK>
 int launch_mode(const GemmParams& p, int epi, dim3 grid, hipStream_t st) {
 #define SM3_LAUNCH(E)                                                  \
   case E:                                                              \
-    gemm_f32_kernel<MODE, E><<<grid, NTHREADS, 0, st>>>(p);            \
+    gemm_f32_kernel<MODE, E, BK><<<grid, NTHREADS, 0, st>>>(p);        \
     return SM3_OK;
   switch (epi) {
     SM3_LAUNCH(EPI_NONE)
@@ -440,11 +479,19 @@ size_t sm3_gemm_f32_workspace_bytes(const sm3_gemm_desc* d) {
   return (size_t)groups * splits * d->M * d->N * sizeof(float);
 }
 
+// k-step depth: 16 gives 4 resident blocks per CU (33.8 KB LDS, <=128 VGPRs), 32 gives 2.
+static int choose_bk(const sm3_gemm_desc* d) {
+  if (d->mode == MODE_TN) return 16;   // measured on MI355X (scripts/gemm_shapes.py): split-K wgrad always prefers 16
+  return d->K <= 768 ? 16 : 32;        // short-K GEMMs are prologue/epilogue bound: more resident blocks win
+}
+
 int sm3_gemm_f32(const sm3_gemm_desc* d, void* workspace, size_t workspace_bytes, sm3_stream_t stream) {
   if (!d) return SM3_ERR_INVALID_ARG;
   if (d->M < 0 || d->N <= 0 || d->K < 0) return SM3_ERR_INVALID_ARG;
   if ((d->lda & 3) || (d->ldb & 3) || (d->N & 3)) return SM3_ERR_UNSUPPORTED;  // float4 loads
-  if (d->mode != MODE_TN && (d->K % BK) != 0) return SM3_ERR_UNSUPPORTED;
+  if (d->mode != MODE_TN && (d->K % BK_MAX) != 0) return SM3_ERR_UNSUPPORTED;
+  static const int env_bk = [] { const char* e = getenv("SM3_GEMM_BK"); return e ? atoi(e) : 0; }();
+  int bk = env_bk == 16 || env_bk == 32 ? env_bk : choose_bk(d);
   if (d->mode == MODE_TN && (d->M & 3)) return SM3_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   GemmParams p;
@@ -471,7 +518,8 @@ int sm3_gemm_f32(const sm3_gemm_desc* d, void* workspace, size_t workspace_bytes
     p.C = (float*)workspace;
     p.ldc = d->N;
     dim3 grid(ntn * ntm, 1, p.num_groups * p.splits);
-    gemm_f32_kernel<MODE_TN, EPI_NONE><<<grid, NTHREADS, 0, st>>>(p);
+    if (bk == 16) gemm_f32_kernel<MODE_TN, EPI_NONE, 16><<<grid, NTHREADS, 0, st>>>(p);
+    else gemm_f32_kernel<MODE_TN, EPI_NONE, 32><<<grid, NTHREADS, 0, st>>>(p);
     const long mn = (long)d->M * d->N;
     long nb = (mn * p.num_groups / 4 + 255) / 256;
     if (nb > 4096) nb = 4096;
@@ -489,8 +537,10 @@ int sm3_gemm_f32(const sm3_gemm_desc* d, void* workspace, size_t workspace_bytes
     p.colpart = (float*)workspace;
   }
   int rc;
-  if (d->mode == MODE_NT) rc = launch_mode<MODE_NT>(p, d->epilogue, grid, st);
-  else if (d->mode == MODE_NN) rc = launch_mode<MODE_NN>(p, d->epilogue, grid, st);
+  if (d->mode == MODE_NT)
+    rc = bk == 16 ? launch_mode<MODE_NT, 16>(p, d->epilogue, grid, st) : launch_mode<MODE_NT, 32>(p, d->epilogue, grid, st);
+  else if (d->mode == MODE_NN)
+    rc = bk == 16 ? launch_mode<MODE_NN, 16>(p, d->epilogue, grid, st) : launch_mode<MODE_NN, 32>(p, d->epilogue, grid, st);
   else return SM3_ERR_INVALID_ARG;
   if (rc) return rc;
   if (want_colsum) {

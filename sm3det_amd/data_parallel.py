@@ -48,6 +48,10 @@ class BucketedGradReducer:
                 self._index[p] = bi
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
         self._armed = False
+        # overlap=True: each bucket's all-reduce is issued from the autograd hook of its last gradient (eager mode).
+        # overlap=False: hooks only count; finalize() issues all collectives back to back (used when forward+backward
+        # are replayed from a captured hipGraph, where Python hooks do not run).
+        self.overlap = True
 
     def _close(self, plist):
         total = sum(p.numel() for p in plist)
@@ -84,7 +88,7 @@ class BucketedGradReducer:
             return
         b = self.buckets[self._index[p]]
         b['pending'] -= 1
-        if b['pending'] == 0 and self.world > 1:
+        if b['pending'] == 0 and self.world > 1 and self.overlap:
             b['handle'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def finalize(self):
