@@ -1,0 +1,14 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from sm3det_amd import _lib_backbone as LB
+for (M, N, K) in [(16384, 1536, 384), (16384, 384, 1536), (131072, 384, 96)]:
+    A = torch.randn(M, K, device='cuda'); B = torch.randn(N, K, device='cuda'); C = torch.empty(M, N, device='cuda')
+    for _ in range(3): LB.gemm(LB.NT, A, B, C, M, N, K)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20): LB.gemm(LB.NT, A, B, C, M, N, K)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 20
+    print(f'ablate={os.environ.get("SM3_GEMM_ABLATE","0")} bk={os.environ.get("SM3_GEMM_BK","auto")} {M}x{N}x{K}: {ms*1e3:.1f} us {2*M*N*K/ms/1e9:.1f} TF')

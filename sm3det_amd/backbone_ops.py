@@ -202,7 +202,8 @@ class _MoEBlock(Function):
         top_val, gates = _e(T, m, like=x), _e(T, k, like=x)
         clean, hnorm = _e(T, E, like=x), _e(T, like=x)
         sigma = _e(T, E, like=x) if train else None
-        nblk = (T + 255) // 256
+        from . import _lib
+        nblk = _lib.lib().sm3_moe_router_partial_rows(T)
         partials = _e(nblk, 2 * E, like=x)
         call('moe_router_fwd', hcat, PC, P, snorm, scale, noise, T, E, k, int(train), top_idx, top_val, gates,
              clean, sigma, hnorm, partials)
@@ -261,7 +262,8 @@ class _MoEBlock(Function):
         dxslot = dyslot  # reuse
         gemm(LB.NN, dh, w1, dxslot, S, C, Hd, offsets=offsets, num_groups=E)
         # router backward
-        nblk = (T + 255) // 256
+        from . import _lib
+        nblk = _lib.lib().sm3_moe_router_partial_rows(T)
         dhcat, dcn, ds_part = _e(T, PC, like=x), _e(T, E, like=x), _e(nblk, like=x)
         call('moe_router_bwd', hcat, PC, P, snorm, scale, noise, T, E, k, int(train), top_idx, top_val, gates, clean,
              sigma, hnorm, dgate, dimp, dload, dhcat, dcn, ds_part)

@@ -387,281 +387,6 @@ __global__ __launch_bounds__(256) void scale_bwd_prep_kernel(const float* __rest
   block_colsum_store<G, NV, 2>(acc, partials, C);
 }
 
-// ============================================================================================== MoE router
-constexpr int ROUTER_TB = 256;  // tokens per block (one thread per token)
-
-__device__ __forceinline__ float normal_cdf(float z) { return 0.5f * (1.0f + erff(z * 0.70710678118654752440f)); }
-__device__ __forceinline__ float normal_pdf(float z) { return 0.39894228040143267794f * __expf(-0.5f * z * z); }
-__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(__expf(x)); }  // torch threshold 20
-
-// hcat row layout: [h (P) | raw (E) | pad]; snorm = column-normalised sim_matrix (P,E); scale = exp(min(tau, ln 100)).
-// Outputs per token: top_idx/top_val (m = min(k+1,E), descending), gates (k, softmax of the top k), clean (E),
-// sigma (E, train only), hnorm; per-block partial sums [importance (E) | load (E)] to `partials`.
-template <int ET>
-__global__ __launch_bounds__(ROUTER_TB) void moe_router_fwd_kernel(
-    const float* __restrict__ hcat, int ldh, int P, const float* __restrict__ snorm, const float* __restrict__ scale_p,
-    const float* __restrict__ noise, int T, int E, int k, int train, int32_t* __restrict__ top_idx,
-    float* __restrict__ top_val, float* __restrict__ gates, float* __restrict__ clean_o, float* __restrict__ sigma_o,
-    float* __restrict__ hnorm_o, float* __restrict__ partials) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];  // snorm (P*E) then reduction scratch
-  float* s_s = sm;
-  float* s_red = sm + (long)P * E;  // [2E][ROUTER_TB/64]
-  for (int i = threadIdx.x; i < P * E; i += blockDim.x) s_s[i] = snorm[i];
-  __syncthreads();
-  const int t = blockIdx.x * ROUTER_TB + threadIdx.x;
-  const bool tv = t < T;
-  const int m = min(k + 1, E);
-  float imp[ET], ld[ET];
-#pragma unroll
-  for (int e = 0; e < ET; e++) imp[e] = ld[e] = 0.f;
-  if (tv) {
-    const float* h = hcat + (long)t * ldh;
-    float dot[ET];
-#pragma unroll
-    for (int e = 0; e < ET; e++) dot[e] = 0.f;
-    float nn = 0.f;
-    for (int p = 0; p < P; p += 4) {
-      const f32x4 hv = ld4(h + p);
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        nn += hv[j] * hv[j];
-#pragma unroll
-        for (int e = 0; e < ET; e++)
-          if (e < E) dot[e] += hv[j] * s_s[(p + j) * E + e];
-      }
-    }
-    const float hn = sqrtf(nn);
-    const float inv = 1.0f / fmaxf(hn, 1e-12f);  // F.normalize eps
-    const float scale = *scale_p;
-    float logit[ET], cl[ET], sg[ET];
-#pragma unroll
-    for (int e = 0; e < ET; e++) {
-      cl[e] = (e < E) ? dot[e] * inv * scale : -INFINITY;
-      sg[e] = 1.f;
-      logit[e] = cl[e];
-      if (e < E && train) {
-        sg[e] = softplus_f(h[P + e]) + 1e-2f;
-        logit[e] = cl[e] + noise[(long)t * E + e] * sg[e];
-      }
-    }
-    // top-m selection (descending); ties -> lower index, like a stable descending sort
-    float tvv[ET];
-    int tii[ET];
-    unsigned used = 0;
-#pragma unroll
-    for (int j = 0; j < ET; j++) {
-      if (j < m) {
-        float best = -INFINITY;
-        int bi = -1;
-#pragma unroll
-        for (int e = 0; e < ET; e++)
-          if (e < E && !((used >> e) & 1u) && (bi < 0 || logit[e] > best)) {
-            best = logit[e];
-            bi = e;
-          }
-        used |= 1u << bi;
-        tvv[j] = best;
-        tii[j] = bi;
-        top_idx[(long)t * m + j] = bi;
-        top_val[(long)t * m + j] = best;
-      }
-    }
-    // softmax over the top k
-    float gsum = 0.f, gk[ET];
-#pragma unroll
-    for (int j = 0; j < ET; j++)
-      if (j < k) {
-        gk[j] = __expf(tvv[j] - tvv[0]);
-        gsum += gk[j];
-      }
-#pragma unroll
-    for (int j = 0; j < ET; j++)
-      if (j < k) {
-        gk[j] /= gsum;
-        gates[(long)t * k + j] = gk[j];
-#pragma unroll
-        for (int e = 0; e < ET; e++)
-          if (e == tii[j]) imp[e] += gk[j];
-      }
-    const bool smooth = train && (k < E);
-#pragma unroll
-    for (int e = 0; e < ET; e++)
-      if (e < E) {
-        clean_o[(long)t * E + e] = cl[e];
-        if (train) sigma_o[(long)t * E + e] = sg[e];
-        if (smooth) {
-          float vin = 0.f, vout = 0.f;
-#pragma unroll
-          for (int j = 0; j < ET; j++) {
-            if (j == k) vin = tvv[j];
-            if (j == k - 1) vout = tvv[j];
-          }
-          const float thr = (logit[e] > vin) ? vin : vout;  // _prob_in_top_k :159-173
-          ld[e] = normal_cdf((cl[e] - thr) / sg[e]);
-        } else {
-          float gg = 0.f;
-#pragma unroll
-          for (int j = 0; j < ET; j++)
-            if (j < k && tii[j] == e) gg = gk[j];
-          ld[e] = gg > 0.f ? 1.f : 0.f;  // _gates_to_load :149-150
-        }
-      }
-    hnorm_o[t] = hn;
-  }
-  // block partials (deterministic: wave shuffle tree, then fixed-order fold of the 4 waves)
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll
-  for (int e = 0; e < ET; e++) {
-    float a = group_sum<64>(imp[e]);
-    float c = group_sum<64>(ld[e]);
-    if (lane == 0 && e < E) {
-      s_red[e * 4 + wv] = a;
-      s_red[(E + e) * 4 + wv] = c;
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x < 2 * E) {
-    const float* r = s_red + threadIdx.x * 4;
-    partials[(long)blockIdx.x * 2 * E + threadIdx.x] = (r[0] + r[1]) + (r[2] + r[3]);
-  }
-}
-
-// backward of the router: per token dlogits from (i) the combine (dgate), (ii) the importance term, (iii) the
-// load term (train), then through noise / softplus / cosine normalisation.  Writes
-//   dhcat[t] = [dh (P) | draw (E) | 0...]   (row-major, ld = ldh; the gate GEMMs turn it into dWp, dWn, dx)
-//   dcn[t,e] = dclean[t,e] / max(|h_t|, eps)      (so that dSnorm = scale * h^T . dcn is one TN GEMM)
-//   ds_part[block] = sum_t sum_e dclean[t,e] * clean[t,e] / scale   (d scale)
-template <int ET>
-__global__ __launch_bounds__(ROUTER_TB) void moe_router_bwd_kernel(
-    const float* __restrict__ hcat, int ldh, int P, const float* __restrict__ snorm, const float* __restrict__ scale_p,
-    const float* __restrict__ noise, int T, int E, int k, int train, const int32_t* __restrict__ top_idx,
-    const float* __restrict__ top_val, const float* __restrict__ gates, const float* __restrict__ clean_i,
-    const float* __restrict__ sigma_i, const float* __restrict__ hnorm_i, const float* __restrict__ dgate,
-    const float* __restrict__ dimp, const float* __restrict__ dload, float* __restrict__ dhcat,
-    float* __restrict__ dcn, float* __restrict__ ds_part) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* s_s = sm;                   // snorm P*E
-  float* s_red = sm + (long)P * E;   // [4]
-  for (int i = threadIdx.x; i < P * E; i += blockDim.x) s_s[i] = snorm[i];
-  __syncthreads();
-  const int t = blockIdx.x * ROUTER_TB + threadIdx.x;
-  const int m = min(k + 1, E);
-  float ds_local = 0.f;
-  if (t < T) {
-    const float scale = *scale_p;
-    float dlogit[ET], dclean[ET], dsig[ET];
-#pragma unroll
-    for (int e = 0; e < ET; e++) dlogit[e] = dclean[e] = dsig[e] = 0.f;
-    int tii[ET];
-    float tvv[ET];
-#pragma unroll
-    for (int j = 0; j < ET; j++)
-      if (j < m) {
-        tii[j] = top_idx[(long)t * m + j];
-        tvv[j] = top_val[(long)t * m + j];
-      }
-    // softmax backward
-    float gk[ET], dg[ET], dotg = 0.f;
-#pragma unroll
-    for (int j = 0; j < ET; j++)
-      if (j < k) {
-        gk[j] = gates[(long)t * k + j];
-        dg[j] = dgate[(long)t * k + j] + dimp[tii[j]];
-        dotg += gk[j] * dg[j];
-      }
-#pragma unroll
-    for (int j = 0; j < ET; j++)
-      if (j < k) {
-        const float dv = gk[j] * (dg[j] - dotg);
-#pragma unroll
-        for (int e = 0; e < ET; e++)
-          if (e == tii[j]) dlogit[e] += dv;
-      }
-    const float* h = hcat + (long)t * ldh;
-    const bool smooth = train && (k < E);
-    if (smooth) {
-      float vin = 0.f, vout = 0.f;
-      int iin = -1, iout = -1;
-#pragma unroll
-      for (int j = 0; j < ET; j++) {
-        if (j == k) { vin = tvv[j]; iin = tii[j]; }
-        if (j == k - 1) { vout = tvv[j]; iout = tii[j]; }
-      }
-      float dthr_in = 0.f, dthr_out = 0.f;
-#pragma unroll
-      for (int e = 0; e < ET; e++)
-        if (e < E) {
-          const float cl = clean_i[(long)t * E + e], sg = sigma_i[(long)t * E + e];
-          const float lg = cl + noise[(long)t * E + e] * sg;
-          const bool is_in = lg > vin;
-          const float thr = is_in ? vin : vout;
-          const float z = (cl - thr) / sg;
-          const float q = dload[e] * normal_pdf(z) / sg;
-          dclean[e] += q;
-          dsig[e] -= q * z;
-          if (is_in) dthr_in -= q; else dthr_out -= q;
-        }
-#pragma unroll
-      for (int e = 0; e < ET; e++) {
-        if (e == iin) dlogit[e] += dthr_in;
-        if (e == iout) dlogit[e] += dthr_out;
-      }
-    }
-    float* dh = dhcat + (long)t * ldh;
-#pragma unroll
-    for (int e = 0; e < ET; e++)
-      if (e < E) {
-        dclean[e] += dlogit[e];
-        float draw = 0.f;
-        if (train) {
-          dsig[e] += noise[(long)t * E + e] * dlogit[e];
-          const float r = h[P + e];
-          draw = dsig[e] / (1.0f + __expf(-r));  // d softplus = sigmoid
-        }
-        dh[P + e] = draw;
-      }
-    for (int c = P + E; c < ldh; c++) dh[c] = 0.f;
-    const float hn = hnorm_i[t];
-    const float inv = 1.0f / fmaxf(hn, 1e-12f);
-#pragma unroll
-    for (int e = 0; e < ET; e++)
-      if (e < E) {
-        dcn[(long)t * E + e] = dclean[e] * inv;
-        ds_local += dclean[e] * clean_i[(long)t * E + e];
-      }
-    ds_local /= scale;
-    // dh = (dhh - hh <hh, dhh>) * inv,  dhh = scale * snorm . dclean,  hh = h * inv
-    float proj = 0.f;
-    for (int p = 0; p < P; p++) {
-      float dhh = 0.f;
-#pragma unroll
-      for (int e = 0; e < ET; e++)
-        if (e < E) dhh += s_s[p * E + e] * dclean[e];
-      dhh *= scale;
-      proj += dhh * h[p] * inv;
-    }
-    if (hn < 1e-12f) proj = 0.f;  // clamp region of F.normalize: d/dh (h/eps) = dhh/eps
-    for (int p = 0; p < P; p += 4) {
-      f32x4 o;
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        float dhh = 0.f;
-#pragma unroll
-        for (int e = 0; e < ET; e++)
-          if (e < E) dhh += s_s[(p + j) * E + e] * dclean[e];
-        dhh *= scale;
-        o[j] = (dhh - h[p + j] * inv * proj) * inv;
-      }
-      st4(dh + p, o);
-    }
-  }
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const float a = group_sum<64>(ds_local);
-  if (lane == 0) s_red[wv] = a;
-  __syncthreads();
-  if (threadIdx.x == 0) ds_part[blockIdx.x] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
-}
-
 // ============================================================================================== MoE plan (dispatch tables)
 // Deterministic expert-major slot assignment without a host sync: slot(t,j) = offsets[e] + rank of (t,j) among the
 // pairs routed to e in (t,j) order.  Three launches: per-block histogram, one-block scan, per-block ranks.
@@ -958,52 +683,6 @@ int sm3_scale_bwd_prep(const float* dout, const float* y, const float* gamma, co
   SM3_ROW_DISPATCH(C, CALL);
 #undef CALL
   partials_reduce_kernel<<<(2 * C + 63) / 64, 256, 0, st>>>(part, nb, 2 * C, dgamma_db);
-  return launch_status();
-}
-
-int sm3_moe_router_fwd(const float* hcat, int ldh, int P, const float* snorm, const float* scale, const float* noise,
-                       int T, int E, int k, int train, int32_t* top_idx, float* top_val, float* gates, float* clean,
-                       float* sigma, float* hnorm, float* partials, sm3_stream_t stream) {
-  if (!hcat || !snorm || !scale || !top_idx || !top_val || !gates || !clean || !hnorm || !partials)
-    return SM3_ERR_INVALID_ARG;
-  if (T <= 0 || E < 1 || E > 32 || k < 1 || k > E || (P & 3) || P + E > ldh) return SM3_ERR_INVALID_ARG;
-  if (train && (!noise || !sigma)) return SM3_ERR_INVALID_ARG;
-  const int nblk = (T + ROUTER_TB - 1) / ROUTER_TB;
-  const size_t lds = ((size_t)P * E + 2 * E * 4) * sizeof(float);
-  hipStream_t st = (hipStream_t)stream;
-#define CALL(ET)                                                                                                    \
-  moe_router_fwd_kernel<ET><<<nblk, ROUTER_TB, lds, st>>>(hcat, ldh, P, snorm, scale, noise, T, E, k, train, top_idx, \
-                                                          top_val, gates, clean, sigma, hnorm, partials)
-  if (E <= 4) CALL(4);
-  else if (E <= 8) CALL(8);
-  else if (E <= 16) CALL(16);
-  else CALL(32);
-#undef CALL
-  return launch_status();
-}
-
-int sm3_moe_router_bwd(const float* hcat, int ldh, int P, const float* snorm, const float* scale, const float* noise,
-                       int T, int E, int k, int train, const int32_t* top_idx, const float* top_val,
-                       const float* gates, const float* clean, const float* sigma, const float* hnorm,
-                       const float* dgate, const float* dimp, const float* dload, float* dhcat, float* dcn,
-                       float* ds_part, sm3_stream_t stream) {
-  if (!hcat || !snorm || !scale || !top_idx || !top_val || !gates || !clean || !hnorm || !dgate || !dimp || !dload ||
-      !dhcat || !dcn || !ds_part)
-    return SM3_ERR_INVALID_ARG;
-  if (T <= 0 || E < 1 || E > 32 || k < 1 || k > E || (P & 3) || P + E > ldh) return SM3_ERR_INVALID_ARG;
-  if (train && (!noise || !sigma)) return SM3_ERR_INVALID_ARG;
-  const int nblk = (T + ROUTER_TB - 1) / ROUTER_TB;
-  const size_t lds = ((size_t)P * E + 4) * sizeof(float);
-  hipStream_t st = (hipStream_t)stream;
-#define CALL(ET)                                                                                                     \
-  moe_router_bwd_kernel<ET><<<nblk, ROUTER_TB, lds, st>>>(hcat, ldh, P, snorm, scale, noise, T, E, k, train, top_idx,  \
-                                                          top_val, gates, clean, sigma, hnorm, dgate, dimp, dload,   \
-                                                          dhcat, dcn, ds_part)
-  if (E <= 4) CALL(4);
-  else if (E <= 8) CALL(8);
-  else if (E <= 16) CALL(16);
-  else CALL(32);
-#undef CALL
   return launch_status();
 }
 

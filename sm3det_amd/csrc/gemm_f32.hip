@@ -156,82 +156,75 @@ __global__ __launch_bounds__(NTHREADS, (BK == 32 ? 2 : 4)) void gemm_f32_kernel(
   const float* __restrict__ Bg = p.B + (MODE == MODE_TN ? 0 : (long)g * p.strideB);
 
   // ---- loaders ----------------------------------------------------------------------------------------------
-  // transposed loader: source rows are k-contiguous: thread -> (row r + 32 i, k quad kq)
+  // transposed loader: source rows are k-contiguous: thread -> (row t_r + T_ROWS i, k quad t_kq)
   const int t_kq = tid % (BK / 4), t_r = tid / (BK / 4);
   constexpr int T_ROWS = NTHREADS / (BK / 4);  // rows covered per pass of the transposed loader
-  // direct loader: source is k-major: thread -> (k row kk + 8 i, column quad nq)
+  // direct loader: source is k-major: thread -> (k row d_kk + 8 i, column quad d_nq)
   const int d_nq = tid & 31, d_kk = tid >> 5;
-
-  f32x4 ra[NLD], rb[NLD];
   const int nk = (MODE == MODE_TN) ? (max(row_end - row0, 0) + BK - 1) / BK : p.K / BK;
 
-  auto load_tiles = [&](int kt) {
+  // Per-thread source pointers, computed once.  Out-of-range rows / columns are CLAMPED to a valid address instead
+  // of branched around (the garbage they bring only reaches output rows/columns the epilogue masks); the one place
+  // where zeros are required -- reduction rows past the segment end in TN -- uses a select after the load.
+  const float* pa[NLD];
+  const float* pb[NLD];
+#pragma unroll
+  for (int i = 0; i < NLD; i++) {
     if (MODE == MODE_TN) {
-      const int kbase = row0 + kt * BK;
-#pragma unroll
-      for (int i = 0; i < NLD; i++) {
-        const int kr = kbase + d_kk + 8 * i;
-        const int mcol = m0 + 4 * d_nq;
-        const int ncol = n0 + 4 * d_nq;
-        f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
-        if (kr < row_end) {
-          if (mcol < p.M) va = *reinterpret_cast<const f32x4*>(Ag + (long)kr * p.lda + mcol);
-          if (ncol < p.N) vb = *reinterpret_cast<const f32x4*>(Bg + (long)kr * p.ldb + ncol);
-        }
-        ra[i] = va;
-        rb[i] = vb;
-      }
+      const int mc = min(m0 + 4 * d_nq, p.M - 4), nc = min(n0 + 4 * d_nq, p.N - 4);
+      pa[i] = Ag + mc;
+      pb[i] = Bg + nc;
     } else {
-      const int k0 = kt * BK;
-#pragma unroll
-      for (int i = 0; i < NLD; i++) {
-        const int r = row0 + t_r + T_ROWS * i;
-        f32x4 va = {0.f, 0.f, 0.f, 0.f};
-        if (r < row_end) va = *reinterpret_cast<const f32x4*>(Ag + (long)r * p.lda + k0 + 4 * t_kq);
-        ra[i] = va;
-      }
+      const int r = min(row0 + t_r + T_ROWS * i, row_end - 1);
+      pa[i] = Ag + (long)r * p.lda + 4 * t_kq;
       if (MODE == MODE_NT) {
-#pragma unroll
-        for (int i = 0; i < NLD; i++) {
-          const int n = n0 + t_r + T_ROWS * i;
-          f32x4 vb = {0.f, 0.f, 0.f, 0.f};
-          if (n < p.N) vb = *reinterpret_cast<const f32x4*>(Bg + (long)n * p.ldb + k0 + 4 * t_kq);
-          rb[i] = vb;
-        }
+        const int n = min(n0 + t_r + T_ROWS * i, p.N - 1);
+        pb[i] = Bg + (long)n * p.ldb + 4 * t_kq;
       } else {
-#pragma unroll
-        for (int i = 0; i < NLD; i++) {
-          const int kr = k0 + d_kk + 8 * i;
-          const int ncol = n0 + 4 * d_nq;
-          f32x4 vb = {0.f, 0.f, 0.f, 0.f};
-          if (ncol < p.N) vb = *reinterpret_cast<const f32x4*>(Bg + (long)kr * p.ldb + ncol);
-          rb[i] = vb;
-        }
+        const int nc = min(n0 + 4 * d_nq, p.N - 4);
+        pb[i] = Bg + (long)(d_kk + 8 * i) * p.ldb + nc;
       }
+    }
+  }
+  // piece q in [0, 2*NLD): q < NLD -> A piece q, else B piece q - NLD
+  auto load_piece = [&](f32x4 (&ra)[NLD], f32x4 (&rb)[NLD], int q, int kt) {
+    if (MODE == MODE_TN) {
+      const int i = q < NLD ? q : q - NLD;
+      const int kr = row0 + kt * BK + d_kk + 8 * i;
+      const int krc = min(kr, row_end - 1);
+      if (q < NLD) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(pa[i] + (long)krc * p.lda);
+        ra[i] = kr < row_end ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      } else {
+        f32x4 v = *reinterpret_cast<const f32x4*>(pb[i] + (long)krc * p.ldb);
+        rb[i] = kr < row_end ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    } else if (q < NLD) {
+      ra[q] = *reinterpret_cast<const f32x4*>(pa[q] + kt * BK);
+    } else if (MODE == MODE_NT) {
+      rb[q - NLD] = *reinterpret_cast<const f32x4*>(pb[q - NLD] + kt * BK);
+    } else {
+      rb[q - NLD] = *reinterpret_cast<const f32x4*>(pb[q - NLD] + (long)kt * BK * p.ldb);
     }
   };
-  auto store_tiles = [&](int buf) {
-    float* a_s = As + buf * BK * LDA_S;
-    float* b_s = Bs + buf * BK * LDB_S;
-    if (A_TRANS) {
+  auto store_piece = [&](const f32x4 (&ra)[NLD], const f32x4 (&rb)[NLD], int q, int buf) {
+    if (q < NLD) {
+      float* a_s = As + buf * BK * LDA_S;
+      if (A_TRANS) {
 #pragma unroll
-      for (int i = 0; i < NLD; i++) {
-#pragma unroll
-        for (int j = 0; j < 4; j++) a_s[(4 * t_kq + j) * LDA_S + t_r + T_ROWS * i] = ra[i][j];
+        for (int j = 0; j < 4; j++) a_s[(4 * t_kq + j) * LDA_S + t_r + T_ROWS * q] = ra[q][j];
+      } else {
+        *reinterpret_cast<f32x4*>(a_s + (d_kk + 8 * q) * LDA_S + 4 * d_nq) = ra[q];
       }
     } else {
-#pragma unroll
-      for (int i = 0; i < NLD; i++) *reinterpret_cast<f32x4*>(a_s + (d_kk + 8 * i) * LDA_S + 4 * d_nq) = ra[i];
-    }
-    if (B_TRANS) {
-#pragma unroll
-      for (int i = 0; i < NLD; i++) {
+      const int i = q - NLD;
+      float* b_s = Bs + buf * BK * LDB_S;
+      if (B_TRANS) {
 #pragma unroll
         for (int j = 0; j < 4; j++) b_s[(4 * t_kq + j) * LDB_S + t_r + T_ROWS * i] = rb[i][j];
+      } else {
+        *reinterpret_cast<f32x4*>(b_s + (d_kk + 8 * i) * LDB_S + 4 * d_nq) = rb[i];
       }
-    } else {
-#pragma unroll
-      for (int i = 0; i < NLD; i++) *reinterpret_cast<f32x4*>(b_s + (d_kk + 8 * i) * LDB_S + 4 * d_nq) = rb[i];
     }
   };
 
@@ -243,42 +236,60 @@ __global__ __launch_bounds__(NTHREADS, (BK == 32 ? 2 : 4)) void gemm_f32_kernel(
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
+  // Two register sets: while tile kt is multiplied out of LDS, the global loads of tile kt+2 are ISSUED into one set
+  // (first half of the k-pairs) and tile kt+1 -- loaded one iteration earlier, long landed -- is WRITTEN to the other
+  // LDS buffer from the other set (second half), one piece between each group of four MFMAs.  The matrix pipe never
+  // waits for address arithmetic, a vmcnt drain or the LDS write pass; one barrier per k-step remains.
+  f32x4 sa0[NLD], sb0[NLD], sa1[NLD], sb1[NLD];
+  constexpr int NP = 2 * NLD;  // pieces per tile (== BK/4 == half of the BK/2 k-pairs)
+  static_assert(NP * 2 == BK / 2, "piece schedule assumes 2*NP k-pairs per tile");
   if (nk > 0) {
-    load_tiles(0);
-    store_tiles(0);
+#pragma unroll
+    for (int q = 0; q < NP; q++) load_piece(sa0, sb0, q, 0);
+#pragma unroll
+    for (int q = 0; q < NP; q++) store_piece(sa0, sb0, q, 0);
+#pragma unroll
+    for (int q = 0; q < NP; q++) load_piece(sa0, sb0, q, min(1, nk - 1));
   }
   __syncthreads();
-  for (int kt = 0; kt < nk; kt++) {
+
+  auto k_step = [&](f32x4 (&ca)[NLD], f32x4 (&cb)[NLD], f32x4 (&na)[NLD], f32x4 (&nb)[NLD], int kt) {
+    // ca/cb hold tile kt+1 (to be stored), na/nb receive tile kt+2
     const int buf = kt & 1;
-    if (kt + 1 < nk) load_tiles(kt + 1);
+    // branch-free on purpose: a conditional around a load makes hipcc drain vmcnt(0) at the join, serialising the
+    // pipeline.  Past the end the last tile is simply re-loaded / re-stored into the idle buffer (never read).
+    const int kt_load = min(kt + 2, nk - 1);
     const float* a_s = As + buf * BK * LDA_S + wm0 + l31;
     const float* b_s = Bs + buf * BK * LDB_S + wn0 + l31;
-    // software-pipelined fragment reads: the ds_reads of k-pair kk+1 are issued BEFORE the four MFMAs of k-pair kk
-    // (256 cycles of matrix work cover the ~100-cycle LDS latency; hipcc otherwise waits lgkmcnt(0) right before use)
     float a0 = a_s[lh * LDA_S], a1 = a_s[lh * LDA_S + 32];
     float b0 = b_s[lh * LDB_S], b1 = b_s[lh * LDB_S + 32];
 #pragma unroll
     for (int kk = 0; kk < BK / 2; kk++) {
-      float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
-      if (kk + 1 < BK / 2) {
+      float xa0 = 0.f, xa1 = 0.f, xb0 = 0.f, xb1 = 0.f;
+      if (kk + 1 < BK / 2) {  // fragment reads of the NEXT k-pair go out before this k-pair's MFMAs
         const int krow = 2 * (kk + 1) + lh;
-        na0 = a_s[krow * LDA_S];
-        na1 = a_s[krow * LDA_S + 32];
-        nb0 = b_s[krow * LDB_S];
-        nb1 = b_s[krow * LDB_S + 32];
+        xa0 = a_s[krow * LDA_S];
+        xa1 = a_s[krow * LDA_S + 32];
+        xb0 = b_s[krow * LDB_S];
+        xb1 = b_s[krow * LDB_S + 32];
       }
-      __builtin_amdgcn_sched_barrier(0);  // keep the prefetch reads above this k-pair's MFMAs
+      if (kk < NP) load_piece(na, nb, kk, kt_load);
+      else store_piece(ca, cb, kk - NP, buf ^ 1);
+      __builtin_amdgcn_sched_barrier(0);  // everything above is issued before this k-pair's MFMAs
       // operands swapped on purpose: D = (B fragment) x (A fragment) = the TRANSPOSED 32x32 tile, so that each lane
       // ends up with 4 consecutive output COLUMNS of one row -> 16-byte epilogue loads/stores
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0, a0, acc[0][0], 0, 0, 0);
       acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1, a0, acc[0][1], 0, 0, 0);
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0, a1, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1, a1, acc[1][1], 0, 0, 0);
-      a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+      a0 = xa0; a1 = xa1; b0 = xb0; b1 = xb1;
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (kt + 1 < nk) store_tiles(buf ^ 1);
     __syncthreads();
+  };
+  for (int kt = 0; kt < nk; kt += 2) {
+    k_step(sa0, sb0, sa1, sb1, kt);
+    if (kt + 1 < nk) k_step(sa1, sb1, sa0, sb0, kt + 1);
   }
 
   // ---- epilogue ---------------------------------------------------------------------------------------------
