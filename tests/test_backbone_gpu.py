@@ -138,6 +138,57 @@ def test_tiny_e8t2_vs_cpu_oracle_eval_and_train():
     assert n_checked > 300
 
 
+@pytest.mark.parametrize('name,cfg,res', [
+    # BASELINE config #4: ablation_moe_et e16t2_last2blocks (16 experts: ragged small-M grouped GEMMs)
+    ('e16t2_last2', dict(arch='tiny', MoE_Block_inds=[[], [], [0, 2, 4, 6, 8], [0, 2]], num_experts=16, top_k=2), 128),
+    # BASELINE config #5: SM3Det_convnext_b (ConvNeXt-B, C = 128..1024, 18 MoE + 18 dense blocks)
+    ('base_e8t2', dict(arch='base', MoE_Block_inds=[[], [0, 2], [i * 2 for i in range(14)], [0, 2]], num_experts=8,
+                       top_k=2), 64),
+    # configs/SM3Det/SM3Det_convnext_t.py: top_k = 3 (three-term combine)
+    ('tiny_e8t3', dict(arch='tiny', MoE_Block_inds=[[], [], [0, 2, 4, 6, 8], [0, 2]], num_experts=8, top_k=3), 64),
+])
+def test_other_baseline_layouts_vs_cpu_oracle(name, cfg, res):
+    from oracle import moe_oracle as MO
+    from sm3det_amd.convnext_moe import ConvNeXt_moe_MultiInput
+    torch.manual_seed(11)
+    net = ConvNeXt_moe_MultiInput(**cfg)
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        for n, p in net.named_parameters():
+            if n.endswith('gamma'):
+                p.copy_(torch.empty_like(p).uniform_(0.5, 1.5, generator=g))
+            elif 'w_noise' in n:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.3)
+            elif 'sim_matrix' in n:
+                p.copy_(torch.randn(p.shape, generator=g))
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    x = torch.randn(1, 3, res, res, generator=g)
+    net = net.cuda().train()
+    E, k = cfg['num_experts'], cfg['top_k']
+    toks, H = [], res // 4
+    for i, inds in enumerate(cfg['MoE_Block_inds']):
+        if i > 0:
+            H //= 2
+        toks += [H * H] * len([q for q in inds if q < MO.ARCH[cfg['arch']]['depths'][i]])
+    noise = [torch.randn(t, E, generator=g) for t in toks]
+    outs, gl = net(x.cuda(), ['single'], noise=[n.cuda() for n in noise])
+    loss_of(outs, gl).backward()
+    p = {kk: v.clone().requires_grad_(v.is_floating_point() and not kk.endswith(('.mean', '.std')))
+         for kk, v in sd.items()}
+    ro, rg = MO.backbone_forward(x, p, arch=cfg['arch'], moe_block_inds=cfg['MoE_Block_inds'], num_experts=E, top_k=k,
+                                 train=True, noise=noise)
+    for o, r in zip(outs, ro):
+        assert rel_err(o, r) < FWD_TOL, (name, rel_err(o, r))
+    assert rel_err(gl, rg) < FWD_TOL
+    loss_of(ro, rg).backward()
+    grads = _ref_key_grads(net)
+    worst = 0.0
+    for kk, v in p.items():
+        if v.grad is not None:
+            worst = max(worst, rel_err(grads[kk], v.grad))
+    assert worst < BWD_TOL, (name, worst)
+
+
 def test_no_moe_returns_plain_tuple():
     from sm3det_amd.convnext_moe import ConvNeXt_moe_MultiInput
     net = ConvNeXt_moe_MultiInput(arch='tiny').cuda().eval()
