@@ -245,9 +245,18 @@ def main():
         g_fl = sum(v['flops'] for v in gem)
         g_n = sum(v['launches'] for v in gem)
         achieved = g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
+        g_by = sum(v['bytes'] for v in gem)
+        traffic = None  # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside bench.py)
+        try:
+            with open(os.path.join(ROOT, 'profiles', 'r01', 'pmc_traffic.json')) as f:
+                traffic = round(json.load(f)['hbm_bytes_per_launch'])
+        except Exception:
+            pass
         roofline = dict(bound='mfma', kernel='gemm_f32_kernel (NT/NN/TN, fp32 v_mfma_f32_32x32x2_f32)',
                         achieved=round(achieved, 2), peak=MI355X_FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
-                        frac=round(achieved / MI355X_FP32_MFMA_PEAK_TFLOPS, 4), traffic=None,
+                        frac=round(achieved / MI355X_FP32_MFMA_PEAK_TFLOPS, 4), traffic=traffic,
+                        traffic_source='profiles/r01/pmc_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, per launch)',
+                        algorithmic_bytes_per_launch=round(g_by / max(g_n, 1)),
                         launches_per_step=g_n, avg_launch_us=round(g_ms / max(g_n, 1) * 1e3, 2),
                         algorithmic_gflop_per_step=round(g_fl / 1e9, 1),
                         gemm_ms_per_step=round(g_ms, 3),

@@ -132,7 +132,11 @@ def gemm(mode, A, B, C, M, N, K, *, epilogue=EPI_NONE, bias=None, aux_in=None, a
     tag = 'gemm_f32_' + ('nt', 'nn', 'tn')[mode]
     if PROFILE is not None and PROFILE_SHAPES:
         tag += f' {M}x{N}x{K} g{num_groups} e{epilogue} s{splits}'
-    with _Prof(tag, 2.0 * rows * N * (M if mode == TN else K)):
+    # algorithmic bytes: each operand read once, the output (and the epilogue's auxiliary tensor) written once
+    nb_alg = 4.0 * (rows * (M if mode == TN else K) + (rows if mode == TN else K) * N + M * N * max(num_groups if mode == TN else 1, 1))
+    if epilogue in (EPI_BIAS_GELU, EPI_BIAS_SCALE_RES, EPI_GELU_BWD):
+        nb_alg += 4.0 * M * N * (2 if epilogue == EPI_BIAS_SCALE_RES else 1)
+    with _Prof(tag, 2.0 * rows * N * (M if mode == TN else K), nb_alg):
         _lib.check(L.sm3_gemm_f32(ctypes.byref(d), _p(ws), nbytes, _lib.stream_ptr()), 'gemm_f32')
 
 
@@ -144,7 +148,7 @@ def colsum(x, M, N, out, offsets=None, num_groups=1, ld=None):
                    'colsum_f32')
 
 
-def tn_splits(tiles, rows, target_blocks=1024):
+def tn_splits(tiles, rows, target_blocks=512):
     """split-K factor so a weight-gradient GEMM fills the 256 CUs (>= ~4 blocks per CU) without tiny K chunks."""
     s = max(1, target_blocks // max(tiles, 1))
     s = min(s, max(1, rows // 256))

@@ -493,7 +493,7 @@ size_t sm3_gemm_f32_workspace_bytes(const sm3_gemm_desc* d) {
 // k-step depth: 16 gives 4 resident blocks per CU (33.8 KB LDS, <=128 VGPRs), 32 gives 2.
 static int choose_bk(const sm3_gemm_desc* d) {
   if (d->mode == MODE_TN) return 16;   // measured on MI355X (scripts/gemm_shapes.py): split-K wgrad always prefers 16
-  return d->K <= 768 ? 16 : 32;        // short-K GEMMs are prologue/epilogue bound: more resident blocks win
+  return (d->K >= 192 && d->K <= 768) ? 16 : 32;  // mid-K GEMMs are prologue/epilogue bound: more resident blocks win
 }
 
 int sm3_gemm_f32(const sm3_gemm_desc* d, void* workspace, size_t workspace_bytes, sm3_stream_t stream) {
