@@ -114,6 +114,12 @@ def ops_microbench():
     y = layer(x, rois)
     go = torch.randn_like(y)
     out['roi_align_rotated_bwd_512x256x7x7'] = timeit(lambda: torch.autograd.grad(y, x, go, retain_graph=True))
+    xl = x.detach().contiguous(memory_format=torch.channels_last).requires_grad_(True)  # NHWC features (MI355X layout)
+    out['roi_align_rotated_fwd_nhwc'] = timeit(lambda: layer(xl, rois))
+    yl = layer(xl, rois)
+    out['roi_align_rotated_bwd_nhwc'] = timeit(lambda: torch.autograd.grad(yl, xl, go, retain_graph=True))
+    d10, s10 = dev(synth.rotated_boxes(10000, 7)), dev(synth.unique_scores(10000, 8))
+    out['nms_rotated_10000'] = timeit(lambda: ops.nms_rotated(d10, s10, 0.1), n=3)
     return {k: round(v, 1) for k, v in out.items()}
 
 
