@@ -9,7 +9,7 @@ Metric (BASELINE.json): train imgs/sec, SM3Det ConvNeXt-T e8t2 @1024^2, bs2/GPU.
 Workload timed here (config.workload): one TRAINING STEP of the hot path = the `main_SM3Det.py` backbone
 (ConvNeXt_moe_MultiInput, ConvNeXt-T, 8 experts top-2, MoE in stages 1-3: 9 MoE + 9 dense blocks, drop_path 0.1,
 noisy gating) forward + backward in fp32 on a synthetic (2,3,1024,1024) batch per GPU, gradient all-reduce across
-ranks (bucketed, overlapped with backward) and a fused AdamW step.  The detector's FPN/heads (mmdet glue, SURVEY.md
+ranks (bucketed) and the optimizer step (global-norm clip 35 + AdamW with one lr per parameter, one fused launch).  The detector's FPN/heads (mmdet glue, SURVEY.md
 8(f) "next" rows) are NOT part of the timed step; the rotated-detection operators of hot path (b) are reported as
 per-op timings in `ops_us`, outside `value`.
 
@@ -154,8 +154,11 @@ def main():
     params = [p for p in net.parameters() if p.requires_grad]
     reducer = BucketedGradReducer(params, bucket_mb=64.0)
     reducer.broadcast_parameters(0)
-    opt = torch.optim.AdamW(params, lr=1e-4, betas=(0.9, 0.999), weight_decay=0.05, fused=True,
-                            capturable=not args.no_graph)
+    # optimizer of local_configs/main_SM3Det.py: AdamW(lr 1e-4, betas (0.9, 0.999), wd 0.05), one param group per
+    # parameter (paramwise_cfg / dynamic-lr hook), grad_clip max_norm 35 -- here one fused launch with a per-tensor lr vector
+    from sm3det_amd.optim import MultiTensorAdamW
+    opt = MultiTensorAdamW([dict(params=[p]) for p in params], lr=1e-4, betas=(0.9, 0.999), weight_decay=0.05,
+                           max_grad_norm=35.0)
 
     g = torch.Generator(device='cpu').manual_seed(rank)  # rank r draws its own synthetic shard
     x = torch.randn(BATCH, 3, RES, RES, generator=g).cuda()
@@ -277,7 +280,7 @@ def main():
             'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'main_SM3Det.py backbone (ConvNeXt_moe_MultiInput tiny, 8 experts top-2, 9 MoE + 9 '
-                                   'dense blocks) fwd+bwd + bucketed grad all-reduce + fused AdamW; synthetic '
+                                   'dense blocks) fwd+bwd + bucketed grad all-reduce + grad-clip(35)+AdamW (per-parameter lr); synthetic '
                                    f'randn({BATCH},3,{RES},{RES}) per GPU, random-init weights; FPN/heads excluded',
                        'global_batch': world * BATCH, 'resolution': RES, 'parallelism': f'dp{world}',
                        'grad_buckets': reducer.num_buckets, 'hip_graph': bool(use_graph)},

@@ -238,6 +238,19 @@ int sm3_deform_col2im_coord(const float* col, const float* im, const float* offs
                             int height, int width, int kh, int kw, int pad_h, int pad_w, int stride_h, int stride_w,
                             int dil_h, int dil_w, int imgs, int deformable_group, long ld_col, sm3_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * Optimizer step: clip_grad_norm_(max_norm) + AdamW over all tensors, one param group per
+ * tensor (mmcv/mmcv/runner/hooks/optimizer.py:55-73, optimizer/default_constructor.py:180-227; per-group lr written by
+ * mmrotate/core/hook/dynamic_lr.py:197-218).  Device tables: *_ptrs[t] = float* of tensor t (param, grad, exp_avg,
+ * exp_avg_sq), numel[t]; chunk_tab[c] = (tensor id, chunk index) with sm3_optim_chunk_elems() elements per chunk;
+ * lr[t], wd[t] device vectors.  step / clip_coef / grad_norm are device scalars (step is incremented here;
+ * max_grad_norm <= 0 disables clipping; partials = n_chunks floats of scratch).  torch.optim.AdamW arithmetic. */
+int sm3_optim_chunk_elems(void);
+int sm3_adamw_multi(const uint64_t* p_ptrs, const uint64_t* g_ptrs, const uint64_t* m_ptrs, const uint64_t* v_ptrs,
+                    const int64_t* numel, const int32_t* chunk_tab, int n_chunks, const float* lr, const float* wd,
+                    float beta1, float beta2, float eps, float max_grad_norm, float* step, float* clip_coef,
+                    float* grad_norm, float* partials, sm3_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -48,6 +48,8 @@ def signatures():
         'sm3_moe_combine_fwd': (I, [P, P, P, P, P, P, I, P, LL, I, I, P]),
         'sm3_moe_combine_bwd': (I, [P, P, P, P, P, P, I, P, P, P, LL, I, I, P, S, P]),
         'sm3_moe_gather_add': (I, [P, P, P, LL, I, I, I, P]),
+        'sm3_optim_chunk_elems': (I, []),
+        'sm3_adamw_multi': (I, [P, P, P, P, P, P, I, P, P, F, F, F, F, P, P, P, P, P]),
         'sm3_deform_im2col': (I, [P, P, P] + [I] * 13 + [LL, P]),
         'sm3_deform_col2im': (I, [P, P, P] + [I] * 13 + [LL, P]),
         'sm3_deform_col2im_coord': (I, [P, P, P, P] + [I] * 13 + [LL, P]),
@@ -148,7 +150,7 @@ def colsum(x, M, N, out, offsets=None, num_groups=1, ld=None):
                    'colsum_f32')
 
 
-def tn_splits(tiles, rows, target_blocks=512):
+def tn_splits(tiles, rows, target_blocks=1024):
     """split-K factor so a weight-gradient GEMM fills the 256 CUs (>= ~4 blocks per CU) without tiny K chunks."""
     s = max(1, target_blocks // max(tiles, 1))
     s = min(s, max(1, rows // 256))

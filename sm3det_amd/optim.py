@@ -1,0 +1,166 @@
+"""Optimizer step of the SM3Det training loop on MI355X.
+
+``MultiTensorAdamW`` -- drop-in for ``torch.optim.AdamW`` as the reference configures it (AdamW, betas (0.9, 0.999),
+weight_decay 0.05, ONE param group per parameter: mmcv/mmcv/runner/optimizer/default_constructor.py:180-227) fused
+with the gradient clipping of ``OptimizerHook`` (``grad_clip=dict(max_norm=35, norm_type=2)``,
+mmcv/mmcv/runner/hooks/optimizer.py:55-73).  All tensors are updated by ONE kernel launch that reads each group's
+``lr`` / ``weight_decay`` from a device vector, so the per-parameter learning rates that the dynamic-lr hook writes
+every step cost nothing; step counter, gradient norm and clip coefficient stay on the device (no host sync, hipGraph
+capturable).
+
+``DynamicLrPolicy`` -- the scalar arithmetic of ``DynamicLrUpdaterHook.get_dynamic_lr``
+(mmrotate/core/hook/dynamic_lr.py:107-175; default ``head_policy='normal'``, ``backbone_policy`` min/avg/max) as a
+plain object: feed it the step's loss scalars, get one lr multiplier per parameter name.
+"""
+import math
+
+import torch
+
+from . import _lib
+from . import _lib_backbone as LB
+
+
+class MultiTensorAdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm=None):
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        super().__init__(params, defaults)
+        self.max_grad_norm = float(max_grad_norm) if max_grad_norm else 0.0
+        self._built = False
+        self._last_hyper = None
+
+    # ------------------------------------------------------------------------------------------- tables
+    def _build(self):
+        ps = []
+        for gi, g in enumerate(self.param_groups):
+            for p in g['params']:
+                if p.grad is None:
+                    continue
+                if p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous():
+                    raise _lib.SM3Error('MultiTensorAdamW: parameters must be contiguous float32 GPU tensors')
+                ps.append((gi, p))
+        if not ps:
+            raise _lib.SM3Error('MultiTensorAdamW: no parameter has a gradient')
+        dev = ps[0][1].device
+        self._params = ps
+        chunk = _lib.lib().sm3_optim_chunk_elems()
+        tab = []
+        for ti, (_, p) in enumerate(ps):
+            st = self.state[p]
+            if 'exp_avg' not in st:
+                st['exp_avg'] = torch.zeros_like(p)
+                st['exp_avg_sq'] = torch.zeros_like(p)
+            for c in range((p.numel() + chunk - 1) // chunk):
+                tab.append((ti, c))
+        as_u64 = lambda ts: torch.tensor([t.data_ptr() for t in ts], dtype=torch.int64, device=dev)  # noqa: E731
+        self._p_ptrs = as_u64([p for _, p in ps])
+        self._m_ptrs = as_u64([self.state[p]['exp_avg'] for _, p in ps])
+        self._v_ptrs = as_u64([self.state[p]['exp_avg_sq'] for _, p in ps])
+        self._g_ptrs = as_u64([p.grad for _, p in ps])
+        self._g_addr = [p.grad.data_ptr() for _, p in ps]
+        self._numel = torch.tensor([p.numel() for _, p in ps], dtype=torch.int64, device=dev)
+        self._chunks = torch.tensor(tab, dtype=torch.int32, device=dev).contiguous()
+        self._n_chunks = len(tab)
+        self._lr = torch.empty(len(ps), dtype=torch.float32, device=dev)
+        self._wd = torch.empty(len(ps), dtype=torch.float32, device=dev)
+        self._step = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._coef = torch.ones(1, dtype=torch.float32, device=dev)
+        self.grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._partials = torch.empty(self._n_chunks, dtype=torch.float32, device=dev)
+        self._built = True
+        self.update_hyperparams(force=True)
+
+    def update_hyperparams(self, force=False):
+        """Push the groups' lr / weight_decay to the device vectors (call before replaying a captured graph whenever a
+        scheduler changed them; ``step()`` does it itself when not capturing)."""
+        if not self._built:
+            return
+        lr = [self.param_groups[gi]['lr'] for gi, _ in self._params]
+        wd = [self.param_groups[gi]['weight_decay'] for gi, _ in self._params]
+        if force or (lr, wd) != self._last_hyper:
+            self._lr.copy_(torch.tensor(lr, dtype=torch.float32), non_blocking=True)
+            self._wd.copy_(torch.tensor(wd, dtype=torch.float32), non_blocking=True)
+            self._last_hyper = (lr, wd)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        if not self._built:
+            self._build()
+        elif not torch.cuda.is_current_stream_capturing():
+            if any(p.grad is None or p.grad.data_ptr() != a for (_, p), a in zip(self._params, self._g_addr)):
+                self._g_ptrs.copy_(torch.tensor([p.grad.data_ptr() for _, p in self._params], dtype=torch.int64))
+                self._g_addr = [p.grad.data_ptr() for _, p in self._params]
+            self.update_hyperparams()
+        g0 = self.param_groups[0]
+        b1, b2 = g0['betas']
+        LB.call('adamw_multi', self._p_ptrs, self._g_ptrs, self._m_ptrs, self._v_ptrs, self._numel, self._chunks,
+                self._n_chunks, self._lr, self._wd, float(b1), float(b2), float(g0['eps']), float(self.max_grad_norm),
+                self._step, self._coef, self.grad_norm, self._partials)
+        return loss
+
+
+class _EMA:
+    """EMA_meter of dynamic_lr.py:27-43"""
+
+    def __init__(self, alpha):
+        self.alpha, self.ema, self.steps = alpha, None, 0
+
+    def update(self, v):
+        self.ema = v if self.ema is None else self.alpha * v + (1 - self.alpha) * self.ema
+        self.steps += 1
+
+    def get(self):
+        return self.ema if self.ema is not None else 1e-3
+
+
+DEFAULT_REWEIGHT = {  # dynamic_lr.py:64-67
+    'sar_loss_cls': 'sar_bbox_head', 'sar_loss_bbox': 'sar_bbox_head', 'sar_loss_dfl': 'sar_bbox_head',
+    'rgb_loss_rpn_cls': 'rgb_rpn_head', 'rgb_loss_rpn_bbox': 'rgb_rpn_head', 'rgb_loss_cls': 'rgb_roi_head',
+    'rgb_loss_bbox': 'rgb_roi_head', 'ifr_loss_rpn_cls': 'ifr_rpn_head', 'ifr_loss_rpn_bbox': 'ifr_rpn_head',
+    'ifr_loss_cls': 'ifr_roi_head', 'ifr_loss_bbox': 'ifr_roi_head'}
+
+
+class DynamicLrPolicy:
+    """Per-parameter lr multipliers from the step's loss scalars (dynamic_lr.py:107-175)."""
+
+    def __init__(self, T=5, b=0.5, ema=0.005, backbone_policy='min', head_policy='normal', warmup_iters=0,
+                 reweight_losses=None):
+        self.T, self.b = T, b
+        self.backbone_policy, self.head_policy = backbone_policy, head_policy
+        self.warmup_iters = warmup_iters
+        self.reweight_losses = dict(reweight_losses or DEFAULT_REWEIGHT)
+        self.history = [_EMA(ema) for _ in self.reweight_losses]
+
+    def multipliers(self, log_vars, param_names):
+        """log_vars: {loss name: float}; returns {param name: multiplier}."""
+        names = [k for k in log_vars if k in self.reweight_losses]
+        cur = [float(sum(log_vars[k]) if isinstance(log_vars[k], list) else log_vars[k]) for k in names]
+        n = len(cur)
+        if self.history[0].steps < self.warmup_iters or self.head_policy == 'None':
+            bw = [1.0] * n
+        else:
+            hist = [m.get() for m in self.history[:n]]
+            w = [(c / h) if self.head_policy == 'reverse' else (h / c) for c, h in zip(cur, hist)]
+            mx = max(x / self.T for x in w)
+            ex = [math.exp(x / self.T - mx) for x in w]
+            bw = [n * e / sum(ex) for e in ex]
+        subnet = {}
+        for s in set(self.reweight_losses.values()):
+            ws = [bw[i] for i, k in enumerate(names) if self.reweight_losses[k] == s]
+            subnet[s] = sum(ws) / len(ws) if ws else 1.0
+        vals = list(subnet.values())
+        shared = {'min': min(vals), 'avg': sum(vals) / len(vals), 'max': max(vals)}.get(self.backbone_policy, 1.0)
+        for i, c in enumerate(cur):
+            self.history[i].update(c)
+        out = {}
+        for pn in param_names:
+            mult = shared
+            for s, v in subnet.items():
+                if s in pn:
+                    mult = v
+                    break
+            out[pn] = mult
+        return out
