@@ -594,6 +594,13 @@ inline int ew_blocks(long work, int threads = 256) {
 
 }  // namespace
 
+// LDS-tiled depthwise kernels (dwconv_lds.hip)
+bool sm3_dwconv7_lds_supported(int H, int W, int C);
+void sm3_dwconv7_lds_fwd(const float* x, const float* w49, const float* bias, const float* addend, float* y, int B,
+                         int H, int W, int C, hipStream_t st);
+void sm3_dwconv7_lds_bwd_weight(const float* x, const float* du, float* dw49, float* dbias, int B, int H, int W, int C,
+                                hipStream_t st);
+
 extern "C" {
 
 int sm3_stem_patchify(const float* x, float* a, int B, int H, int W, sm3_stream_t stream) {
@@ -640,6 +647,10 @@ int sm3_layernorm_bwd(const float* dy, const float* x, const float* w, const flo
 int sm3_dwconv7_fwd(const float* x, const float* w49, const float* bias, const float* addend, float* y, int B, int H,
                     int W, int C, sm3_stream_t stream) {
   if (!x || !w49 || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || C > 1024) return SM3_ERR_INVALID_ARG;
+  if (sm3_dwconv7_lds_supported(H, W, C)) {
+    sm3_dwconv7_lds_fwd(x, w49, bias, addend, y, B, H, W, C, (hipStream_t)stream);
+    return launch_status();
+  }
   const int nq = C / 4;
   const int spb = 256 / nq > 0 ? 256 / nq : 1;
   const long nstrips = (long)B * ((H + DW_RY - 1) / DW_RY) * ((W + DW_RX - 1) / DW_RX);
@@ -655,6 +666,10 @@ int sm3_dwconv7_bwd_weight(const float* x, const float* du, float* dw49, float* 
   hipStream_t st = (hipStream_t)stream;
   (void)hipMemsetAsync(dw49, 0, sizeof(float) * 49 * C, st);
   (void)hipMemsetAsync(dbias, 0, sizeof(float) * C, st);
+  if (sm3_dwconv7_lds_supported(H, W, C)) {
+    sm3_dwconv7_lds_bwd_weight(x, du, dw49, dbias, B, H, W, C, st);
+    return launch_status();
+  }
   const int nq = C / 4;
   const int spb = 256 / nq > 0 ? 256 / nq : 1;
   const long nstrips = (long)B * H * ((W + DW_RX - 1) / DW_RX);

@@ -1,0 +1,204 @@
+// dwconv_lds.hip -- depthwise 7x7 (padding 3) on NHWC tokens, LDS-tiled variant for gfx950.
+//
+// ConvNeXtBlock.depthwise_conv (mmrotate/models/backbones/convnext_moe.py:311-312, :347) forward, its input gradient
+// (same kernel, reversed taps, residual gradient fused as `addend`) and its weight/bias gradient.
+//
+// Tile = 16 x 16 output pixels x 32 channels per 256-thread workgroup.  The 22 x 22 x 32 input patch (halo 3) is brought
+// into LDS once with coalesced 16-byte loads (pixel stride padded to 40 floats so that the 16-lane groups of a
+// ds_read_b128 hit 16 distinct 16-byte slots), the 49 x 32 taps sit next to it; every lane then owns one channel quad
+// and a 2 x 4 pixel strip: 80 patch reads + 49 tap reads feed 392 float4 FMAs -> VALU-bound instead of the
+// address-arithmetic/latency-bound direct version in backbone.hip (69 us at 2x256x256x96; HBM time 16 us).
+// Used when C % 32 == 0 and H, W are multiples of 16 (every stage of ConvNeXt-T/B at 1024^2); otherwise the generic
+// kernels in backbone.hip run.
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+constexpr int TH = 16, TW = 16, CB = 32;          // tile
+constexpr int PH = TH + 6, PW = TW + 6;           // patch with halo
+constexpr int PS = CB + 8;                        // padded pixel stride (floats) in LDS
+constexpr int LDS_PATCH = PH * PW * PS;           // floats (77.4 KB -> two workgroups per CU)
+constexpr int TH_B = 8;                           // weight-gradient kernel: 8-row tiles (65.7 KB of LDS)
+constexpr int LDS_PATCH_B = (TH_B + 6) * PW * PS;
+
+template <int ROWS>
+__device__ __forceinline__ void load_patch(const float* __restrict__ x, int b, int H, int W, int C, int y0, int x0,
+                                           int c0, float* patch) {
+  // ROWS x 22 pixels x 8 quads; out-of-image pixels are zero (padding=3)
+  for (int idx = threadIdx.x; idx < ROWS * PW * (CB / 4); idx += 256) {
+    const int q = idx & 7, px = idx >> 3;
+    const int py = px / PW, pxx = px - py * PW;
+    const int iy = y0 - 3 + py, ix = x0 - 3 + pxx;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = ld4(x + (((long)b * H + iy) * W + ix) * C + c0 + 4 * q);
+    st4(patch + px * PS + 4 * q, v);
+  }
+}
+
+// y = conv(x) + bias (+ addend); grid = (W/16 * H/16, C/32, B)
+__global__ __launch_bounds__(256) void dwconv7_lds_fwd_kernel(const float* __restrict__ x,
+                                                             const float* __restrict__ w49,
+                                                             const float* __restrict__ bias,
+                                                             const float* __restrict__ addend, float* __restrict__ y,
+                                                             int H, int W, int C) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* patch = sm;
+  const int tiles_x = W / TW;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int c0 = blockIdx.y * CB, b = blockIdx.z;
+  const int y0 = ty * TH, x0 = tx * TW;
+  load_patch<PH>(x, b, H, W, C, y0, x0, c0, patch);
+  __syncthreads();
+  const float* taps = w49 + c0;  // 49 x 16 B per lane straight from L1/L2 (every workgroup of a chunk reads the same 6 KB)
+  const int cq = threadIdx.x & 7, xg = (threadIdx.x >> 3) & 3, rp = threadIdx.x >> 5;  // 8 quads x 4 x-groups x 8 row pairs
+  const int ry = 2 * rp, rx = 4 * xg;
+  f32x4 acc[2][4];
+  const f32x4 bv = bias ? ld4(bias + c0 + 4 * cq) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int r = 0; r < 2; r++)
+#pragma unroll
+    for (int c = 0; c < 4; c++) acc[r][c] = bv;
+  // Patch row ry+ir feeds output row 0 through tap row ky=ir and output row 1 through ky=ir-1.  The row loop is kept
+  // rolled (a full unroll hoists all 98 tap loads and spills); the 7 taps of the NEXT tap row are fetched from L1/L2
+  // while the FMAs of this one run.
+  f32x4 wprev[7], wcur[7], wnext[7];
+#pragma unroll
+  for (int kx = 0; kx < 7; kx++) {
+    wcur[kx] = ld4(taps + (long)kx * C + 4 * cq);
+    wprev[kx] = wcur[kx];
+  }
+#pragma unroll 1
+  for (int ir = 0; ir < 8; ir++) {
+    const int kn = ir + 1 < 7 ? ir + 1 : 6;  // clamped: branch-free prefetch
+#pragma unroll
+    for (int kx = 0; kx < 7; kx++) wnext[kx] = ld4(taps + (long)(kn * 7 + kx) * C + 4 * cq);
+    f32x4 in[10];
+    const float* prow = patch + ((ry + ir) * PW + rx) * PS + 4 * cq;
+#pragma unroll
+    for (int c = 0; c < 10; c++) in[c] = ld4(prow + c * PS);
+    const float m0 = ir < 7 ? 1.f : 0.f, m1 = ir > 0 ? 1.f : 0.f;  // rows 7 / 0 have no tap for output row 0 / 1
+#pragma unroll
+    for (int kx = 0; kx < 7; kx++) {
+      const f32x4 w0 = wcur[kx] * m0, w1 = wprev[kx] * m1;
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        acc[0][c] += in[c + kx] * w0;
+        acc[1][c] += in[c + kx] * w1;
+      }
+    }
+#pragma unroll
+    for (int kx = 0; kx < 7; kx++) {
+      wprev[kx] = wcur[kx];
+      wcur[kx] = wnext[kx];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 2; r++)
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const long o = (((long)b * H + y0 + ry + r) * W + x0 + rx + c) * C + c0 + 4 * cq;
+      f32x4 v = acc[r][c];
+      if (addend) v += ld4(addend + o);
+      st4(y + o, v);
+    }
+}
+
+// dw49[ky*7+kx][c] += sum_p du[p] * x[p + (ky-3, kx-3)] ; dbias[c] += sum_p du[p]   (outputs pre-zeroed)
+// grid = (spatial workers, C/32): each workgroup walks tiles with stride gridDim.x keeping its partial sums in
+// registers.  Thread = (channel quad, tap row ky, quarter of the tile rows): 8 x 7 x 4 = 224 active threads.
+__global__ __launch_bounds__(256) void dwconv7_lds_bwd_weight_kernel(const float* __restrict__ x,
+                                                                    const float* __restrict__ du,
+                                                                    float* __restrict__ dw49,
+                                                                    float* __restrict__ dbias, int B, int H, int W,
+                                                                    int C) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* patch = sm;                 // x with halo, [TH_B+6][22][PS]
+  float* dut = sm + LDS_PATCH_B;     // du tile [TH_B][16][CB]
+  const int c0 = blockIdx.y * CB;
+  const int tiles_x = W / TW, tiles_y = H / TH_B;
+  const int ntiles = B * tiles_y * tiles_x;
+  const int cq = threadIdx.x & 7;
+  const int ky = (threadIdx.x >> 3) % 7;
+  const int qr = (threadIdx.x >> 3) / 7;  // 0..3 active, 4 = idle lanes (threads 224..255)
+  const bool active = qr < 4;
+  f32x4 aw[7], ab = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 7; k++) aw[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int tx = t % tiles_x;
+    const int t2 = t / tiles_x;
+    const int ty = t2 % tiles_y, b = t2 / tiles_y;
+    const int y0 = ty * TH_B, x0 = tx * TW;
+    __syncthreads();  // previous tile fully consumed
+    load_patch<TH_B + 6>(x, b, H, W, C, y0, x0, c0, patch);
+    for (int idx = threadIdx.x; idx < TH_B * TW * (CB / 4); idx += 256) {
+      const int q = idx & 7, px = idx >> 3;
+      const int py = px >> 4, pxx = px & 15;
+      st4(dut + px * CB + 4 * q, ld4(du + (((long)b * H + y0 + py) * W + x0 + pxx) * C + c0 + 4 * q));
+    }
+    __syncthreads();
+    if (active) {
+#pragma unroll 1
+      for (int r = 0; r < TH_B / 4; r++) {
+        const int oy = (TH_B / 4) * qr + r;  // output row of the tile; input row oy + ky
+        const float* xr = patch + ((oy + ky) * PW) * PS + 4 * cq;
+        const float* gr = dut + (oy * TW) * CB + 4 * cq;
+        f32x4 in[PW];
+#pragma unroll
+        for (int c = 0; c < PW; c++) in[c] = ld4(xr + c * PS);
+#pragma unroll
+        for (int c = 0; c < TW; c++) {
+          const f32x4 g = ld4(gr + c * CB);
+          if (ky == 0) ab += g;
+#pragma unroll
+          for (int kx = 0; kx < 7; kx++) aw[kx] += g * in[c + kx];
+        }
+      }
+    }
+  }
+  // fold the 4 row-quarters through LDS, then one atomic per (tap, channel) per workgroup
+  __syncthreads();
+  float* red = sm;  // [4][7 ky][8 slots (7 taps + bias)][CB]
+  if (active) {
+#pragma unroll
+    for (int k = 0; k < 7; k++) st4(red + (((qr * 7 + ky) * 8 + k) * CB) + 4 * cq, aw[k]);
+    st4(red + (((qr * 7 + ky) * 8 + 7) * CB) + 4 * cq, ab);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 7 * 8 * CB; i += 256) {
+    const int c = i % CB, k = (i / CB) & 7, kyy = i / (8 * CB);
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; q++) s += red[((q * 7 + kyy) * 8 + k) * CB + c];
+    if (k < 7) atomicAdd(dw49 + (long)(kyy * 7 + k) * C + c0 + c, s);
+    else if (kyy == 0) atomicAdd(dbias + c0 + c, s);
+  }
+}
+
+}  // namespace
+
+// C++ entry points used by backbone.hip's C ABI functions (same library)
+bool sm3_dwconv7_lds_supported(int H, int W, int C) { return (C % CB) == 0 && (H % TH) == 0 && (W % TW) == 0; }
+
+void sm3_dwconv7_lds_fwd(const float* x, const float* w49, const float* bias, const float* addend, float* y, int B,
+                         int H, int W, int C, hipStream_t st) {
+  dim3 grid((W / TW) * (H / TH), C / CB, B);
+  const size_t lds = (size_t)LDS_PATCH * sizeof(float);
+  dwconv7_lds_fwd_kernel<<<grid, 256, lds, st>>>(x, w49, bias, addend, y, H, W, C);
+}
+
+void sm3_dwconv7_lds_bwd_weight(const float* x, const float* du, float* dw49, float* dbias, int B, int H, int W, int C,
+                                hipStream_t st) {
+  const int ntiles = B * (H / TH_B) * (W / TW);
+  int workers = 1024 / (C / CB);  // ~4 workgroups per CU in total
+  if (workers < 1) workers = 1;
+  if (workers > ntiles) workers = ntiles;
+  dim3 grid(workers, C / CB);
+  size_t lds = (size_t)(LDS_PATCH_B + TH_B * TW * CB) * sizeof(float);
+  if (lds < (size_t)4 * 7 * 8 * CB * sizeof(float)) lds = (size_t)4 * 7 * 8 * CB * sizeof(float);
+  dwconv7_lds_bwd_weight_kernel<<<grid, 256, lds, st>>>(x, du, dw49, dbias, B, H, W, C);
+}

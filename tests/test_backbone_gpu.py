@@ -243,7 +243,8 @@ def test_layernorm_patch_major_is_the_downsample_im2col():
     assert rel_err(x.grad, xr.grad) < 1e-4 and rel_err(cw.grad, cwr.grad) < 1e-4 and rel_err(cb.grad, cbr.grad) < 1e-4
 
 
-@pytest.mark.parametrize('B,H,W,C', [(2, 16, 16, 96), (1, 8, 24, 192), (1, 8, 8, 768), (2, 32, 32, 32)])
+@pytest.mark.parametrize('B,H,W,C', [(2, 16, 16, 96), (1, 8, 24, 192), (1, 8, 8, 768), (2, 32, 32, 32),
+                                     (2, 32, 48, 96), (1, 64, 32, 192), (2, 16, 32, 768), (1, 20, 16, 64)])
 def test_dwconv7_fwd_and_grads(B, H, W, C):
     from sm3det_amd import _lib_backbone as LB
     x = torch.randn(B, H, W, C, device='cuda')
