@@ -184,10 +184,11 @@ def main():
         torch.cuda.synchronize()
 
     # The whole step is sync-free (routing tables are built on the device), so it is captured once into hipGraphs and
-    # replayed: ~600 launches per step would otherwise leave the GPU idle ~15 % of the time behind the Python/ctypes
-    # launch path.  N=1: one graph (zero-grad, forward, backward, AdamW).  N>1: graph A = zero-grad + forward +
-    # backward into the flat gradient buckets, then the RCCL all-reduces of the buckets (eager, back to back on RCCL's
-    # stream), then graph B = AdamW.  (`--no-graph` runs eagerly with the all-reduces overlapped with backward.)
+    # replayed: ~800 launches per step would otherwise leave the GPU idle behind the Python/ctypes launch path.
+    # Graph A = forward + backward (gradients adopted by autograd: no zero-fill, no accumulate launches) and, for N>1,
+    # the pack of the gradients into the flat xGMI buckets; then the RCCL all-reduces of the buckets (eager, back to
+    # back on RCCL's stream); then graph B = grad-clip + AdamW reading the reduced buckets (N>1) or the gradients
+    # themselves (N=1).  (`--no-graph` runs eagerly with the all-reduces overlapped with backward.)
     use_graph = not args.no_graph
     run = step
     graph_loss = None
@@ -199,6 +200,7 @@ def main():
             outs, gl = net(x, ['single'])
             l = loss_fn(outs, gl, proj)
             l.backward()
+            reducer.pack_all()
             return l
 
         side = torch.cuda.Stream()
@@ -211,12 +213,16 @@ def main():
         g_fb, g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         with torch.cuda.graph(g_fb):
             graph_loss = fwd_bwd()
+        keep_alive = [p.grad for p in params]  # the tensors graph A writes the gradients to  # noqa: F841
+        g_fb.replay()
+        reducer.finalize(repack=False)  # N>1: p.grad -> slices of the reduced buckets
+        opt.refresh_grad_pointers()
         with torch.cuda.graph(g_opt, pool=g_fb.pool()):
             opt.step()
 
         def run():
             g_fb.replay()
-            reducer.finalize()  # world 1: no-op; world > 1: bucketed all-reduce + mean
+            reducer.finalize(repack=False)  # world 1: no-op; world > 1: bucketed all-reduce + mean
             g_opt.replay()
             return graph_loss
 

@@ -200,6 +200,24 @@ int sm3_moe_router_bwd(const float* hcat, int ldh, int P, const float* snorm, co
                        const float* dgate, const float* dimp, const float* dload, float* dhcat, float* dcn,
                        float* ds_part, sm3_stream_t stream);
 
+/* Gate parameter preparation, one launch (CosineTopKGate.forward :96-105 + the `x @ w_noise` operand :199-201):
+ * wcat (PC,C) = [cosine_projector.weight (P,C); w_noise^T (E,C); 0], bcat (PC) = [cosine_projector.bias; 0],
+ * snorm (P,E) = F.normalize(sim_matrix, dim=0), scale (1) = exp(min(temperature, clamp_max)). */
+int sm3_moe_gate_prep_fwd(const float* wp, const float* bp, const float* wn, const float* sim,
+                          const float* temperature, float clamp_max, int P, int C, int E, int PC, float* wcat,
+                          float* bcat, float* snorm, float* scale, sm3_stream_t stream);
+/* backward: dwcat (PC,C) / dbcat (PC) from the gate GEMM, dsn (P,E) = h^T.dcn (gradient w.r.t. snorm*scale),
+ * ds_part (n_part) partial sums of d(scale) from sm3_moe_router_bwd -> gradients of the five reference parameters. */
+int sm3_moe_gate_prep_bwd(const float* dwcat, const float* dbcat, const float* dsn, const float* ds_part, int n_part,
+                          const float* sim, const float* temperature, float clamp_max, int P, int C, int E,
+                          float* dwp, float* dbp, float* dwn, float* dsim, float* dtemp, sm3_stream_t stream);
+/* Auxiliary load-balancing loss (:140-147, :234-238): tot (2E) = column sums of the router partials =
+ * [importance | load]; loss (1) = coef * (cv_squared(importance) + cv_squared(load)).  Backward: dimp/dload (E). */
+int sm3_moe_aux_loss_fwd(const float* partials, int nblk, int E, float coef, float* tot, float* loss,
+                         sm3_stream_t stream);
+int sm3_moe_aux_loss_bwd(const float* tot, const float* dloss, int E, float coef, float* dimp, float* dload,
+                         sm3_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * SparseDispatcher (:250-293) without the host sync: expert-major slot tables from the top-k indices.
  * offsets (E+1) prefix of slots per expert; slot_token (T*k) token of each slot; token_slot (T,k) slot of each

@@ -42,6 +42,10 @@ def signatures():
         'sm3_moe_router_partial_rows': (I, [I]),
         'sm3_moe_router_fwd': (I, [P, I, I, P, P, P, I, I, I, I, P, P, P, P, P, P, P, P]),
         'sm3_moe_router_bwd': (I, [P, I, I, P, P, P, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+        'sm3_moe_gate_prep_fwd': (I, [P, P, P, P, P, F, I, I, I, I, P, P, P, P, P]),
+        'sm3_moe_gate_prep_bwd': (I, [P, P, P, P, I, P, P, F, I, I, I, P, P, P, P, P, P]),
+        'sm3_moe_aux_loss_fwd': (I, [P, I, I, F, P, P, P]),
+        'sm3_moe_aux_loss_bwd': (I, [P, P, I, F, P, P, P]),
         'sm3_moe_plan_workspace_bytes': (S, [I, I]),
         'sm3_moe_plan': (I, [P, I, I, I, I, P, P, P, P, S, P]),
         'sm3_moe_dispatch': (I, [P, P, P, LL, I, P]),

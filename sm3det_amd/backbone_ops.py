@@ -184,17 +184,33 @@ def dense_block(x, w49, bdw, lnw, lnb, w1, b1, w2, b2, gamma, rs, eps, B, H, W):
 
 
 # ------------------------------------------------------------------------------------------------ MoE block
+def _pad_rows(n):
+    """rows of the fused [Wp; Wn^T; 0] gate matrix: next multiple of 32."""
+    return (n + 31) // 32 * 32
+
+
 class _MoEBlock(Function):
+    """One MoE ConvNeXt block.  Inputs are the REFERENCE parameters (cosine_projector weight/bias `wp`/`bp`, `w_noise`
+    (C,E), `sim_matrix` (P,E), `temperature`); the fused gate operands are built by one prep launch and the auxiliary
+    loss by one more, so a block costs no torch elementwise launches."""
+
     @staticmethod
-    def forward(ctx, x, w49, bdw, lnw, lnb, wcat, bcat, snorm, scale, w1, b1, w2, b2, gamma, rs, noise, eps, B, H,
-                W, P, k, train):
+    def forward(ctx, x, w49, bdw, lnw, lnb, wp, bp, wn, sim, temp, w1, b1, w2, b2, gamma, rs, noise, eps, B, H, W, k,
+                train, clamp_max, loss_coef):
+        from . import _lib
         x = _chk(x, 'x')
         T, C = x.shape
         E, Hd = w1.shape[0], w1.shape[1]
-        PC = wcat.shape[0]
+        P = wp.shape[0]
+        PC = _pad_rows(P + E)
         m = min(k + 1, E)
         S = T * k
         u, xn, mean, rstd = _dw_ln_forward(x, w49, bdw, lnw, lnb, eps, B, H, W, C)
+        # gate operands: wcat = [Wp; Wn^T; 0], bcat = [bp; 0], snorm = normalize(sim, dim=0), scale = exp(clamp(t))
+        wcat, bcat = _e(PC, C, like=x), _e(PC, like=x)
+        snorm, scale = _e(P, E, like=x), _e(1, like=x)
+        call('moe_gate_prep_fwd', wp.contiguous(), bp.contiguous(), wn.contiguous(), sim.contiguous(), temp,
+             float(clamp_max), P, C, E, PC, wcat, bcat, snorm, scale)
         # gate projection (+ noise projection) in one GEMM: hcat = [h | raw | 0]
         hcat = _e(T, PC, like=x)
         gemm(LB.NT, xn, wcat, hcat, T, PC, C, epilogue=LB.EPI_BIAS, bias=bcat)
@@ -202,18 +218,16 @@ class _MoEBlock(Function):
         top_val, gates = _e(T, m, like=x), _e(T, k, like=x)
         clean, hnorm = _e(T, E, like=x), _e(T, like=x)
         sigma = _e(T, E, like=x) if train else None
-        from . import _lib
         nblk = _lib.lib().sm3_moe_router_partial_rows(T)
         partials = _e(nblk, 2 * E, like=x)
         call('moe_router_fwd', hcat, PC, P, snorm, scale, noise, T, E, k, int(train), top_idx, top_val, gates,
              clean, sigma, hnorm, partials)
-        tot = partials.sum(0)
-        importance, load = tot[:E], tot[E:]
+        tot, loss = _e(2 * E, like=x), _e(1, like=x)
+        call('moe_aux_loss_fwd', partials, nblk, E, float(loss_coef), tot, loss)
         # dispatch tables (no host sync)
         offsets = _e(E + 1, like=x, dtype=torch.int32)
         slot_token = _e(S, like=x, dtype=torch.int32)
         token_slot = _e(T, k, like=x, dtype=torch.int32)
-        from . import _lib
         nb = _lib.lib().sm3_moe_plan_workspace_bytes(T, E)
         ws = _lib.workspace(nb, x.device)
         call('moe_plan', top_idx, m, T, E, k, offsets, slot_token, token_slot, ws, nb)
@@ -229,23 +243,28 @@ class _MoEBlock(Function):
         call('moe_combine_fwd', yslot, token_slot, gates, x, gamma, rs, H * W, out, T, C, k)
         ctx.save_for_backward(x, u, mean, rstd, xn, hcat, top_idx, top_val, gates, clean, sigma, hnorm, offsets,
                               token_slot, xslot, hpre, act, yslot, w49, lnw, wcat, snorm, scale, w1, w2, gamma, rs,
-                              noise)
-        ctx.meta = (B, H, W, P, k, train)
-        ctx.mark_non_differentiable(offsets)
-        return out, importance, load, offsets
+                              noise, sim, temp, tot)
+        ctx.meta = (B, H, W, P, k, train, float(clamp_max), float(loss_coef))
+        ctx.mark_non_differentiable(tot, offsets)
+        return out, loss.reshape(()), tot, offsets
 
     @staticmethod
-    def backward(ctx, dout, dimp, dload, _doff):
+    def backward(ctx, dout, dloss, _dtot, _doff):
+        from . import _lib
         (x, u, mean, rstd, xn, hcat, top_idx, top_val, gates, clean, sigma, hnorm, offsets, token_slot, xslot, hpre,
-         act, yslot, w49, lnw, wcat, snorm, scale, w1, w2, gamma, rs, noise) = ctx.saved_tensors
-        B, H, W, P, k, train = ctx.meta
+         act, yslot, w49, lnw, wcat, snorm, scale, w1, w2, gamma, rs, noise, sim, temp, tot) = ctx.saved_tensors
+        B, H, W, P, k, train, clamp_max, loss_coef = ctx.meta
         T, C = x.shape
         E, Hd = w1.shape[0], w1.shape[1]
         PC = wcat.shape[0]
         S = T * k
         dout = dout.contiguous()
-        dimp = torch.zeros(E, device=x.device) if dimp is None else dimp.contiguous().float()
-        dload = torch.zeros(E, device=x.device) if dload is None else dload.contiguous().float()
+        # aux loss backward -> dimp | dload
+        dimp_load = _e(2 * E, like=x)
+        if dloss is None:
+            dimp_load.zero_()
+        else:
+            call('moe_aux_loss_bwd', tot, dloss.contiguous().float(), E, loss_coef, dimp_load, dimp_load[E:])
         # combine backward
         dyslot, dgate, dgamma = _e(S, C, like=x), _e(T, k, like=x), _e(C, like=x)
         ws, nb = LB.row_ws(C, x)
@@ -262,32 +281,35 @@ class _MoEBlock(Function):
         dxslot = dyslot  # reuse
         gemm(LB.NN, dh, w1, dxslot, S, C, Hd, offsets=offsets, num_groups=E)
         # router backward
-        from . import _lib
         nblk = _lib.lib().sm3_moe_router_partial_rows(T)
         dhcat, dcn, ds_part = _e(T, PC, like=x), _e(T, E, like=x), _e(nblk, like=x)
         call('moe_router_bwd', hcat, PC, P, snorm, scale, noise, T, E, k, int(train), top_idx, top_val, gates, clean,
-             sigma, hnorm, dgate, dimp, dload, dhcat, dcn, ds_part)
-        dscale = ds_part.sum().reshape(scale.shape)
+             sigma, hnorm, dgate, dimp_load, dimp_load[E:], dhcat, dcn, ds_part)
         if E % 4 == 0:
             dsn = _e(P, E, like=x)
             tiles = (P + 127) // 128
             gemm(LB.TN, hcat, dcn, dsn, P, E, T, lda=PC, ldb=E, splits=LB.tn_splits(tiles, T))
         else:  # tiny (P x E) product; E not a multiple of the 16-byte vector width
-            dsn = hcat[:, :P].t() @ dcn
-        dsnorm = dsn * scale
+            dsn = (hcat[:, :P].t() @ dcn).contiguous()
         dwcat = _tn(dhcat, xn, PC, C, T)
         dbcat = _e(PC, like=x)
         colsum(dhcat, T, PC, dbcat)
+        # gate parameters: [Wp; Wn^T] rows, normalize and exp(clamp) backward in one launch
+        dwp, dbp, dwn = _e(P, C, like=x), _e(P, like=x), _e(C, E, like=x)
+        dsim, dtemp = _e(P, E, like=x), _e(1, like=x)
+        call('moe_gate_prep_bwd', dwcat, dbcat, dsn, ds_part, nblk, sim.contiguous(), temp, clamp_max, P, C, E, dwp,
+             dbp, dwn, dsim, dtemp)
         dxn = _e(T, C, like=x)
         gemm(LB.NN, dhcat, wcat, dxn, T, C, PC)
         call('moe_gather_add', dxslot, token_slot, dxn, T, C, k, 1)
         dx, dw49, dbdw, dlnw, dlnb = _dw_ln_backward(dxn, dout, x, u, w49, lnw, mean, rstd, B, H, W, C)
-        return (dx, dw49, dbdw, dlnw, dlnb, dwcat, dbcat, dsnorm, dscale, dw1, db1, dw2, db2, dgamma, None, None,
-                None, None, None, None, None, None, None)
+        return (dx, dw49, dbdw, dlnw, dlnb, dwp, dbp, dwn, dsim, dtemp.reshape(temp.shape), dw1, db1, dw2, db2, dgamma,
+                None, None, None, None, None, None, None, None, None, None)
 
 
-def moe_block(x, w49, bdw, lnw, lnb, wcat, bcat, snorm, scale, w1, b1, w2, b2, gamma, rs, noise, eps, B, H, W, P, k,
-              train):
-    """Returns (out (T,C), importance (E), load (E), expert slot offsets (E+1, int32, non-differentiable))."""
-    return _MoEBlock.apply(x, w49, bdw, lnw, lnb, wcat, bcat, snorm, scale, w1, b1, w2, b2, gamma, rs, noise, eps, B,
-                           H, W, P, k, train)
+def moe_block(x, w49, bdw, lnw, lnb, wp, bp, wn, sim, temp, w1, b1, w2, b2, gamma, rs, noise, eps, B, H, W, k, train,
+              clamp_max, loss_coef=1e-2):
+    """Returns (out (T,C), aux loss (scalar), [importance | load] (2E, non-differentiable), expert slot offsets
+    (E+1, int32, non-differentiable))."""
+    return _MoEBlock.apply(x, w49, bdw, lnw, lnb, wp, bp, wn, sim, temp, w1, b1, w2, b2, gamma, rs, noise, eps, B, H,
+                           W, k, train, clamp_max, loss_coef)

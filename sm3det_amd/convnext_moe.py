@@ -136,7 +136,9 @@ class MoE_layer(nn.Module):
         self.w_noise = nn.Parameter(torch.zeros(C, E), requires_grad=True)
         self.register_buffer('mean', torch.tensor([0.0]))
         self.register_buffer('std', torch.tensor([1.0]))
+        self.loss_coef = 1e-2  # reference :226 (forward(x, loss_coef=1e-2))
         self.last_expert_offsets = None  # device int32 (E+1): expert loads of the last forward (no sync)
+        self.last_importance_load = None  # device fp32 (2E): [importance | load] of the last forward
 
     # ---- reference key schema <-> fused storage ---------------------------------------------------------
     _FUSED = {'w1': 'pointwise_conv1.weight', 'b1': 'pointwise_conv1.bias',
@@ -233,15 +235,17 @@ class ConvNeXtBlock(nn.Module):
                                   f.pointwise_conv2.bias, self.gamma, rs, self.norm.eps, B, H, W)
             return out, None
         moe = self.ffn
-        wcat, bcat, snorm, scale, P = moe.gate_inputs()
+        g = moe.w_gate
         train = bool(moe.training and moe.noisy_gating)
         if train and noise is None:
             noise = torch.randn(x.shape[0], moe.num_experts, device=x.device)  # torch.randn_like(clean) :203
-        out, importance, load, offsets = ops.moe_block(
-            x, w49, self.depthwise_conv.bias, self.norm.weight, self.norm.bias, wcat, bcat, snorm, scale, moe.w1,
-            moe.b1, moe.w2, moe.b2, self.gamma, rs, noise if train else None, self.norm.eps, B, H, W, P, moe.k, train)
+        out, loss, tot, offsets = ops.moe_block(
+            x, w49, self.depthwise_conv.bias, self.norm.weight, self.norm.bias, g.cosine_projector.weight,
+            g.cosine_projector.bias, moe.w_noise, g.sim_matrix, g.temperature, moe.w1, moe.b1, moe.w2, moe.b2,
+            self.gamma, rs, noise if train else None, self.norm.eps, B, H, W, moe.k, train, g.clamp_max,
+            moe.loss_coef)  # aux loss (:234-238) comes out of the block: coef * (cv^2(importance) + cv^2(load))
         moe.last_expert_offsets = offsets
-        loss = (moe.cv_squared(importance) + moe.cv_squared(load)) * 1e-2  # :234-238, loss_coef=1e-2
+        moe.last_importance_load = tot
         return out, loss
 
     def forward(self, x):
@@ -378,7 +382,7 @@ class ConvNeXt_moe(nn.Module):
                     o = norm_layer.forward_tokens(tok).view(B, H, W, C).permute(0, 3, 1, 2)
                     outs.append(o.contiguous() if self.nchw_outputs else o)
         if len(gate_losses) > 0:
-            return tuple(outs), sum(gate_losses) / len(gate_losses)
+            return tuple(outs), torch.stack(gate_losses).mean()  # == sum(losses) / len(losses), two launches
         return tuple(outs)
 
     def forward(self, x):

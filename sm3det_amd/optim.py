@@ -69,6 +69,20 @@ class MultiTensorAdamW(torch.optim.Optimizer):
         self._built = True
         self.update_hyperparams(force=True)
 
+    def refresh_grad_pointers(self):
+        """Re-read the addresses of ``p.grad`` (they move when gradients are dropped with set_to_none and re-created
+        by autograd).  ``step()`` does it itself when not capturing; call it once, outside the capture, before capturing
+        a graph that contains ``step()`` so the graph reads the gradients where the captured backward writes them."""
+        if not self._built:
+            return
+        if any(p.grad is None for _, p in self._params):
+            raise _lib.SM3Error('MultiTensorAdamW: a parameter that had a gradient when the tables were built has '
+                                'none now')
+        addr = [p.grad.data_ptr() for _, p in self._params]
+        if addr != self._g_addr:
+            self._g_ptrs.copy_(torch.tensor(addr, dtype=torch.int64))
+            self._g_addr = addr
+
     def update_hyperparams(self, force=False):
         """Push the groups' lr / weight_decay to the device vectors (call before replaying a captured graph whenever a
         scheduler changed them; ``step()`` does it itself when not capturing)."""
@@ -90,9 +104,7 @@ class MultiTensorAdamW(torch.optim.Optimizer):
         if not self._built:
             self._build()
         elif not torch.cuda.is_current_stream_capturing():
-            if any(p.grad is None or p.grad.data_ptr() != a for (_, p), a in zip(self._params, self._g_addr)):
-                self._g_ptrs.copy_(torch.tensor([p.grad.data_ptr() for _, p in self._params], dtype=torch.int64))
-                self._g_addr = [p.grad.data_ptr() for _, p in self._params]
+            self.refresh_grad_pointers()
             self.update_hyperparams()
         g0 = self.param_groups[0]
         b1, b2 = g0['betas']

@@ -96,5 +96,8 @@ def test_single_process_reducer_is_a_noop_mean():
     red.zero_grad()
     m(torch.randn(3, 16)).sum().backward()
     red.finalize()
-    assert m.body[0].weight.grad.data_ptr() >= red.buckets[0]['flat'].data_ptr()
+    assert red.buckets[0]['flat'] is None  # world 1: no flat buffers, autograd's own gradient tensors are kept
     assert float(m.body[0].weight.grad.abs().sum()) > 0
+    assert m.unused.weight.grad is None
+    red.zero_grad()
+    assert all(p.grad is None for p in m.parameters())
