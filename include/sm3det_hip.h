@@ -167,11 +167,11 @@ int sm3_layernorm_bwd(const float* dy, const float* x, const float* w, const flo
 
 /* ---------------------------------------------------------------------------------------------------------
  * Depthwise 7x7, padding 3 (ConvNeXtBlock.depthwise_conv, convnext_moe.py:311-312,347) on NHWC tokens.
- * w49 (49,C) = weight (C,1,7,7) permuted to tap-major; y = conv(x) + bias (+ addend).  The input gradient is the
- * same kernel with the taps reversed (w49 flipped along dim 0) and addend = the residual branch gradient.
- * bwd_weight: dw49 (49,C) and dbias (C) overwritten. */
+ * w49 (49,C) = weight (C,1,7,7) permuted to tap-major; y = conv(x) + bias (+ addend).  flip != 0 reads the taps
+ * reversed (w49[48 - t]): the input gradient is this kernel with flip = 1 and addend = the residual branch gradient.
+ * bwd_weight: dw49 (49,C) and dbias (C) overwritten (one fill when dbias == dw49 + 49*C, i.e. a (50,C) buffer). */
 int sm3_dwconv7_fwd(const float* x, const float* w49, const float* bias, const float* addend, float* y, int B, int H,
-                    int W, int C, sm3_stream_t stream);
+                    int W, int C, int flip, sm3_stream_t stream);
 int sm3_dwconv7_bwd_weight(const float* x, const float* du, float* dw49, float* dbias, int B, int H, int W, int C,
                            sm3_stream_t stream);
 

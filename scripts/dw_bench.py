@@ -14,8 +14,8 @@ for (B, H, C) in [(2, 256, 96), (2, 128, 192), (2, 64, 384), (2, 32, 768)]:
     x = torch.randn(T, C, device='cuda'); w49 = torch.randn(49, C, device='cuda'); b = torch.randn(C, device='cuda')
     y = torch.empty_like(x); du = torch.randn_like(x); dw = torch.empty(49, C, device='cuda'); db = torch.empty(C, device='cuda')
     lw = torch.ones(C, device='cuda'); mean = torch.empty(T, device='cuda'); rstd = torch.empty(T, device='cuda')
-    f = t(lambda: LB.call('dwconv7_fwd', x, w49, b, None, y, B, H, W, C))
-    fa = t(lambda: LB.call('dwconv7_fwd', x, w49, None, du, y, B, H, W, C))
+    f = t(lambda: LB.call('dwconv7_fwd', x, w49, b, None, y, B, H, W, C, 0))
+    fa = t(lambda: LB.call('dwconv7_fwd', x, w49, None, du, y, B, H, W, C, 1))
     bw = t(lambda: LB.call('dwconv7_bwd_weight', x, du, dw, db, B, H, W, C))
     ln = t(lambda: LB.call('layernorm_fwd', x, lw, b, 1e-6, y, mean, rstd, T, C, 0, H, W))
     mb = T * C * 4 / 1e6

@@ -36,7 +36,7 @@ def signatures():
         'sm3_layernorm_fwd': (I, [P, P, P, F, P, P, P, LL, I, I, I, I, P]),
         'sm3_row_reduce_workspace_bytes': (S, [I]),
         'sm3_layernorm_bwd': (I, [P, P, P, P, P, P, P, LL, I, I, I, I, I, P, S, P]),
-        'sm3_dwconv7_fwd': (I, [P, P, P, P, P, I, I, I, I, P]),
+        'sm3_dwconv7_fwd': (I, [P, P, P, P, P, I, I, I, I, I, P]),
         'sm3_dwconv7_bwd_weight': (I, [P, P, P, P, I, I, I, I, P]),
         'sm3_scale_bwd_prep': (I, [P, P, P, P, I, P, P, LL, I, P, S, P]),
         'sm3_moe_router_partial_rows': (I, [I]),

@@ -119,7 +119,7 @@ def layer_norm(x, w, b, eps, patch_major=False, H=0, W=0):
 def _dw_ln_forward(x, w49, bdw, lnw, lnb, eps, B, H, W, C):
     T = B * H * W
     u = _e(T, C, like=x)
-    call('dwconv7_fwd', x, w49, bdw, None, u, B, H, W, C)
+    call('dwconv7_fwd', x, w49, bdw, None, u, B, H, W, C, 0)
     xn = _e(T, C, like=x)
     mean, rstd = _e(T, like=x), _e(T, like=x)
     call('layernorm_fwd', u, lnw, lnb, float(eps), xn, mean, rstd, T, C, 0, H, W)
@@ -135,8 +135,9 @@ def _dw_ln_backward(dxn, dout, x, u, w49, lnw, mean, rstd, B, H, W, C):
     ws, nb = LB.row_ws(C, x)
     call('layernorm_bwd', dxn, u, lnw, mean, rstd, du, dwdb, T, C, 0, H, W, 0, ws, nb)
     dx = _e(T, C, like=x)
-    call('dwconv7_fwd', du, w49.flip(0).contiguous(), None, dout, dx, B, H, W, C)
-    dw49, dbdw = _e(49, C, like=x), _e(C, like=x)
+    call('dwconv7_fwd', du, w49, None, dout, dx, B, H, W, C, 1)  # flip=1: correlation with the reversed taps
+    dwb = _e(50, C, like=x)  # [dw49 (49,C); dbias (C)] in one buffer: one fill inside the kernel wrapper
+    dw49, dbdw = dwb[:49], dwb[49]
     call('dwconv7_bwd_weight', x, du, dw49, dbdw, B, H, W, C)
     return dx, dw49, dbdw, dwdb[0], dwdb[1]
 

@@ -179,6 +179,45 @@ class MoE_layer(nn.Module):
         return wcat.contiguous(), bcat, snorm, scale, P
 
 
+class DepthwiseConv7x7(nn.Module):
+    """Parameter holder of ``nn.Conv2d(C, C, kernel_size=7, padding=3, groups=C)`` (reference :311-312).
+
+    The weight lives TAP-MAJOR, ``(49, C)`` -- the layout the gfx950 kernels read (one 16-byte load = one tap of four
+    channels) -- so no per-step transpose / flip launches are needed; ``state_dict`` shows and accepts it under the
+    reference key and shape ``weight (C, 1, 7, 7)``."""
+
+    def __init__(self, channels, kernel_size=7, padding=3):
+        super().__init__()
+        if kernel_size != 7 or padding != 3:
+            raise NotImplementedError('only the 7x7 / padding 3 depthwise conv is implemented')
+        ref = nn.Conv2d(channels, channels, kernel_size=7, padding=3, groups=channels)  # same init / RNG consumption
+        self.in_channels = self.out_channels = self.groups = channels
+        self.kernel_size, self.padding, self.stride = (7, 7), (3, 3), (1, 1)
+        self.weight = nn.Parameter(ref.weight.data.view(channels, 49).t().contiguous())
+        self.bias = nn.Parameter(ref.bias.data.clone())
+
+    @property
+    def weight_oihw(self):
+        """the reference layout (C, 1, 7, 7) (a copy)"""
+        return self.weight.t().reshape(self.in_channels, 1, 7, 7)
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+        w = destination[prefix + 'weight']
+        destination[prefix + 'weight'] = w.t().reshape(self.in_channels, 1, 7, 7)
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                              error_msgs):
+        k = prefix + 'weight'
+        if k in state_dict and state_dict[k].dim() == 4:
+            state_dict[k] = state_dict[k].reshape(self.in_channels, 49).t().contiguous()
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                                      error_msgs)
+
+    def forward(self, x):
+        raise RuntimeError('DepthwiseConv7x7 is executed inside ConvNeXtBlock.forward_tokens (fused dwconv + LN)')
+
+
 class ConvNeXtBlock(nn.Module):
     """ConvNeXt block (reference :295-379): dw7x7 -> LN -> FFN | MoE -> layer scale -> drop path -> residual."""
 
@@ -194,7 +233,8 @@ class ConvNeXtBlock(nn.Module):
             raise NotImplementedError('layer_scale_init_value must be > 0')
         self.with_cp = with_cp  # accepted for API parity; activations fit easily in 288 GB, never checkpointed
         self.in_channels = in_channels
-        self.depthwise_conv = nn.Conv2d(in_channels, in_channels, groups=in_channels, **dw_conv_cfg)
+        self.depthwise_conv = DepthwiseConv7x7(in_channels, dw_conv_cfg.get('kernel_size', 7),
+                                               dw_conv_cfg.get('padding', 3))
         self.linear_pw_conv = linear_pw_conv
         self.norm = build_LayerNorm2d_layer(norm_cfg, in_channels)
         mid_channels = int(mlp_ratio * in_channels)
@@ -226,7 +266,7 @@ class ConvNeXtBlock(nn.Module):
     def forward_tokens(self, x, B, H, W, noise=None, drop_scale=None):
         """x (B*H*W, C) -> (out tokens, gate loss or None).  noise / drop_scale: injected randomness (tests)."""
         C = self.in_channels
-        w49 = self.depthwise_conv.weight.view(C, 49).t().contiguous()
+        w49 = self.depthwise_conv.weight  # tap-major (49, C)
         rs = self._rowscale(B, x.device) if drop_scale is None else drop_scale.to(x.device, torch.float32)
         if self.MoE_cfg is None:
             f = self.ffn
@@ -354,6 +394,10 @@ class ConvNeXt_moe(nn.Module):
         tok = ops.linear(a, w64, conv.bias)
         H, W = Hi // 4, Wi // 4
         outs, gate_losses = [], []
+        if self.training and (noise is None or drop_scale is None):
+            gen_noise, gen_drop = self._step_randomness(B, H, W, x.device)
+            noise = gen_noise if noise is None else noise
+            drop_scale = gen_drop if drop_scale is None else drop_scale
         noise_iter = iter(noise) if noise is not None else None
         drop_iter = iter(drop_scale) if drop_scale is not None else None
         for i, stage in enumerate(self.stages):
@@ -384,6 +428,41 @@ class ConvNeXt_moe(nn.Module):
         if len(gate_losses) > 0:
             return tuple(outs), torch.stack(gate_losses).mean()  # == sum(losses) / len(losses), two launches
         return tuple(outs)
+
+    def _step_randomness(self, B, H0, W0, device):
+        """All of one training step's randomness in a handful of launches instead of three per block: the gating
+        noise ``randn_like(clean_logits)`` (reference :203) of every noisy MoE block as views of ONE normal draw, and the
+        per-sample DropPath scales (timm ``drop_path``: Bernoulli(keep)/keep) of every block from ONE uniform draw."""
+        sizes, rates = [], []
+        H, W = H0, W0
+        for i, stage in enumerate(self.stages):
+            if i > 0:
+                H, W = H // 2, W // 2
+            for blk in stage:
+                rates.append(blk.drop_path_rate if blk.training else 0.0)
+                if blk.MoE_cfg is not None:
+                    moe = blk.ffn
+                    sizes.append((B * H * W, moe.num_experts) if (moe.training and moe.noisy_gating) else None)
+        noise = None
+        if any(sz is not None for sz in sizes):
+            flat = torch.randn(sum(t * e for t, e in filter(None, sizes)), device=device)
+            noise, off = [], 0
+            for sz in sizes:
+                if sz is None:
+                    noise.append(None)
+                else:
+                    noise.append(flat[off:off + sz[0] * sz[1]].view(sz))
+                    off += sz[0] * sz[1]
+        drop = None
+        if any(r > 0 for r in rates):
+            key = (str(device), tuple(rates))
+            if getattr(self, '_keep_cache', (None, None))[0] != key:  # built once (outside any graph capture)
+                keep = torch.tensor([1.0 - r for r in rates], dtype=torch.float32).to(device)
+                self._keep_cache = (key, keep.view(-1, 1), keep.clamp_min(1e-30).reciprocal().view(-1, 1))
+            _, keep, inv = self._keep_cache
+            scales = (torch.rand(len(rates), B, device=device) < keep).float() * inv
+            drop = [scales[j] if rates[j] > 0 else None for j in range(len(rates))]
+        return noise, drop
 
     def forward(self, x):
         return self._forward_impl(x)

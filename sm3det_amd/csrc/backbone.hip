@@ -230,7 +230,7 @@ constexpr int DW_RY = 2, DW_RX = 8;
 __global__ __launch_bounds__(256) void dwconv7_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w49,
                                                          const float* __restrict__ bias,
                                                          const float* __restrict__ addend, float* __restrict__ y,
-                                                         int B, int H, int W, int C, int spb) {
+                                                         int B, int H, int W, int C, int spb, int flip) {
   const int nq = C >> 2;
   const int cq = threadIdx.x % nq;
   const int sl = threadIdx.x / nq;
@@ -267,7 +267,8 @@ __global__ __launch_bounds__(256) void dwconv7_fwd_kernel(const float* __restric
       if (ky < 0 || ky > 6) continue;
 #pragma unroll
       for (int kx = 0; kx < 7; kx++) {
-        const f32x4 wv = ld4(w49 + (long)(ky * 7 + kx) * C + 4 * cq);
+        const int t = flip ? 48 - (ky * 7 + kx) : ky * 7 + kx;  // flip: correlation with the reversed taps (dgrad)
+        const f32x4 wv = ld4(w49 + (long)t * C + 4 * cq);
 #pragma unroll
         for (int c = 0; c < DW_RX; c++) acc[r][c] += in[c + kx] * wv;
       }
@@ -597,7 +598,7 @@ inline int ew_blocks(long work, int threads = 256) {
 // LDS-tiled depthwise kernels (dwconv_lds.hip)
 bool sm3_dwconv7_lds_supported(int H, int W, int C);
 void sm3_dwconv7_lds_fwd(const float* x, const float* w49, const float* bias, const float* addend, float* y, int B,
-                         int H, int W, int C, hipStream_t st);
+                         int H, int W, int C, int flip, hipStream_t st);
 void sm3_dwconv7_lds_bwd_weight(const float* x, const float* du, float* dw49, float* dbias, int B, int H, int W, int C,
                                 hipStream_t st);
 
@@ -645,17 +646,17 @@ int sm3_layernorm_bwd(const float* dy, const float* x, const float* w, const flo
 }
 
 int sm3_dwconv7_fwd(const float* x, const float* w49, const float* bias, const float* addend, float* y, int B, int H,
-                    int W, int C, sm3_stream_t stream) {
+                    int W, int C, int flip, sm3_stream_t stream) {
   if (!x || !w49 || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || C > 1024) return SM3_ERR_INVALID_ARG;
   if (sm3_dwconv7_lds_supported(H, W, C)) {
-    sm3_dwconv7_lds_fwd(x, w49, bias, addend, y, B, H, W, C, (hipStream_t)stream);
+    sm3_dwconv7_lds_fwd(x, w49, bias, addend, y, B, H, W, C, flip, (hipStream_t)stream);
     return launch_status();
   }
   const int nq = C / 4;
   const int spb = 256 / nq > 0 ? 256 / nq : 1;
   const long nstrips = (long)B * ((H + DW_RY - 1) / DW_RY) * ((W + DW_RX - 1) / DW_RX);
   const int blocks = (int)((nstrips + spb - 1) / spb);
-  dwconv7_fwd_kernel<<<blocks, nq * spb, 0, (hipStream_t)stream>>>(x, w49, bias, addend, y, B, H, W, C, spb);
+  dwconv7_fwd_kernel<<<blocks, nq * spb, 0, (hipStream_t)stream>>>(x, w49, bias, addend, y, B, H, W, C, spb, flip);
   return launch_status();
 }
 
@@ -664,8 +665,12 @@ int sm3_dwconv7_bwd_weight(const float* x, const float* du, float* dw49, float* 
   if (!x || !du || !dw49 || !dbias || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || C > 1024)
     return SM3_ERR_INVALID_ARG;
   hipStream_t st = (hipStream_t)stream;
-  (void)hipMemsetAsync(dw49, 0, sizeof(float) * 49 * C, st);
-  (void)hipMemsetAsync(dbias, 0, sizeof(float) * C, st);
+  if (dbias == dw49 + (size_t)49 * C) {  // one (50, C) buffer [dw49; dbias]: one fill
+    (void)hipMemsetAsync(dw49, 0, sizeof(float) * 50 * C, st);
+  } else {
+    (void)hipMemsetAsync(dw49, 0, sizeof(float) * 49 * C, st);
+    (void)hipMemsetAsync(dbias, 0, sizeof(float) * C, st);
+  }
   if (sm3_dwconv7_lds_supported(H, W, C)) {
     sm3_dwconv7_lds_bwd_weight(x, du, dw49, dbias, B, H, W, C, st);
     return launch_status();

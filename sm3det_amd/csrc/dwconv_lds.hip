@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void dwconv7_lds_fwd_kernel(const float* __res
                                                              const float* __restrict__ w49,
                                                              const float* __restrict__ bias,
                                                              const float* __restrict__ addend, float* __restrict__ y,
-                                                             int H, int W, int C) {
+                                                             int H, int W, int C, int flip) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* patch = sm;
   const int tiles_x = W / TW;
@@ -53,6 +53,8 @@ __global__ __launch_bounds__(256) void dwconv7_lds_fwd_kernel(const float* __res
   const int y0 = ty * TH, x0 = tx * TW;
   load_patch<PH>(x, b, H, W, C, y0, x0, c0, patch);
   __syncthreads();
+  // flip: tap (ky,kx) reads w49[48 - (ky*7+kx)] (correlation with the reversed kernel = input gradient)
+  const int tb = flip ? 48 : 0, ts = flip ? -1 : 1;
   const float* taps = w49 + c0;  // 49 x 16 B per lane straight from L1/L2 (every workgroup of a chunk reads the same 6 KB)
   const int cq = threadIdx.x & 7, xg = (threadIdx.x >> 3) & 3, rp = threadIdx.x >> 5;  // 8 quads x 4 x-groups x 8 row pairs
   const int ry = 2 * rp, rx = 4 * xg;
@@ -68,14 +70,14 @@ __global__ __launch_bounds__(256) void dwconv7_lds_fwd_kernel(const float* __res
   f32x4 wprev[7], wcur[7], wnext[7];
 #pragma unroll
   for (int kx = 0; kx < 7; kx++) {
-    wcur[kx] = ld4(taps + (long)kx * C + 4 * cq);
+    wcur[kx] = ld4(taps + (long)(tb + ts * kx) * C + 4 * cq);
     wprev[kx] = wcur[kx];
   }
 #pragma unroll 1
   for (int ir = 0; ir < 8; ir++) {
     const int kn = ir + 1 < 7 ? ir + 1 : 6;  // clamped: branch-free prefetch
 #pragma unroll
-    for (int kx = 0; kx < 7; kx++) wnext[kx] = ld4(taps + (long)(kn * 7 + kx) * C + 4 * cq);
+    for (int kx = 0; kx < 7; kx++) wnext[kx] = ld4(taps + (long)(tb + ts * (kn * 7 + kx)) * C + 4 * cq);
     f32x4 in[10];
     const float* prow = patch + ((ry + ir) * PW + rx) * PS + 4 * cq;
 #pragma unroll
@@ -185,10 +187,10 @@ __global__ __launch_bounds__(256) void dwconv7_lds_bwd_weight_kernel(const float
 bool sm3_dwconv7_lds_supported(int H, int W, int C) { return (C % CB) == 0 && (H % TH) == 0 && (W % TW) == 0; }
 
 void sm3_dwconv7_lds_fwd(const float* x, const float* w49, const float* bias, const float* addend, float* y, int B,
-                         int H, int W, int C, hipStream_t st) {
+                         int H, int W, int C, int flip, hipStream_t st) {
   dim3 grid((W / TW) * (H / TH), C / CB, B);
   const size_t lds = (size_t)LDS_PATCH * sizeof(float);
-  dwconv7_lds_fwd_kernel<<<grid, 256, lds, st>>>(x, w49, bias, addend, y, H, W, C);
+  dwconv7_lds_fwd_kernel<<<grid, 256, lds, st>>>(x, w49, bias, addend, y, H, W, C, flip);
 }
 
 void sm3_dwconv7_lds_bwd_weight(const float* x, const float* du, float* dw49, float* dbias, int B, int H, int W, int C,

@@ -37,6 +37,8 @@ def _ref_key_grads(net):
                    'b2': 'pointwise_conv2.bias'}[leaf]
             for e in range(p.shape[0]):
                 out[f'{n[:-len(leaf)]}experts.{e}.{ref}'] = p.grad[e]
+        elif n.endswith('depthwise_conv.weight') and p.dim() == 2:  # tap-major (49, C) -> (C, 1, 7, 7)
+            out[n] = p.grad.t().reshape(p.shape[1], 1, 7, 7)
         else:
             out[n] = p.grad
     return out
@@ -258,7 +260,7 @@ def test_dwconv7_fwd_and_grads(B, H, W, C):
     b = torch.randn(C, device='cuda')
     w49 = w.view(C, 49).t().contiguous()
     y = torch.empty_like(x)
-    LB.call('dwconv7_fwd', x, w49, b, None, y, B, H, W, C)
+    LB.call('dwconv7_fwd', x, w49, b, None, y, B, H, W, C, 0)
     xr = x.double().permute(0, 3, 1, 2).requires_grad_(True)
     wr, br = w.double().requires_grad_(True), b.double().requires_grad_(True)
     yr = F.conv2d(xr, wr, br, padding=3, groups=C)
@@ -267,7 +269,7 @@ def test_dwconv7_fwd_and_grads(B, H, W, C):
     yr.backward(go.double().permute(0, 3, 1, 2))
     res = torch.randn_like(x)
     dx = torch.empty_like(x)
-    LB.call('dwconv7_fwd', go, w49.flip(0).contiguous(), None, res, dx, B, H, W, C)
+    LB.call('dwconv7_fwd', go, w49, None, res, dx, B, H, W, C, 1)
     assert rel_err(dx, xr.grad.permute(0, 2, 3, 1) + res.double()) < 1e-5
     dw49, db = torch.empty(49, C, device='cuda'), torch.empty(C, device='cuda')
     LB.call('dwconv7_bwd_weight', x, go, dw49, db, B, H, W, C)
