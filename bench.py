@@ -30,7 +30,8 @@ sys.path.insert(0, ROOT)
 MI355X_FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
 BACKBONE_CFG = dict(arch='tiny', MoE_Block_inds=[[], [0, 2], [0, 2, 4, 6, 8], [0, 2]], num_experts=8, top_k=2,
                     drop_path_rate=0.1)  # local_configs/main_SM3Det.py:13-21
-BATCH, RES = 2, 1024
+BATCH = 2
+RES = int(os.environ.get('SM3_BENCH_RES', '1024'))  # 1024 = BASELINE config; the override is a debugging aid only
 
 
 def build_model():
@@ -139,12 +140,21 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}')
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    # SM3_BENCH_BACKEND=gloo lets two ranks share ONE GPU (the 1-GPU dev box) to exercise the N>1 control flow --
+    # graph A + bucket pack, eager all-reduce, graph B on the reduced buckets -- without RCCL; never used for numbers.
+    backend = os.environ.get('SM3_BENCH_BACKEND', 'nccl')
+    if os.environ.get('SM3_BENCH_WATCHDOG'):  # debugging aid: dump all Python stacks and exit after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ['SM3_BENCH_WATCHDOG']), exit=True)
+    local_rank = local_rank % torch.cuda.device_count() if backend != 'nccl' else local_rank
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world,
-                                device_id=torch.device('cuda', local_rank))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from sm3det_amd import _lib, _lib_backbone as LB
     from sm3det_amd.data_parallel import BucketedGradReducer
@@ -240,14 +250,24 @@ def main():
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
     value = world * BATCH * args.steps / dt
+    # replicas must stay bit-identical (same averaged gradients on every rank): spread of a parameter checksum
+    replica_spread = 0.0
+    if world > 1:
+        chk = torch.stack([p.detach().double().sum() for p in params]).sum().reshape(1)
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        replica_spread = float((hi - lo).item())
 
     # ---- roofline of the dominant kernel: one more identical step with HIP events around every launch ---------
     roofline = None
     kernels = {}
+    # every rank runs the step (it contains the bucket all-reduces); only rank 0 records the per-launch events
     if rank == 0:
         LB.PROFILE = []
-        step()
-        torch.cuda.synchronize()
+    step()
+    torch.cuda.synchronize()
+    if rank == 0:
         prof, LB.PROFILE = LB.PROFILE, None
         for name, flops, nbytes, e0, e1 in prof:
             k = kernels.setdefault(name, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
@@ -289,7 +309,8 @@ def main():
                                    'dense blocks) fwd+bwd + bucketed grad all-reduce + grad-clip(35)+AdamW (per-parameter lr); synthetic '
                                    f'randn({BATCH},3,{RES},{RES}) per GPU, random-init weights; FPN/heads excluded',
                        'global_batch': world * BATCH, 'resolution': RES, 'parallelism': f'dp{world}',
-                       'grad_buckets': reducer.num_buckets, 'hip_graph': bool(use_graph)},
+                       'grad_buckets': reducer.num_buckets, 'hip_graph': bool(use_graph),
+                       'replica_checksum_spread': replica_spread},
             'loss': float(loss.detach()),
             'roofline': roofline,
             'kernels_ms_per_step': {n: round(v['ms'], 3) for n, v in sorted(kernels.items(), key=lambda kv: -kv[1]['ms'])},
