@@ -220,21 +220,30 @@ def main():
                 step()
         torch.cuda.current_stream().wait_stream(side)
         fence()
-        g_fb, g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g_fb):
-            graph_loss = fwd_bwd()
-        keep_alive = [p.grad for p in params]  # the tensors graph A writes the gradients to  # noqa: F841
-        g_fb.replay()
-        reducer.finalize(repack=False)  # N>1: p.grad -> slices of the reduced buckets
-        opt.refresh_grad_pointers()
-        with torch.cuda.graph(g_opt, pool=g_fb.pool()):
-            opt.step()
-
-        def run():
+        # N>1: RCCL's watchdog thread may touch the HIP runtime while this thread captures -> thread-local capture mode
+        cap_kw = dict(capture_error_mode='thread_local') if world > 1 else {}
+        try:
+            g_fb, g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_fb, **cap_kw):
+                graph_loss = fwd_bwd()
+            keep_alive = [p.grad for p in params]  # the tensors graph A writes the gradients to  # noqa: F841
             g_fb.replay()
-            reducer.finalize(repack=False)  # world 1: no-op; world > 1: bucketed all-reduce + mean
-            g_opt.replay()
-            return graph_loss
+            reducer.finalize(repack=False)  # N>1: p.grad -> slices of the reduced buckets
+            opt.refresh_grad_pointers()
+            with torch.cuda.graph(g_opt, pool=g_fb.pool(), **cap_kw):
+                opt.step()
+
+            def run():
+                g_fb.replay()
+                reducer.finalize(repack=False)  # world 1: no-op; world > 1: bucketed all-reduce + mean
+                g_opt.replay()
+                return graph_loss
+        except Exception as e:  # keep the measurement alive: eager launches, all-reduces overlapped with backward
+            print(f'[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly', file=sys.stderr)
+            use_graph = False
+            reducer.overlap = True
+            torch.cuda.synchronize()
+            run = step
 
     for _ in range(args.warmup):
         run()

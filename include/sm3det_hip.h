@@ -148,6 +148,26 @@ int sm3_colsum_f32(const float* x, int ld, int m, int n, const int32_t* group_of
                    sm3_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * FPN: MultitaskFPN.forward, mmrotate/models/necks/Multitask_FPN.py:113-162, on NHWC tokens.
+ * 3x3 convolution, padding 1, stride 1 or 2 (ConvModule(out, out, 3, padding=1) :75-83 and the stride-2 extra levels
+ * :97-106; conv/norm/act cfg None -> nn.Conv2d + bias) as implicit GEMMs -- no im2col buffer.  x (B,H,W,Cin),
+ * w (Cout,3,3,Cin) [= Conv2d.weight.permute(0,2,3,1)], y (B,Ho,Wo,Cout), Ho = (H-1)/stride + 1.
+ * fwd needs Cin % 32 == 0, bwd_input Cout % 32 == 0, bwd_weight Cin % 128 == 0; channel counts multiples of 4. */
+int sm3_conv3x3_nhwc_fwd(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cin,
+                         int Cout, int stride, sm3_stream_t stream);
+int sm3_conv3x3_nhwc_bwd_input(const float* dy, const float* w, float* dx, int B, int H, int W, int Cin, int Cout,
+                               int stride, sm3_stream_t stream);
+size_t sm3_conv3x3_nhwc_bwd_weight_workspace_bytes(int B, int H, int W, int Cin, int Cout, int stride);
+int sm3_conv3x3_nhwc_bwd_weight(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout,
+                                int stride, void* workspace, size_t workspace_bytes, sm3_stream_t stream);
+/* top-down merge (:123-135): out = fine + nearest_upsample_2x(coarse); fine/out (B,H,W,C), coarse (B,H/2,W/2,C).
+ * gradient: dcoarse = base (may be NULL) + 2x2 sum-pool of dfine; dfine (B,2Hc,2Wc,C). */
+int sm3_upsample2x_add(const float* fine, const float* coarse, float* out, int B, int H, int W, int C,
+                       sm3_stream_t stream);
+int sm3_sumpool2x_add(const float* dfine, const float* base, float* dcoarse, int B, int Hc, int Wc, int C,
+                      sm3_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * Stem: Conv2d(3,C0,k=4,s=4) (convnext_moe.py:783-791) as patchify + NT GEMM.  x (B,3,H,W) NCHW ->
  * a (B*H/4*W/4, 64), columns c*16+kh*4+kw (= weight.view(C0,48) order), columns 48..63 zero. */
 int sm3_stem_patchify(const float* x, float* a, int B, int H, int W, sm3_stream_t stream);

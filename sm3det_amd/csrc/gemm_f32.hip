@@ -20,6 +20,7 @@
 // register-prefetched double-buffered LDS (one barrier per k-step), XCD-aware block remap so the N-tiles that
 // share an A row-panel land on one XCD's L2.
 #include <stdlib.h>
+#include <string.h>
 
 #include "common.h"
 
@@ -59,7 +60,28 @@ struct GemmParams {
   const float* rowscale;  // [M / rows_per_scale] (stochastic-depth keep/keep_prob per image) or NULL
   int rows_per_scale;
   int ld_aux;
+  // GATHER (implicit-GEMM 3x3 convolution over NHWC tokens, padding 1): the gathered operand has `cC` channels per tap,
+  // its rows live on an (sH, sW) grid per image; the GEMM's own rows (NT/NN: A/C rows, TN: reduction rows) live on an
+  // (rH, rW) grid.  cT = 0: source = row * cS + d - 1 (forward / weight gradient);  cT = 1: source = (row - d + 1) / cS
+  // where divisible (input gradient = transposed convolution).  cInv: (kt * cInv) >> 16 == kt / (cC / BK).
+  int cC, sH, sW, rH, rW, cS, cT;
+  unsigned cInv, mRW, mRH;  // mRW/mRH: ceil(2^32 / rW), ceil(2^32 / rH) for exact umulhi division of row indices
 };
+
+// exact n / d for n * d < 2^32 with m = floor(2^32 / d) + 1 (d >= 2); d == 1 passes through
+__device__ __forceinline__ unsigned fast_div(unsigned n, unsigned d, unsigned m) { return d == 1 ? n : __umulhi(n, m); }
+
+// source coordinate of one axis for tap offset dd in {0,1,2}; returns -1 when the tap falls outside / between pixels
+__device__ __forceinline__ int gather_coord(int r, int dd, int stride, int transposed, int lim) {
+  if (!transposed) {
+    const int v = r * stride + dd - 1;
+    return (v >= 0 && v < lim) ? v : -1;
+  }
+  const int t = r - dd + 1;  // stride is 1 or 2 (checked on the host)
+  const int q = stride == 2 ? (t >> 1) : t;
+  const bool ok = t >= 0 && (stride == 1 || (t & 1) == 0) && q < lim;
+  return ok ? q : -1;
+}
 
 // GELU(erf) and its derivative share one exponential: y = h*Phi(h), y' = Phi(h) + h*phi(h).  The forward epilogue stores
 // y' so the backward epilogue is a single multiply (no transcendental on the dgrad critical path).
@@ -84,7 +106,7 @@ __device__ __forceinline__ void gelu_erf_both(float h, float& y, float& dy) {
 // EPI codes (must match include/sm3det_hip.h)
 constexpr int EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_BIAS_SCALE_RES = 3, EPI_GELU_BWD = 4;
 
-template <int MODE, int EPI, int BK>
+template <int MODE, int EPI, int BK, int GATHER = 0>
 __global__ __launch_bounds__(NTHREADS, (BK == 32 ? 2 : 4)) void gemm_f32_kernel(GemmParams p) {
   constexpr int LD_T = LdT<BK>::v;
   constexpr int NLD = BK / 8;  // global->LDS passes per operand tile
@@ -179,15 +201,31 @@ __global__ __launch_bounds__(NTHREADS, (BK == 32 ? 2 : 4)) void gemm_f32_kernel(
   // where zeros are required -- reduction rows past the segment end in TN -- uses a select after the load.
   const float* pa[NLD];
   const float* pb[NLD];
+  int gy[NLD], gx[NLD];  // GATHER (NT/NN): grid coordinates of this thread's A rows
+  int tn_tap = 0;        // GATHER (TN): the tap this N-tile belongs to (cC % BN == 0)
 #pragma unroll
   for (int i = 0; i < NLD; i++) {
+    gy[i] = gx[i] = 0;
     if (MODE == MODE_TN) {
       const int mc = min(m0 + 4 * d_nq, p.M - 4), nc = min(n0 + 4 * d_nq, p.N - 4);
       pa[i] = Ag + mc;
-      pb[i] = Bg + nc;
+      if (GATHER) {
+        tn_tap = n0 / p.cC;
+        pb[i] = Bg + (nc - tn_tap * p.cC);  // channel offset inside the tap; the row part is added per load
+      } else {
+        pb[i] = Bg + nc;
+      }
     } else {
       const int r = min(row0 + t_r + T_ROWS * i, row_end - 1);
-      pa[i] = Ag + (long)r * p.lda + 4 * t_kq;
+      if (GATHER) {
+        const unsigned t = fast_div((unsigned)r, (unsigned)p.rW, p.mRW);
+        gx[i] = r - (int)t * p.rW;
+        const unsigned b = fast_div(t, (unsigned)p.rH, p.mRH);
+        gy[i] = (int)t - (int)b * p.rH;
+        pa[i] = Ag + (long)b * p.sH * p.sW * p.cC + 4 * t_kq;
+      } else {
+        pa[i] = Ag + (long)r * p.lda + 4 * t_kq;
+      }
       if (MODE == MODE_NT) {
         const int n = min(n0 + t_r + T_ROWS * i, p.N - 1);
         pb[i] = Bg + (long)n * p.ldb + 4 * t_kq;
@@ -199,21 +237,49 @@ __global__ __launch_bounds__(NTHREADS, (BK == 32 ? 2 : 4)) void gemm_f32_kernel(
   }
   // piece q in [0, 2*NLD): q < NLD -> A piece q, else B piece q - NLD
   auto load_piece = [&](f32x4 (&ra)[NLD], f32x4 (&rb)[NLD], int q, int kt) {
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     if (MODE == MODE_TN) {
       const int i = q < NLD ? q : q - NLD;
       const int kr = row0 + kt * BK + d_kk + 8 * i;
       const int krc = min(kr, row_end - 1);
       if (q < NLD) {
         f32x4 v = *reinterpret_cast<const f32x4*>(pa[i] + (long)krc * p.lda);
-        ra[i] = kr < row_end ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+        ra[i] = kr < row_end ? v : zero4;
+      } else if (GATHER) {
+        // reduction row = output position (b, oy, ox); B row = the input pixel this N-tile's tap reads for it
+        const unsigned t = fast_div((unsigned)krc, (unsigned)p.rW, p.mRW);
+        const int ox = krc - (int)t * p.rW;
+        const unsigned b = fast_div(t, (unsigned)p.rH, p.mRH);
+        const int oy = (int)t - (int)b * p.rH;
+        const int sy = gather_coord(oy, tn_tap / 3, p.cS, p.cT, p.sH);
+        const int sx = gather_coord(ox, tn_tap % 3, p.cS, p.cT, p.sW);
+        const bool ok = kr < row_end && sy >= 0 && sx >= 0;
+        const long off = (((long)b * p.sH + max(sy, 0)) * p.sW + max(sx, 0)) * p.cC;
+        f32x4 v = *reinterpret_cast<const f32x4*>(pb[i] + off);
+        rb[i] = ok ? v : zero4;
       } else {
         f32x4 v = *reinterpret_cast<const f32x4*>(pb[i] + (long)krc * p.ldb);
-        rb[i] = kr < row_end ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+        rb[i] = kr < row_end ? v : zero4;
       }
     } else if (q < NLD) {
-      ra[q] = *reinterpret_cast<const f32x4*>(pa[q] + kt * BK);
+      if (GATHER) {
+        const int tap = (int)(((unsigned)kt * p.cInv) >> 16);  // k-tile -> tap (uniform), channel offset inside it
+        const int c0 = kt * BK - tap * p.cC;
+        const int sy = gather_coord(gy[q], tap / 3, p.cS, p.cT, p.sH);
+        const int sx = gather_coord(gx[q], tap % 3, p.cS, p.cT, p.sW);
+        const long off = ((long)max(sy, 0) * p.sW + max(sx, 0)) * p.cC + c0;
+        f32x4 v = *reinterpret_cast<const f32x4*>(pa[q] + off);
+        ra[q] = (sy >= 0 && sx >= 0) ? v : zero4;
+      } else {
+        ra[q] = *reinterpret_cast<const f32x4*>(pa[q] + kt * BK);
+      }
     } else if (MODE == MODE_NT) {
       rb[q - NLD] = *reinterpret_cast<const f32x4*>(pb[q - NLD] + kt * BK);
+    } else if (GATHER) {
+      // NN gather (input gradient): B row k = (tap, co) lives at W[co][tap][:]  (ldb = 9 * Cin, + tap * N columns)
+      const int tap = (int)(((unsigned)kt * p.cInv) >> 16);
+      const int c0 = kt * BK - tap * p.cC;
+      rb[q - NLD] = *reinterpret_cast<const f32x4*>(pb[q - NLD] + (long)c0 * p.ldb + tap * p.N);
     } else {
       rb[q - NLD] = *reinterpret_cast<const f32x4*>(pb[q - NLD] + (long)kt * BK * p.ldb);
     }
@@ -584,6 +650,105 @@ int sm3_colsum_f32(const float* x, int ld, int m, int n, const int32_t* group_of
   dim3 grid((n + 63) / 64, splits, groups);
   (void)hipMemsetAsync(out, 0, sizeof(float) * (size_t)groups * n, (hipStream_t)stream);
   colsum_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, ld, n, group_offsets, m, splits, out);
+  return launch_status();
+}
+
+
+// ------------------------------------------------------------------------------------------------------------
+// 3x3 convolution (padding 1, stride 1 or 2) on NHWC tokens as implicit GEMMs on the same kernel (GATHER = 1): the
+// operand that a materialised im2col would hold is gathered tap by tap while the tile is loaded, so no column buffer
+// exists (the FPN 3x3 at 256^2 x 256 ch would need a 1.2 GB one).  Weight layout (Cout, 3, 3, Cin) = [Cout][9*Cin].
+static void conv_geometry(GemmParams& p, int cC, int sH, int sW, int rH, int rW, int stride, int transposed, int bk) {
+  p.cC = cC; p.sH = sH; p.sW = sW; p.rH = rH; p.rW = rW; p.cS = stride; p.cT = transposed;
+  const unsigned tpt = (unsigned)(cC / bk);
+  p.cInv = (65536u + tpt - 1) / tpt;
+  p.mRW = (unsigned)((1ull << 32) / (unsigned)rW + 1);
+  p.mRH = (unsigned)((1ull << 32) / (unsigned)rH + 1);
+}
+
+static GemmParams conv_params_zero() {
+  GemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.num_groups = 1;
+  p.splits = 1;
+  p.rows_per_scale = 1;
+  return p;
+}
+
+static bool conv_dims_ok(int B, int H, int W, int Cin, int Cout, int stride) {
+  return B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && (stride == 1 || stride == 2) &&
+         (long)B * H * W < (1l << 24);
+}
+
+int sm3_conv3x3_nhwc_fwd(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cin,
+                         int Cout, int stride, sm3_stream_t stream) {
+  if (!x || !w || !y || !conv_dims_ok(B, H, W, Cin, Cout, stride)) return SM3_ERR_INVALID_ARG;
+  if ((Cin % 32) || (Cout & 3)) return SM3_ERR_UNSUPPORTED;
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  GemmParams p = conv_params_zero();
+  p.A = x; p.B = w; p.C = y;
+  p.M = B * Ho * Wo; p.N = Cout; p.K = 9 * Cin;
+  p.lda = Cin; p.ldb = 9 * Cin; p.ldc = Cout; p.ld_aux = Cout;
+  p.bias = bias;
+  conv_geometry(p, Cin, H, W, Ho, Wo, stride, 0, 32);
+  dim3 grid(((Cout + BN - 1) / BN) * ((p.M + BM - 1) / BM), 1, 1);
+  if (bias) gemm_f32_kernel<MODE_NT, EPI_BIAS, 32, 1><<<grid, NTHREADS, 0, (hipStream_t)stream>>>(p);
+  else gemm_f32_kernel<MODE_NT, EPI_NONE, 32, 1><<<grid, NTHREADS, 0, (hipStream_t)stream>>>(p);
+  return launch_status();
+}
+
+int sm3_conv3x3_nhwc_bwd_input(const float* dy, const float* w, float* dx, int B, int H, int W, int Cin, int Cout,
+                               int stride, sm3_stream_t stream) {
+  if (!dy || !w || !dx || !conv_dims_ok(B, H, W, Cin, Cout, stride)) return SM3_ERR_INVALID_ARG;
+  if ((Cout % 32) || (Cin & 3)) return SM3_ERR_UNSUPPORTED;
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  GemmParams p = conv_params_zero();
+  p.A = dy; p.B = w; p.C = dx;
+  p.M = B * H * W; p.N = Cin; p.K = 9 * Cout;
+  p.lda = Cout; p.ldb = 9 * Cin; p.ldc = Cin; p.ld_aux = Cin;
+  conv_geometry(p, Cout, Ho, Wo, H, W, stride, 1, 32);
+  dim3 grid(((Cin + BN - 1) / BN) * ((p.M + BM - 1) / BM), 1, 1);
+  gemm_f32_kernel<MODE_NN, EPI_NONE, 32, 1><<<grid, NTHREADS, 0, (hipStream_t)stream>>>(p);
+  return launch_status();
+}
+
+static int conv_wgrad_splits(int B, int H, int W, int Cin, int Cout, int stride) {
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  const long rows = (long)B * Ho * Wo;
+  const long tiles = (long)((Cout + BM - 1) / BM) * ((9 * Cin + BN - 1) / BN);
+  long s = (1024 + tiles - 1) / tiles;          // ~4 workgroups per CU in total
+  const long smax = (rows + 255) / 256;         // at least 256 reduction rows per split
+  if (s > smax) s = smax;
+  if (s < 1) s = 1;
+  return (int)s;
+}
+
+size_t sm3_conv3x3_nhwc_bwd_weight_workspace_bytes(int B, int H, int W, int Cin, int Cout, int stride) {
+  if (!conv_dims_ok(B, H, W, Cin, Cout, stride)) return 0;
+  return (size_t)conv_wgrad_splits(B, H, W, Cin, Cout, stride) * Cout * 9 * Cin * sizeof(float);
+}
+
+int sm3_conv3x3_nhwc_bwd_weight(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout,
+                                int stride, void* workspace, size_t workspace_bytes, sm3_stream_t stream) {
+  if (!x || !dy || !dw || !conv_dims_ok(B, H, W, Cin, Cout, stride)) return SM3_ERR_INVALID_ARG;
+  if ((Cin % BN) || (Cout & 3)) return SM3_ERR_UNSUPPORTED;  // an N-tile (128 columns of [9*Cin]) must sit in one tap
+  const size_t need = sm3_conv3x3_nhwc_bwd_weight_workspace_bytes(B, H, W, Cin, Cout, stride);
+  if (!workspace || workspace_bytes < need) return SM3_ERR_WORKSPACE;
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  GemmParams p = conv_params_zero();
+  p.A = dy; p.B = x; p.C = (float*)workspace;
+  p.M = Cout; p.N = 9 * Cin; p.K = B * Ho * Wo;
+  p.lda = Cout; p.ldb = Cin; p.ldc = 9 * Cin; p.ld_aux = 9 * Cin;
+  p.splits = conv_wgrad_splits(B, H, W, Cin, Cout, stride);
+  p.strideC = (long)p.M * p.N;
+  conv_geometry(p, Cin, H, W, Ho, Wo, stride, 0, 16);
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM), 1, p.splits);
+  gemm_f32_kernel<MODE_TN, EPI_NONE, 16, 1><<<grid, NTHREADS, 0, st>>>(p);
+  const long mn = (long)p.M * p.N;
+  long nb = (mn / 4 + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  splitk_reduce_kernel<<<(int)nb, 256, 0, st>>>((const float*)workspace, dw, mn, p.splits, 1);
   return launch_status();
 }
 

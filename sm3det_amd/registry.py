@@ -62,6 +62,7 @@ class Registry:
 
 ROTATED_BACKBONES = Registry('models')  # alias of mmdet's MODELS in the reference
 MODELS = ROTATED_BACKBONES
+ROTATED_NECKS = MODELS  # mmrotate/models/builder.py:4-12: every ROTATED_* name is the same mmdet MODELS registry
 
 
 def register_into(registry, force=True):
