@@ -121,6 +121,18 @@ def ops_microbench():
     out['roi_align_rotated_bwd_nhwc'] = timeit(lambda: torch.autograd.grad(yl, xl, go, retain_graph=True))
     d10, s10 = dev(synth.rotated_boxes(10000, 7)), dev(synth.unique_scores(10000, 8))
     out['nms_rotated_10000'] = timeit(lambda: ops.nms_rotated(d10, s10, 0.1), n=3)
+    # the neck of main_SM3Det.py on backbone-shaped NHWC inputs (bs 2 @ 1024^2, start_level 0)
+    from sm3det_amd.fpn import MultitaskFPN
+    fpn = MultitaskFPN(in_channels=[96, 192, 384, 768], out_channels=256, extra_level=1, add_extra_convs='on_output',
+                       num_outs=5).cuda()
+    feats = [torch.randn(BATCH, c, 256 >> i, 256 >> i, device='cuda').contiguous(memory_format=torch.channels_last)
+             .requires_grad_(True) for i, c in enumerate([96, 192, 384, 768])]
+
+    def fpn_step():
+        for q in fpn.parameters():
+            q.grad = None
+        sum((o * o).mean() for o in fpn(feats)).backward()
+    out['multitask_fpn_fwd_bwd_bs2_1024'] = timeit(fpn_step, n=5)
     return {k: round(v, 1) for k, v in out.items()}
 
 

@@ -153,10 +153,12 @@ int sm3_colsum_f32(const float* x, int ld, int m, int n, const int32_t* group_of
  * :97-106; conv/norm/act cfg None -> nn.Conv2d + bias) as implicit GEMMs -- no im2col buffer.  x (B,H,W,Cin),
  * w (Cout,3,3,Cin) [= Conv2d.weight.permute(0,2,3,1)], y (B,Ho,Wo,Cout), Ho = (H-1)/stride + 1.
  * fwd needs Cin % 32 == 0, bwd_input Cout % 32 == 0, bwd_weight Cin % 128 == 0; channel counts multiples of 4. */
+/* workspace of fwd (backward_input = 0) / bwd_input (= 1): split-K slabs when the level has few output tiles, else 0 */
+size_t sm3_conv3x3_nhwc_workspace_bytes(int B, int H, int W, int Cin, int Cout, int stride, int backward_input);
 int sm3_conv3x3_nhwc_fwd(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cin,
-                         int Cout, int stride, sm3_stream_t stream);
+                         int Cout, int stride, void* workspace, size_t workspace_bytes, sm3_stream_t stream);
 int sm3_conv3x3_nhwc_bwd_input(const float* dy, const float* w, float* dx, int B, int H, int W, int Cin, int Cout,
-                               int stride, sm3_stream_t stream);
+                               int stride, void* workspace, size_t workspace_bytes, sm3_stream_t stream);
 size_t sm3_conv3x3_nhwc_bwd_weight_workspace_bytes(int B, int H, int W, int Cin, int Cout, int stride);
 int sm3_conv3x3_nhwc_bwd_weight(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout,
                                 int stride, void* workspace, size_t workspace_bytes, sm3_stream_t stream);

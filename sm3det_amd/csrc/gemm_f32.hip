@@ -65,6 +65,7 @@ struct GemmParams {
   // (rH, rW) grid.  cT = 0: source = row * cS + d - 1 (forward / weight gradient);  cT = 1: source = (row - d + 1) / cS
   // where divisible (input gradient = transposed convolution).  cInv: (kt * cInv) >> 16 == kt / (cC / BK).
   int cC, sH, sW, rH, rW, cS, cT;
+  int kTilesPerSplit;  // GATHER NT/NN: > 0 -> blockIdx.z owns k-tiles [z*kTilesPerSplit, ...) and writes slab z of C
   unsigned cInv, mRW, mRH;  // mRW/mRH: ceil(2^32 / rW), ceil(2^32 / rH) for exact umulhi division of row indices
 };
 
@@ -194,7 +195,12 @@ __global__ __launch_bounds__(NTHREADS, (BK == 32 ? 2 : 4)) void gemm_f32_kernel(
   constexpr int T_ROWS = NTHREADS / (BK / 4);  // rows covered per pass of the transposed loader
   // direct loader: source is k-major: thread -> (k row d_kk + 8 i, column quad d_nq)
   const int d_nq = tid & 31, d_kk = tid >> 5;
-  const int nk = (MODE == MODE_TN) ? (max(row_end - row0, 0) + BK - 1) / BK : p.K / BK;
+  int nk = (MODE == MODE_TN) ? (max(row_end - row0, 0) + BK - 1) / BK : p.K / BK;
+  int kbase = 0;  // first k-tile of this block (split-K over the taps of small implicit-GEMM convolutions)
+  if (GATHER && MODE != MODE_TN && p.kTilesPerSplit > 0) {
+    kbase = blockIdx.z * p.kTilesPerSplit;
+    nk = min(p.kTilesPerSplit, nk - kbase);
+  }
 
   // Per-thread source pointers, computed once.  Out-of-range rows / columns are CLAMPED to a valid address instead
   // of branched around (the garbage they bring only reaches output rows/columns the epilogue masks); the one place
@@ -263,8 +269,9 @@ __global__ __launch_bounds__(NTHREADS, (BK == 32 ? 2 : 4)) void gemm_f32_kernel(
       }
     } else if (q < NLD) {
       if (GATHER) {
-        const int tap = (int)(((unsigned)kt * p.cInv) >> 16);  // k-tile -> tap (uniform), channel offset inside it
-        const int c0 = kt * BK - tap * p.cC;
+        const int kg = kt + kbase;
+        const int tap = (int)(((unsigned)kg * p.cInv) >> 16);  // k-tile -> tap (uniform), channel offset inside it
+        const int c0 = kg * BK - tap * p.cC;
         const int sy = gather_coord(gy[q], tap / 3, p.cS, p.cT, p.sH);
         const int sx = gather_coord(gx[q], tap % 3, p.cS, p.cT, p.sW);
         const long off = ((long)max(sy, 0) * p.sW + max(sx, 0)) * p.cC + c0;
@@ -274,11 +281,12 @@ __global__ __launch_bounds__(NTHREADS, (BK == 32 ? 2 : 4)) void gemm_f32_kernel(
         ra[q] = *reinterpret_cast<const f32x4*>(pa[q] + kt * BK);
       }
     } else if (MODE == MODE_NT) {
-      rb[q - NLD] = *reinterpret_cast<const f32x4*>(pb[q - NLD] + kt * BK);
+      rb[q - NLD] = *reinterpret_cast<const f32x4*>(pb[q - NLD] + (kt + kbase) * BK);
     } else if (GATHER) {
       // NN gather (input gradient): B row k = (tap, co) lives at W[co][tap][:]  (ldb = 9 * Cin, + tap * N columns)
-      const int tap = (int)(((unsigned)kt * p.cInv) >> 16);
-      const int c0 = kt * BK - tap * p.cC;
+      const int kg = kt + kbase;
+      const int tap = (int)(((unsigned)kg * p.cInv) >> 16);
+      const int c0 = kg * BK - tap * p.cC;
       rb[q - NLD] = *reinterpret_cast<const f32x4*>(pb[q - NLD] + (long)c0 * p.ldb + tap * p.N);
     } else {
       rb[q - NLD] = *reinterpret_cast<const f32x4*>(pb[q - NLD] + (long)kt * BK * p.ldb);
@@ -378,6 +386,7 @@ __global__ __launch_bounds__(NTHREADS, (BK == 32 ? 2 : 4)) void gemm_f32_kernel(
     c_base = (long)blockIdx.z * p.strideC;
     m_lim = p.M;
   } else {
+    if (GATHER && p.kTilesPerSplit > 0) c_base = (long)blockIdx.z * p.strideC;
     m_lim = row_end;
   }
   const float* bias = (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_SCALE_RES)
@@ -486,13 +495,14 @@ __global__ __launch_bounds__(256) void tile_colsum_reduce_kernel(const float* __
 
 // Sum the split-K partials of a TN GEMM: out[g][i] = sum_s ws[(g*splits+s)][i]
 __global__ void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, long mn, int splits,
-                                     int groups) {
+                                     int groups, const float* __restrict__ bias = nullptr, int ncols = 0) {
   const long total = mn * groups;
   for (long idx = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; idx < total;
        idx += (long)gridDim.x * blockDim.x * 4) {
     const long gidx = idx / mn;
     const long e = idx - gidx * mn;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (bias) s = *reinterpret_cast<const f32x4*>(bias + (e % ncols));  // rows of ncols (multiple of 4) columns
     for (int k = 0; k < splits; k++) s += *reinterpret_cast<const f32x4*>(ws + (gidx * splits + k) * mn + e);
     *reinterpret_cast<f32x4*>(out + idx) = s;
   }
@@ -680,36 +690,78 @@ static bool conv_dims_ok(int B, int H, int W, int Cin, int Cout, int stride) {
          (long)B * H * W < (1l << 24);
 }
 
+// Small pyramid levels have fewer 128x128 output tiles than the chip has CUs while K = 9*C is long: split K across
+// blockIdx.z (whole k-tiles, tap-aligned or not), partial slabs to the workspace, one reduce (+ bias).
+static int conv_ksplits(long m_rows, int n_cols, int k_tiles) {
+  const long tiles = ((m_rows + BM - 1) / BM) * ((n_cols + BN - 1) / BN);
+  if (tiles >= 512) return 1;
+  long s = (1024 + tiles - 1) / tiles;
+  if (s > k_tiles / 4) s = k_tiles / 4;  // at least 4 k-tiles per split
+  if (s > 16) s = 16;
+  return s < 1 ? 1 : (int)s;
+}
+
+size_t sm3_conv3x3_nhwc_workspace_bytes(int B, int H, int W, int Cin, int Cout, int stride, int backward_input) {
+  if (!conv_dims_ok(B, H, W, Cin, Cout, stride)) return 0;
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  const long m = backward_input ? (long)B * H * W : (long)B * Ho * Wo;
+  const int n = backward_input ? Cin : Cout, kc = backward_input ? Cout : Cin;
+  const int ks = conv_ksplits(m, n, 9 * kc / 32);
+  return ks > 1 ? (size_t)ks * m * n * sizeof(float) : 0;
+}
+
+static int conv_launch_nt_nn(GemmParams& p, int mode, const float* bias, float* out, void* workspace,
+                             size_t workspace_bytes, hipStream_t st) {
+  const int k_tiles = p.K / 32;
+  const int ks = conv_ksplits(p.M, p.N, k_tiles);
+  const long mn = (long)p.M * p.N;
+  if (ks > 1) {
+    if (!workspace || workspace_bytes < (size_t)ks * mn * sizeof(float)) return SM3_ERR_WORKSPACE;
+    p.kTilesPerSplit = (k_tiles + ks - 1) / ks;
+    p.strideC = mn;
+    p.C = (float*)workspace;
+    p.bias = nullptr;
+  } else {
+    p.C = out;
+  }
+  const int zs = ks > 1 ? (k_tiles + p.kTilesPerSplit - 1) / p.kTilesPerSplit : 1;
+  dim3 grid(((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM), 1, zs);
+  if (mode == MODE_NN) gemm_f32_kernel<MODE_NN, EPI_NONE, 32, 1><<<grid, NTHREADS, 0, st>>>(p);
+  else if (p.bias) gemm_f32_kernel<MODE_NT, EPI_BIAS, 32, 1><<<grid, NTHREADS, 0, st>>>(p);
+  else gemm_f32_kernel<MODE_NT, EPI_NONE, 32, 1><<<grid, NTHREADS, 0, st>>>(p);
+  if (ks > 1) {
+    long nb = (mn / 4 + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    splitk_reduce_kernel<<<(int)nb, 256, 0, st>>>((const float*)workspace, out, mn, zs, 1, bias, p.N);
+  }
+  return launch_status();
+}
+
 int sm3_conv3x3_nhwc_fwd(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cin,
-                         int Cout, int stride, sm3_stream_t stream) {
+                         int Cout, int stride, void* workspace, size_t workspace_bytes, sm3_stream_t stream) {
   if (!x || !w || !y || !conv_dims_ok(B, H, W, Cin, Cout, stride)) return SM3_ERR_INVALID_ARG;
   if ((Cin % 32) || (Cout & 3)) return SM3_ERR_UNSUPPORTED;
   const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
   GemmParams p = conv_params_zero();
-  p.A = x; p.B = w; p.C = y;
+  p.A = x; p.B = w;
   p.M = B * Ho * Wo; p.N = Cout; p.K = 9 * Cin;
   p.lda = Cin; p.ldb = 9 * Cin; p.ldc = Cout; p.ld_aux = Cout;
   p.bias = bias;
   conv_geometry(p, Cin, H, W, Ho, Wo, stride, 0, 32);
-  dim3 grid(((Cout + BN - 1) / BN) * ((p.M + BM - 1) / BM), 1, 1);
-  if (bias) gemm_f32_kernel<MODE_NT, EPI_BIAS, 32, 1><<<grid, NTHREADS, 0, (hipStream_t)stream>>>(p);
-  else gemm_f32_kernel<MODE_NT, EPI_NONE, 32, 1><<<grid, NTHREADS, 0, (hipStream_t)stream>>>(p);
-  return launch_status();
+  return conv_launch_nt_nn(p, MODE_NT, bias, y, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 int sm3_conv3x3_nhwc_bwd_input(const float* dy, const float* w, float* dx, int B, int H, int W, int Cin, int Cout,
-                               int stride, sm3_stream_t stream) {
+                               int stride, void* workspace, size_t workspace_bytes, sm3_stream_t stream) {
   if (!dy || !w || !dx || !conv_dims_ok(B, H, W, Cin, Cout, stride)) return SM3_ERR_INVALID_ARG;
   if ((Cout % 32) || (Cin & 3)) return SM3_ERR_UNSUPPORTED;
   const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
   GemmParams p = conv_params_zero();
-  p.A = dy; p.B = w; p.C = dx;
+  p.A = dy; p.B = w;
   p.M = B * H * W; p.N = Cin; p.K = 9 * Cout;
   p.lda = Cout; p.ldb = 9 * Cin; p.ldc = Cin; p.ld_aux = Cin;
   conv_geometry(p, Cout, Ho, Wo, H, W, stride, 1, 32);
-  dim3 grid(((Cin + BN - 1) / BN) * ((p.M + BM - 1) / BM), 1, 1);
-  gemm_f32_kernel<MODE_NN, EPI_NONE, 32, 1><<<grid, NTHREADS, 0, (hipStream_t)stream>>>(p);
-  return launch_status();
+  return conv_launch_nt_nn(p, MODE_NN, nullptr, dx, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 static int conv_wgrad_splits(int B, int H, int W, int Cin, int Cout, int stride) {

@@ -46,7 +46,10 @@ class _Conv3x3(Function):
         Cout = w.shape[0]
         Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
         y = _e(B, Ho, Wo, Cout, like=x)
-        call('conv3x3_nhwc_fwd', x, w, b, y, B, H, W, Cin, Cout, stride, flops=2.0 * B * Ho * Wo * Cout * 9 * Cin)
+        nb = _lib.lib().sm3_conv3x3_nhwc_workspace_bytes(B, H, W, Cin, Cout, stride, 0)
+        ws = _lib.workspace(nb, x.device)
+        call('conv3x3_nhwc_fwd', x, w, b, y, B, H, W, Cin, Cout, stride, ws, nb,
+             flops=2.0 * B * Ho * Wo * Cout * 9 * Cin)
         ctx.save_for_backward(x, w)
         ctx.stride = stride
         return y
@@ -63,7 +66,9 @@ class _Conv3x3(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = _e(B, H, W, Cin, like=x)
-            call('conv3x3_nhwc_bwd_input', dy, w, dx, B, H, W, Cin, Cout, s, flops=fl)
+            nb = _lib.lib().sm3_conv3x3_nhwc_workspace_bytes(B, H, W, Cin, Cout, s, 1)
+            ws = _lib.workspace(nb, x.device)
+            call('conv3x3_nhwc_bwd_input', dy, w, dx, B, H, W, Cin, Cout, s, ws, nb, flops=fl)
         dw = _e(Cout, 3, 3, Cin, like=x)
         nb = _lib.lib().sm3_conv3x3_nhwc_bwd_weight_workspace_bytes(B, H, W, Cin, Cout, s)
         ws = _lib.workspace(nb, x.device)
