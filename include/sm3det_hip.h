@@ -155,8 +155,10 @@ int sm3_colsum_f32(const float* x, int ld, int m, int n, const int32_t* group_of
  * fwd needs Cin % 32 == 0, bwd_input Cout % 32 == 0, bwd_weight Cin % 128 == 0; channel counts multiples of 4. */
 /* workspace of fwd (backward_input = 0) / bwd_input (= 1): split-K slabs when the level has few output tiles, else 0 */
 size_t sm3_conv3x3_nhwc_workspace_bytes(int B, int H, int W, int Cin, int Cout, int stride, int backward_input);
+/* relu != 0: y = max(conv + bias, 0) (the F.relu after rpn_conv, rotated_rpn_head.py:45-46), needs bias */
 int sm3_conv3x3_nhwc_fwd(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cin,
-                         int Cout, int stride, void* workspace, size_t workspace_bytes, sm3_stream_t stream);
+                         int Cout, int stride, int relu, void* workspace, size_t workspace_bytes,
+                         sm3_stream_t stream);
 int sm3_conv3x3_nhwc_bwd_input(const float* dy, const float* w, float* dx, int B, int H, int W, int Cin, int Cout,
                                int stride, void* workspace, size_t workspace_bytes, sm3_stream_t stream);
 size_t sm3_conv3x3_nhwc_bwd_weight_workspace_bytes(int B, int H, int W, int Cin, int Cout, int stride);
@@ -168,6 +170,19 @@ int sm3_upsample2x_add(const float* fine, const float* coarse, float* out, int B
                        sm3_stream_t stream);
 int sm3_sumpool2x_add(const float* dfine, const float* base, float* dcoarse, int B, int Hc, int Wc, int C,
                       sm3_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Oriented-RPN proposal glue.
+ * relu_bwd: dx = y > 0 ? dy : 0 (n multiple of 4).  sigmoid: y = 1/(1+exp(-x)) (oriented_rpn_head.py:236-238).
+ * rpn_decode_le90: for i < n, src = order ? order[i] : i (order = descending-score permutation: the top-k gather of
+ * :248-254); proposals[i] (cx,cy,w,h,a) = MidpointOffsetCoder.decode(anchors[src] (x1,y1,x2,y2), deltas[src] (6))
+ * (delta_midpointoffset_rbbox_coder.py:150-238, angle version 'le90'), hboxes[i] = obb2xyxy_le90(proposals[i])
+ * (transforms.py:685-702), scores_out[i] = scores[src] (both may be NULL).  means6 / stds6 are HOST arrays. */
+int sm3_relu_bwd(const float* dy, const float* y, float* dx, long n, sm3_stream_t stream);
+int sm3_sigmoid_f32(const float* x, float* y, long n, sm3_stream_t stream);
+int sm3_rpn_decode_le90(const float* anchors, const float* deltas, const float* scores, const int64_t* order, int n,
+                        const float* means6, const float* stds6, float wh_ratio_clip, float* proposals,
+                        float* hboxes, float* scores_out, sm3_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Stem: Conv2d(3,C0,k=4,s=4) (convnext_moe.py:783-791) as patchify + NT GEMM.  x (B,3,H,W) NCHW ->

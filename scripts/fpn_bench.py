@@ -24,7 +24,7 @@ for (B, H, W, Cin, Cout, s) in [(2, 256, 256, 256, 256, 1), (2, 128, 128, 256, 2
     fl = 2.0 * B * Ho * Wo * Cout * 9 * Cin
     n1 = _lib.lib().sm3_conv3x3_nhwc_workspace_bytes(B, H, W, Cin, Cout, s, 0); w1 = _lib.workspace(n1, x.device)
     n2 = _lib.lib().sm3_conv3x3_nhwc_workspace_bytes(B, H, W, Cin, Cout, s, 1); w2 = _lib.workspace(n2, x.device)
-    t1 = timeit(lambda: LB.call('conv3x3_nhwc_fwd', x, w, b, y, B, H, W, Cin, Cout, s, w1, n1))
+    t1 = timeit(lambda: LB.call('conv3x3_nhwc_fwd', x, w, b, y, B, H, W, Cin, Cout, s, 0, w1, n1))
     t2 = timeit(lambda: LB.call('conv3x3_nhwc_bwd_input', y, w, dx, B, H, W, Cin, Cout, s, w2, n2))
     t3 = timeit(lambda: LB.call('conv3x3_nhwc_bwd_weight', x, y, dw, B, H, W, Cin, Cout, s, ws, nb))
     print(f'conv3x3 {B}x{H}x{W} {Cin}->{Cout} s{s}: fwd {t1*1e3:7.1f} us {fl/t1/1e9:6.1f} TF/s | dgrad {t2*1e3:7.1f} us {fl/t2/1e9:6.1f} | wgrad {t3*1e3:7.1f} us {fl/t3/1e9:6.1f}', flush=True)

@@ -40,7 +40,10 @@ def signatures():
         'sm3_dwconv7_bwd_weight': (I, [P, P, P, P, I, I, I, I, P]),
         'sm3_scale_bwd_prep': (I, [P, P, P, P, I, P, P, LL, I, P, S, P]),
         'sm3_conv3x3_nhwc_workspace_bytes': (S, [I, I, I, I, I, I, I]),
-        'sm3_conv3x3_nhwc_fwd': (I, [P, P, P, P, I, I, I, I, I, I, P, S, P]),
+        'sm3_conv3x3_nhwc_fwd': (I, [P, P, P, P, I, I, I, I, I, I, I, P, S, P]),
+        'sm3_relu_bwd': (I, [P, P, P, LL, P]),
+        'sm3_sigmoid_f32': (I, [P, P, LL, P]),
+        'sm3_rpn_decode_le90': (I, [P, P, P, P, I, P, P, F, P, P, P, P]),
         'sm3_conv3x3_nhwc_bwd_input': (I, [P, P, P, I, I, I, I, I, I, P, S, P]),
         'sm3_conv3x3_nhwc_bwd_weight_workspace_bytes': (S, [I, I, I, I, I, I]),
         'sm3_conv3x3_nhwc_bwd_weight': (I, [P, P, P, I, I, I, I, I, I, P, S, P]),

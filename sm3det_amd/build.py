@@ -21,6 +21,7 @@ BASE_FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-Wall', '
 FILE_FLAGS = {
     'ops_rotated.hip': ['-ffp-contract=off'],
     'deform_conv.hip': ['-ffp-contract=off'],
+    'rpn.hip': ['-ffp-contract=off'],
 }
 
 

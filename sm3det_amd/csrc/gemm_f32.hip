@@ -106,6 +106,7 @@ __device__ __forceinline__ void gelu_erf_both(float h, float& y, float& dy) {
 
 // EPI codes (must match include/sm3det_hip.h)
 constexpr int EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_BIAS_SCALE_RES = 3, EPI_GELU_BWD = 4;
+constexpr int EPI_BIAS_RELU = 5;  // conv3x3 + bias + F.relu (RPN tower); only instantiated for the gather variant
 
 template <int MODE, int EPI, int BK, int GATHER = 0>
 __global__ __launch_bounds__(NTHREADS, (BK == 32 ? 2 : 4)) void gemm_f32_kernel(GemmParams p) {
@@ -389,7 +390,7 @@ __global__ __launch_bounds__(NTHREADS, (BK == 32 ? 2 : 4)) void gemm_f32_kernel(
     if (GATHER && p.kTilesPerSplit > 0) c_base = (long)blockIdx.z * p.strideC;
     m_lim = row_end;
   }
-  const float* bias = (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_SCALE_RES)
+  const float* bias = (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_SCALE_RES || EPI == EPI_BIAS_RELU)
                           ? p.bias + (long)g * p.strideBias
                           : nullptr;
   f32x4 csum[2][4];
@@ -418,6 +419,11 @@ __global__ __launch_bounds__(NTHREADS, (BK == 32 ? 2 : 4)) void gemm_f32_kernel(
           *reinterpret_cast<f32x4*>(cp) = v;
         } else if (EPI == EPI_BIAS) {
           *reinterpret_cast<f32x4*>(cp) = v + *reinterpret_cast<const f32x4*>(bias + col);
+        } else if (EPI == EPI_BIAS_RELU) {
+          f32x4 o = v + *reinterpret_cast<const f32x4*>(bias + col);
+#pragma unroll
+          for (int e = 0; e < 4; e++) o[e] = fmaxf(o[e], 0.f);
+          *reinterpret_cast<f32x4*>(cp) = o;
         } else if (EPI == EPI_BIAS_GELU) {
           const f32x4 h = v + *reinterpret_cast<const f32x4*>(bias + col);
           f32x4 y, dy;
@@ -495,7 +501,8 @@ __global__ __launch_bounds__(256) void tile_colsum_reduce_kernel(const float* __
 
 // Sum the split-K partials of a TN GEMM: out[g][i] = sum_s ws[(g*splits+s)][i]
 __global__ void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, long mn, int splits,
-                                     int groups, const float* __restrict__ bias = nullptr, int ncols = 0) {
+                                     int groups, const float* __restrict__ bias = nullptr, int ncols = 0,
+                                     int relu = 0) {
   const long total = mn * groups;
   for (long idx = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; idx < total;
        idx += (long)gridDim.x * blockDim.x * 4) {
@@ -504,6 +511,10 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, float* __rest
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     if (bias) s = *reinterpret_cast<const f32x4*>(bias + (e % ncols));  // rows of ncols (multiple of 4) columns
     for (int k = 0; k < splits; k++) s += *reinterpret_cast<const f32x4*>(ws + (gidx * splits + k) * mn + e);
+    if (relu) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) s[q] = fmaxf(s[q], 0.f);
+    }
     *reinterpret_cast<f32x4*>(out + idx) = s;
   }
 }
@@ -710,7 +721,7 @@ size_t sm3_conv3x3_nhwc_workspace_bytes(int B, int H, int W, int Cin, int Cout, 
   return ks > 1 ? (size_t)ks * m * n * sizeof(float) : 0;
 }
 
-static int conv_launch_nt_nn(GemmParams& p, int mode, const float* bias, float* out, void* workspace,
+static int conv_launch_nt_nn(GemmParams& p, int mode, const float* bias, int relu, float* out, void* workspace,
                              size_t workspace_bytes, hipStream_t st) {
   const int k_tiles = p.K / 32;
   const int ks = conv_ksplits(p.M, p.N, k_tiles);
@@ -727,19 +738,22 @@ static int conv_launch_nt_nn(GemmParams& p, int mode, const float* bias, float* 
   const int zs = ks > 1 ? (k_tiles + p.kTilesPerSplit - 1) / p.kTilesPerSplit : 1;
   dim3 grid(((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM), 1, zs);
   if (mode == MODE_NN) gemm_f32_kernel<MODE_NN, EPI_NONE, 32, 1><<<grid, NTHREADS, 0, st>>>(p);
+  else if (p.bias && relu) gemm_f32_kernel<MODE_NT, EPI_BIAS_RELU, 32, 1><<<grid, NTHREADS, 0, st>>>(p);
   else if (p.bias) gemm_f32_kernel<MODE_NT, EPI_BIAS, 32, 1><<<grid, NTHREADS, 0, st>>>(p);
   else gemm_f32_kernel<MODE_NT, EPI_NONE, 32, 1><<<grid, NTHREADS, 0, st>>>(p);
   if (ks > 1) {
     long nb = (mn / 4 + 255) / 256;
     if (nb > 4096) nb = 4096;
-    splitk_reduce_kernel<<<(int)nb, 256, 0, st>>>((const float*)workspace, out, mn, zs, 1, bias, p.N);
+    splitk_reduce_kernel<<<(int)nb, 256, 0, st>>>((const float*)workspace, out, mn, zs, 1, bias, p.N, relu);
   }
   return launch_status();
 }
 
 int sm3_conv3x3_nhwc_fwd(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cin,
-                         int Cout, int stride, void* workspace, size_t workspace_bytes, sm3_stream_t stream) {
+                         int Cout, int stride, int relu, void* workspace, size_t workspace_bytes,
+                         sm3_stream_t stream) {
   if (!x || !w || !y || !conv_dims_ok(B, H, W, Cin, Cout, stride)) return SM3_ERR_INVALID_ARG;
+  if (relu && !bias) return SM3_ERR_INVALID_ARG;
   if ((Cin % 32) || (Cout & 3)) return SM3_ERR_UNSUPPORTED;
   const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
   GemmParams p = conv_params_zero();
@@ -748,7 +762,7 @@ int sm3_conv3x3_nhwc_fwd(const float* x, const float* w, const float* bias, floa
   p.lda = Cin; p.ldb = 9 * Cin; p.ldc = Cout; p.ld_aux = Cout;
   p.bias = bias;
   conv_geometry(p, Cin, H, W, Ho, Wo, stride, 0, 32);
-  return conv_launch_nt_nn(p, MODE_NT, bias, y, workspace, workspace_bytes, (hipStream_t)stream);
+  return conv_launch_nt_nn(p, MODE_NT, bias, relu, y, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 int sm3_conv3x3_nhwc_bwd_input(const float* dy, const float* w, float* dx, int B, int H, int W, int Cin, int Cout,
@@ -761,7 +775,7 @@ int sm3_conv3x3_nhwc_bwd_input(const float* dy, const float* w, float* dx, int B
   p.M = B * H * W; p.N = Cin; p.K = 9 * Cout;
   p.lda = Cout; p.ldb = 9 * Cin; p.ldc = Cin; p.ld_aux = Cin;
   conv_geometry(p, Cout, Ho, Wo, H, W, stride, 1, 32);
-  return conv_launch_nt_nn(p, MODE_NN, nullptr, dx, workspace, workspace_bytes, (hipStream_t)stream);
+  return conv_launch_nt_nn(p, MODE_NN, nullptr, 0, dx, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 static int conv_wgrad_splits(int B, int H, int W, int Cin, int Cout, int stride) {

@@ -39,7 +39,7 @@ class _Conv3x3(Function):
     """y (B,Ho,Wo,Cout) = conv3x3(x (B,H,W,Cin), w (Cout,3,3,Cin), padding 1, stride s) + bias"""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride):
+    def forward(ctx, x, w, b, stride, relu=False):
         _lib.require_gpu(x, w, b)
         x, w, b = x.contiguous(), w.contiguous(), b.contiguous()
         B, H, W, Cin = x.shape
@@ -48,17 +48,21 @@ class _Conv3x3(Function):
         y = _e(B, Ho, Wo, Cout, like=x)
         nb = _lib.lib().sm3_conv3x3_nhwc_workspace_bytes(B, H, W, Cin, Cout, stride, 0)
         ws = _lib.workspace(nb, x.device)
-        call('conv3x3_nhwc_fwd', x, w, b, y, B, H, W, Cin, Cout, stride, ws, nb,
+        call('conv3x3_nhwc_fwd', x, w, b, y, B, H, W, Cin, Cout, stride, int(relu), ws, nb,
              flops=2.0 * B * Ho * Wo * Cout * 9 * Cin)
-        ctx.save_for_backward(x, w)
-        ctx.stride = stride
+        ctx.save_for_backward(x, w, y if relu else None)
+        ctx.stride, ctx.relu = stride, relu
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w = ctx.saved_tensors
+        x, w, y = ctx.saved_tensors
         s = ctx.stride
         dy = dy.contiguous()
+        if ctx.relu:  # gradient of max(., 0): pass where the saved output is positive
+            dpre = _e(*dy.shape, like=dy)
+            call('relu_bwd', dy, y, dpre, dy.numel())
+            dy = dpre
         B, H, W, Cin = x.shape
         Cout = w.shape[0]
         Ho, Wo = dy.shape[1], dy.shape[2]
@@ -75,7 +79,7 @@ class _Conv3x3(Function):
         call('conv3x3_nhwc_bwd_weight', x, dy, dw, B, H, W, Cin, Cout, s, ws, nb, flops=fl)
         db = _e(Cout, like=x)
         colsum(dy.view(-1, Cout), B * Ho * Wo, Cout, db)
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
 class _UpsampleAdd(Function):
@@ -104,8 +108,8 @@ class _UpsampleAdd(Function):
         return dout, dcoarse
 
 
-def conv3x3_nhwc(x, w, b, stride=1):
-    return _Conv3x3.apply(x, w, b, stride)
+def conv3x3_nhwc(x, w, b, stride=1, relu=False):
+    return _Conv3x3.apply(x, w, b, stride, relu)
 
 
 def upsample2x_add(fine, coarse):

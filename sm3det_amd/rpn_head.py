@@ -1,0 +1,203 @@
+"""Oriented-RPN head on the MI355X kernels: the conv tower and the proposal glue.
+
+Mirrors, for the part that is in the reference tree:
+
+* ``OrientedRPNHead._init_layers`` / ``RotatedRPNHead.forward_single`` (``mmrotate/models/dense_heads/
+  oriented_rpn_head.py:18-24``, ``rotated_rpn_head.py:43-50``): ``rpn_conv`` 3x3 + ReLU, ``rpn_cls`` / ``rpn_reg`` 1x1 --
+  same parameter names and shapes in ``state_dict``; executed on NHWC tokens: one implicit-GEMM 3x3 with a fused
+  bias + ReLU epilogue, then ONE GEMM for both 1x1 heads (their weights are concatenated per call);
+* ``OrientedRPNHead._get_bboxes_single`` (``oriented_rpn_head.py:189-281``): per level sigmoid -> descending sort ->
+  top ``nms_pre`` -> ``MidpointOffsetCoder.decode`` -> ``obb2xyxy`` -> ``batched_nms`` over levels -> top
+  ``max_per_img``; here the gather + decode + obb2xyxy is one kernel per level, sort / NMS are the library's own
+  device kernels, and there is ONE host sync per image (the variable-length result) instead of one per op;
+* ``MidpointOffsetCoder.decode`` (``mmrotate/core/bbox/coder/delta_midpointoffset_rbbox_coder.py:53-84``).
+
+Not mirrored (they live in mmdet 2.x, which the reference does not vendor -- SURVEY.md Appendix A): ``AnchorHead``'s loss
+/ target machinery (``MaxIoUAssigner``, ``RandomSampler``, ``anchor_inside_flags`` ...).  ``grid_anchors`` restates
+mmdet's ``AnchorGenerator.grid_priors`` for the ``scales x ratios`` form the config uses, flagged [memory].
+No CPU fallback.
+"""
+import torch
+import torch.nn as nn
+
+from . import _lib
+from . import _lib_backbone as LB
+from . import backbone_ops as ops
+from . import mmcv_ops
+from .fpn import _Conv, _to_nhwc, conv3x3_nhwc
+from .registry import ROTATED_NECKS as _REG  # every ROTATED_* registry of the reference is the same MODELS object
+
+call = LB.call
+
+
+class MidpointOffsetCoder:
+    """decode-only mirror of the reference coder (angle version 'le90', the one SM3Det uses)."""
+
+    def __init__(self, target_means=(0., 0., 0., 0., 0., 0.), target_stds=(1., 1., 1., 1., 1., 1.),
+                 angle_range='oc'):
+        self.means = tuple(float(v) for v in target_means)
+        self.stds = tuple(float(v) for v in target_stds)
+        self.version = angle_range
+        import ctypes
+        self._means = (ctypes.c_float * 6)(*self.means)
+        self._stds = (ctypes.c_float * 6)(*self.stds)
+
+    def encode(self, bboxes, gt_bboxes):
+        raise NotImplementedError('bbox2delta belongs to the target-assignment half (mmdet sampler/assigner) and is '
+                                  'not part of this round')
+
+    def decode(self, bboxes, pred_bboxes, max_shape=None, wh_ratio_clip=16 / 1000, order=None, scores=None):
+        """(N,4) anchors + (N,6) deltas -> (n,5) oriented boxes; with ``order`` (int64 permutation prefix) only the
+        listed rows are decoded, in that order.  Returns (proposals, hboxes[, gathered scores])."""
+        if self.version != 'le90':
+            raise NotImplementedError("only angle version 'le90' (every SM3Det config) is implemented")
+        _lib.require_gpu(bboxes, pred_bboxes)
+        assert pred_bboxes.size(0) == bboxes.size(0) and bboxes.size(-1) == 4 and pred_bboxes.size(-1) == 6
+        anchors = bboxes.float().contiguous()
+        deltas = pred_bboxes.float().contiguous()
+        n = int(order.numel()) if order is not None else anchors.shape[0]
+        props = torch.empty(n, 5, device=anchors.device)
+        hb = torch.empty(n, 4, device=anchors.device)
+        so = torch.empty(n, device=anchors.device) if scores is not None else None
+        L = _lib.lib()
+        _lib.check(L.sm3_rpn_decode_le90(LB._p(anchors), LB._p(deltas), LB._p(scores),
+                                         LB._p(order), n, self._means, self._stds, float(wh_ratio_clip),
+                                         LB._p(props), LB._p(hb), LB._p(so), _lib.stream_ptr()), 'rpn_decode_le90')
+        return (props, hb) if scores is None else (props, hb, so)
+
+
+def grid_anchors(featmap_sizes, strides, scales=(8,), ratios=(0.5, 1.0, 2.0), device='cuda'):
+    """[memory] mmdet ``AnchorGenerator(scales, ratios, strides).grid_priors``: per level (H*W*A, 4) x1,y1,x2,y2,
+    position-major (y, x) then base anchor (ratio-major, scale-minor), centre offset 0."""
+    out = []
+    for (H, W), s in zip(featmap_sizes, strides):
+        r = torch.tensor(ratios, dtype=torch.float32)
+        sc = torch.tensor(scales, dtype=torch.float32)
+        hr, wr = torch.sqrt(r), 1.0 / torch.sqrt(r)
+        ws = (s * wr[:, None] * sc[None, :]).reshape(-1)
+        hs = (s * hr[:, None] * sc[None, :]).reshape(-1)
+        base = torch.stack([-0.5 * ws, -0.5 * hs, 0.5 * ws, 0.5 * hs], -1)
+        sx = torch.arange(W, dtype=torch.float32) * s
+        sy = torch.arange(H, dtype=torch.float32) * s
+        yy, xx = torch.meshgrid(sy, sx, indexing='ij')
+        shifts = torch.stack([xx.reshape(-1), yy.reshape(-1), xx.reshape(-1), yy.reshape(-1)], -1)
+        out.append((shifts[:, None, :] + base[None, :, :]).reshape(-1, 4).to(device))
+    return out
+
+
+@_REG.register_module()
+class OrientedRPNHead(nn.Module):
+    def __init__(self, in_channels, feat_channels=256, version='oc', anchor_generator=None, bbox_coder=None,
+                 loss_cls=None, loss_bbox=None, train_cfg=None, test_cfg=None,
+                 init_cfg=dict(type='Normal', layer='Conv2d', std=0.01), **kwargs):
+        super().__init__()
+        self.in_channels, self.feat_channels, self.version = in_channels, feat_channels, version
+        ag = dict(anchor_generator or dict(type='AnchorGenerator', scales=[8], ratios=[0.5, 1.0, 2.0],
+                                           strides=[4, 8, 16, 32, 64]))
+        self.anchor_cfg = ag
+        self.num_anchors = len(ag.get('ratios', [1.0])) * len(ag.get('scales', [8]))
+        self.use_sigmoid_cls = True if loss_cls is None else bool(loss_cls.get('use_sigmoid', False))
+        if not self.use_sigmoid_cls:
+            raise NotImplementedError('softmax RPN classification is not used by any SM3Det config')
+        self.cls_out_channels = 1
+        bc = dict(bbox_coder or dict(type='MidpointOffsetCoder', angle_range=version))
+        bc.pop('type', None)
+        self.bbox_coder = MidpointOffsetCoder(**bc)
+        self.loss_cls_cfg, self.loss_bbox_cfg = loss_cls, loss_bbox
+        self.train_cfg, self.test_cfg, self.init_cfg = train_cfg, test_cfg, init_cfg
+        self._init_layers()
+
+    def _init_layers(self):
+        """reference oriented_rpn_head.py:18-24 (parameters named rpn_conv / rpn_cls / rpn_reg .weight/.bias)"""
+        self.rpn_conv = _Conv(self.in_channels, self.feat_channels, 3)
+        self.rpn_cls = _Conv(self.feat_channels, self.num_anchors * self.cls_out_channels, 1)
+        self.rpn_reg = _Conv(self.feat_channels, self.num_anchors * 6, 1)
+
+    def init_weights(self):
+        std = float((self.init_cfg or {}).get('std', 0.01))
+        for m in (self.rpn_conv, self.rpn_cls, self.rpn_reg):
+            nn.init.normal_(m.weight, 0.0, std)
+            nn.init.constant_(m.bias, 0.0)
+
+    # ------------------------------------------------------------------------------------------ conv tower
+    def _fused_heads(self):
+        """[rpn_cls; rpn_reg; 0] as one (NP, feat) matrix, NP = rows padded to a multiple of 32 (the input-gradient
+        GEMM contracts over them: K granule of the fp32 MFMA tiles)."""
+        A = self.num_anchors
+        n = 7 * A
+        pad = (-n) % 32
+        w = torch.cat([self.rpn_cls.weight, self.rpn_reg.weight,
+                       self.rpn_reg.weight.new_zeros(pad, self.feat_channels)], 0)
+        b = torch.cat([self.rpn_cls.bias, self.rpn_reg.bias, self.rpn_reg.bias.new_zeros(pad)], 0)
+        return w, b
+
+    def forward_single(self, x, fused=None):
+        """reference rotated_rpn_head.py:43-50; x logically NCHW -> (cls (B,A,H,W), reg (B,6A,H,W)) views"""
+        w, b = fused if fused is not None else self._fused_heads()
+        A = self.num_anchors
+        t = conv3x3_nhwc(_to_nhwc(x), self.rpn_conv.weight, self.rpn_conv.bias, 1, True)  # conv + bias + ReLU
+        B, H, W, C = t.shape
+        o = ops.linear(t.reshape(-1, C), w, b).view(B, H, W, -1)
+        return o[..., :A].permute(0, 3, 1, 2), o[..., A:7 * A].permute(0, 3, 1, 2)
+
+    def forward(self, feats):
+        """multi_apply(forward_single, feats) -> (list of cls scores, list of bbox preds)"""
+        fused = self._fused_heads()
+        outs = [self.forward_single(f, fused) for f in feats]
+        return [o[0] for o in outs], [o[1] for o in outs]
+
+    # ------------------------------------------------------------------------------------------ proposals
+    def _get_bboxes_single(self, cls_scores, bbox_preds, mlvl_anchors, img_shape=None, scale_factor=None, cfg=None,
+                           rescale=False):
+        """reference oriented_rpn_head.py:189-281.  cls_scores[l] (A,H,W), bbox_preds[l] (6A,H,W), mlvl_anchors[l]
+        (H*W*A, 4).  Returns (n, 6): cx, cy, w, h, a, score."""
+        cfg = dict(self.test_cfg if cfg is None else cfg)
+        nms_pre, max_per_img = int(cfg.get('nms_pre', -1)), int(cfg['max_per_img'])
+        min_size = float(cfg.get('min_bbox_size', 0))
+        L = _lib.lib()
+        props, hboxes, scores, ids = [], [], [], []
+        for idx in range(len(cls_scores)):
+            assert cls_scores[idx].shape[-2:] == bbox_preds[idx].shape[-2:]
+            logits = cls_scores[idx].permute(1, 2, 0).reshape(-1).float().contiguous()
+            deltas = bbox_preds[idx].permute(1, 2, 0).reshape(-1, 6)
+            n = logits.numel()
+            sc = torch.empty_like(logits)
+            call('sigmoid_f32', logits, sc, n)
+            order = None
+            if nms_pre > 0 and n > nms_pre:  # sort descending, keep the first nms_pre (:248-254)
+                nb = L.sm3_argsort_desc_workspace_bytes(n)
+                ws = _lib.workspace(nb, sc.device)
+                full = torch.empty(n, dtype=torch.int64, device=sc.device)
+                call('argsort_desc_f32', sc, n, full, ws, nb)
+                order = full[:nms_pre]
+            p, hb, s = self.bbox_coder.decode(mlvl_anchors[idx], deltas, max_shape=img_shape, order=order,
+                                              scores=sc)
+            props.append(p)
+            hboxes.append(hb)
+            scores.append(s)
+            ids.append(torch.full((s.numel(),), idx, dtype=torch.long, device=s.device))
+        proposals, hproposals = torch.cat(props), torch.cat(hboxes)
+        scores, ids = torch.cat(scores), torch.cat(ids)
+        if min_size > 0:
+            valid = (proposals[:, 2] >= min_size) & (proposals[:, 3] >= min_size)
+            proposals, hproposals, scores, ids = proposals[valid], hproposals[valid], scores[valid], ids[valid]
+        if proposals.numel() == 0:
+            return proposals.new_zeros(0, 5)
+        _, keep = mmcv_ops.batched_nms(hproposals, scores, ids, cfg['nms'])
+        dets = torch.cat([proposals, scores[:, None]], dim=1)[keep]
+        return dets[:max_per_img]
+
+    def get_bboxes(self, cls_scores, bbox_preds, img_metas=None, cfg=None, rescale=False, mlvl_anchors=None):
+        """per-image proposals (list of (n,6) tensors) from the multi-level head outputs"""
+        num_imgs = cls_scores[0].shape[0]
+        if mlvl_anchors is None:
+            sizes = [tuple(c.shape[-2:]) for c in cls_scores]
+            mlvl_anchors = grid_anchors(sizes, self.anchor_cfg['strides'], self.anchor_cfg.get('scales', [8]),
+                                        self.anchor_cfg.get('ratios', [1.0]), device=cls_scores[0].device)
+        out = []
+        for i in range(num_imgs):
+            shape = None if img_metas is None else img_metas[i].get('img_shape')
+            out.append(self._get_bboxes_single([c[i].detach() for c in cls_scores],
+                                               [r[i].detach() for r in bbox_preds], mlvl_anchors, shape, None, cfg,
+                                               rescale))
+        return out

@@ -63,3 +63,13 @@ def test_unsupported_options_raise():
         ConvNeXt_moe(arch='tiny', gate='linear', MoE_Block_inds=[[], [0], [], []])
     with pytest.raises(NotImplementedError):
         ConvNeXt_moe(arch='tiny', use_grn=True)
+
+
+def test_collect_by_source_matches_reference_gather_logic():
+    """host half of TriSourceDetector.gather_dict_values (trisource_H1stage_R2stage_detector.py:190-196)"""
+    import torch
+    from sm3det_amd.h2d import collect_by_source
+    data = [dict(sar=torch.zeros(2), rgb=None), dict(rgb=torch.ones(3)), dict(sar=torch.ones(2), ifr='meta')]
+    got = collect_by_source(data, ['sar', 'rgb', 'ifr'])
+    assert [t.tolist() for t in got['sar']] == [[0.0, 0.0], [1.0, 1.0]]
+    assert len(got['rgb']) == 1 and got['ifr'] == ['meta']
