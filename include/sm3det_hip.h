@@ -98,6 +98,24 @@ int sm3_roi_align_rotated_backward(const float* grad_output, const float* rois, 
                                    int pooled_h, int pooled_w, float spatial_scale, int sampling_ratio,
                                    int aligned, int clockwise, int layout, sm3_stream_t stream);
 
+/* Multi-level RoIAlignRotated = RotatedSingleRoIExtractor.forward (mmrotate/models/roi_heads/roi_extractors/
+ * rotate_single_level_roi_extractor.py:103-140) in ONE launch: RoI n reads level
+ * clamp(floor(log2(sqrt(w*h) / finest_scale + 1e-6)), 0, num_levels-1) (map_roi_levels :66-84) with that level's
+ * spatial scale; no nonzero()/gather/scatter per level, no host sync.  inputs / grad_inputs / heights / widths /
+ * scales are HOST arrays of num_levels (<= 8) entries (device pointers, ints, floats); all levels share
+ * `channels` and the layout flag.  levels_out (n_rois int32, may be NULL) receives the chosen levels.
+ * backward accumulates into grad_inputs[l] with fp32 atomics (zero them first). */
+int sm3_roi_align_rotated_multilevel_forward(const float* const* inputs, const int* heights, const int* widths,
+                                             const float* scales, int num_levels, float finest_scale,
+                                             const float* rois, float* output, int32_t* levels_out, int n_rois,
+                                             int channels, int pooled_h, int pooled_w, int sampling_ratio,
+                                             int aligned, int clockwise, int layout, sm3_stream_t stream);
+int sm3_roi_align_rotated_multilevel_backward(const float* grad_output, const float* rois,
+                                              float* const* grad_inputs, const int* heights, const int* widths,
+                                              const float* scales, int num_levels, float finest_scale, int n_rois,
+                                              int channels, int pooled_h, int pooled_w, int sampling_ratio,
+                                              int aligned, int clockwise, int layout, sm3_stream_t stream);
+
 /* =========================================================================================================
  * Backbone hot path (a): grid-level sparse-MoE ConvNeXt.  Reference: mmrotate/models/backbones/convnext_moe.py.
  * Activations are token-major (T, C) float32 = NHWC; T = B*H*W.
@@ -121,6 +139,7 @@ int sm3_roi_align_rotated_backward(const float* grad_output, const float* rois, 
 #define SM3_EPI_BIAS_SCALE_RES 3 /* aux_out = y = acc + bias ; C = aux_in + gamma[n]*rowscale[m/rows_per_scale]*y */
 #define SM3_EPI_GELU_BWD 4       /* C = acc * aux_in (aux_in = saved gelu'); optional colsum_out[g][n] = column sums of C
                                     per group = the first linear's bias gradient (needs workspace)               */
+#define SM3_EPI_BIAS_RELU 5      /* NT only: C = max(acc + bias, 0) (nn.Linear + ReLU: convfc_rbbox_head.py:176-177)  */
 typedef struct sm3_gemm_desc {
   int32_t mode, epilogue;
   const float* A;

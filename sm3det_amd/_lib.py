@@ -38,6 +38,8 @@ def _declare(lib):
         'sm3_nms_rotated': (I, [P, I, P, P, I, F, I, P, P, P, S, P]),
         'sm3_roi_align_rotated_forward': (I, [P, P, P, I, I, I, I, I, I, I, F, I, I, I, I, P]),
         'sm3_roi_align_rotated_backward': (I, [P, P, P, I, I, I, I, I, I, I, F, I, I, I, I, P]),
+        'sm3_roi_align_rotated_multilevel_forward': (I, [P, P, P, P, I, F, P, P, P, I, I, I, I, I, I, I, I, P]),
+        'sm3_roi_align_rotated_multilevel_backward': (I, [P, P, P, P, P, P, I, F, I, I, I, I, I, I, I, I, P]),
     }
     from . import _lib_backbone
     sig.update(_lib_backbone.signatures())

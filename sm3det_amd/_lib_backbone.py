@@ -7,7 +7,7 @@ import torch
 P, I, F, S = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
 
 NT, NN, TN = 0, 1, 2
-EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_SCALE_RES, EPI_GELU_BWD = 0, 1, 2, 3, 4
+EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_SCALE_RES, EPI_GELU_BWD, EPI_BIAS_RELU = 0, 1, 2, 3, 4, 5
 
 
 class GemmDesc(ctypes.Structure):

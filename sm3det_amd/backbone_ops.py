@@ -75,6 +75,41 @@ def linear(x, w, b):
     return _Linear.apply(x, w, b)
 
 
+class _LinearReLU(Function):
+    """y = relu(x @ w^T + b): bias + ReLU in the GEMM epilogue; backward masks dy with the saved output."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x, w, b = _chk(x, 'x'), _chk(w, 'w'), _chk(b, 'b')
+        M, K = x.shape
+        N = w.shape[0]
+        y = _e(M, N, like=x)
+        gemm(LB.NT, x, w, y, M, N, K, epilogue=LB.EPI_BIAS_RELU, bias=b)
+        ctx.save_for_backward(x, w, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        M, K = x.shape
+        N = w.shape[0]
+        dpre = _e(M, N, like=x)
+        call('relu_bwd', dy.contiguous(), y, dpre, M * N)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _e(M, K, like=x)
+            gemm(LB.NN, dpre, w, dx, M, K, N)
+        dw = _tn(dpre, x, N, K, M)
+        db = _e(N, like=x)
+        colsum(dpre, M, N, db)
+        return dx, dw, db
+
+
+def linear_relu(x, w, b):
+    """relu(x @ w^T + b) (nn.Linear + ReLU of the RoI head's shared fcs); K and N multiples of 32 / 4."""
+    return _LinearReLU.apply(x, w, b)
+
+
 def stem_patchify(x):
     """(B,3,H,W) NCHW image -> (B*H/4*W/4, 64) patch rows (no gradient: the image is a leaf input)."""
     x = _chk(x, 'image')

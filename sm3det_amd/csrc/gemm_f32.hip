@@ -565,6 +565,10 @@ int launch_mode(const GemmParams& p, int epi, dim3 grid, hipStream_t st) {
     SM3_LAUNCH(EPI_BIAS_GELU)
     SM3_LAUNCH(EPI_BIAS_SCALE_RES)
     SM3_LAUNCH(EPI_GELU_BWD)
+    case EPI_BIAS_RELU:  // only the x.W^T form needs it (fully-connected + ReLU of the RoI head)
+      if (MODE != MODE_NT) return SM3_ERR_INVALID_ARG;
+      gemm_f32_kernel<MODE_NT, EPI_BIAS_RELU, BK><<<grid, NTHREADS, 0, st>>>(p);
+      return SM3_OK;
   }
 #undef SM3_LAUNCH
   return SM3_ERR_INVALID_ARG;

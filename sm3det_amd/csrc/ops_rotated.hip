@@ -575,6 +575,29 @@ __device__ __forceinline__ Sample make_sample(const RoiGeom& g, int height, int 
   return s;
 }
 
+// Multi-level variant (RotatedSingleRoIExtractor.forward, mmrotate/models/roi_heads/roi_extractors/
+// rotate_single_level_roi_extractor.py:103-140): every RoI reads the pyramid level map_roi_levels (:66-84) assigns
+// to it.  The reference does nonzero() + gather + one RoIAlign launch + scatter per level (4 host syncs); here the
+// level is evaluated by the RoI's own workgroup and ONE launch serves all levels.
+constexpr int ROI_MAX_LEVELS = 8;
+struct RoiLevels {
+  const float* in[ROI_MAX_LEVELS];
+  float* gin[ROI_MAX_LEVELS];
+  int h[ROI_MAX_LEVELS], w[ROI_MAX_LEVELS];
+  float scale[ROI_MAX_LEVELS];
+  int n;
+  float finest;
+  int32_t* levels_out;
+};
+
+// scale = sqrt(w*h); floor(log2(scale / finest_scale + 1e-6)) clamped to [0, n-1]   (:81-84, fp32 like torch)
+__device__ __forceinline__ int roi_target_level(const float* __restrict__ roi, float finest, int nlev) {
+  const float sc = sqrtf(roi[3] * roi[4]);
+  float l = floorf(log2f(sc / finest + 1e-6f));
+  l = fminf(fmaxf(l, 0.f), (float)(nlev - 1));
+  return (int)l;  // NaN (negative w*h) -> 0 after the clamps above would be UB-free: fmaxf(NaN,0) = 0
+}
+
 constexpr int ROI_THREADS = 256;
 constexpr int ROI_MAX_LDS_SAMPLES = 1024;  // 32 KiB of Sample; larger adaptive grids recompute on the fly
 
@@ -582,13 +605,22 @@ constexpr int ROI_MAX_LDS_SAMPLES = 1024;  // 32 KiB of Sample; larger adaptive 
 // channels (the reference's pre_calc idea).  Phase 2: threads sweep (c, bin) in OUTPUT order -> coalesced
 // stores; layout 1 (NHWC input) sweeps c fastest -> coalesced 4-byte gathers across channels, and the tile
 // is transposed through LDS when it fits.
-template <int LAYOUT>
+template <int LAYOUT, int MULTI = 0>
 __global__ __launch_bounds__(ROI_THREADS) void roi_align_rotated_fwd_kernel(
     const float* __restrict__ input, const float* __restrict__ rois, float* __restrict__ output, int channels,
-    int height, int width, int PH, int PW, float spatial_scale, int sampling_ratio, int aligned, int clockwise) {
+    int height, int width, int PH, int PW, float spatial_scale, int sampling_ratio, int aligned, int clockwise,
+    RoiLevels lv = RoiLevels()) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   Sample* tab = (Sample*)smem;
   const int n = blockIdx.x;
+  if (MULTI) {  // block-uniform: this RoI's pyramid level
+    const int l = roi_target_level(rois + 6 * (size_t)n, lv.finest, lv.n);
+    input = lv.in[l];
+    height = lv.h[l];
+    width = lv.w[l];
+    spatial_scale = lv.scale[l];
+    if (lv.levels_out && threadIdx.x == 0) lv.levels_out[n] = l;
+  }
   const RoiGeom g = roi_geometry(rois + 6 * (size_t)n, spatial_scale, aligned, clockwise, PH, PW, sampling_ratio);
   const int bins = PH * PW;
   const int spb = g.grid_h * g.grid_w;  // samples per bin
@@ -644,14 +676,21 @@ __global__ __launch_bounds__(ROI_THREADS) void roi_align_rotated_fwd_kernel(
   }
 }
 
-template <int LAYOUT>
+template <int LAYOUT, int MULTI = 0>
 __global__ __launch_bounds__(ROI_THREADS) void roi_align_rotated_bwd_kernel(
     const float* __restrict__ grad_output, const float* __restrict__ rois, float* __restrict__ grad_input,
     int channels, int height, int width, int PH, int PW, float spatial_scale, int sampling_ratio, int aligned,
-    int clockwise) {
+    int clockwise, RoiLevels lv = RoiLevels()) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   Sample* tab = (Sample*)smem;
   const int n = blockIdx.x;
+  if (MULTI) {
+    const int l = roi_target_level(rois + 6 * (size_t)n, lv.finest, lv.n);
+    grad_input = lv.gin[l];
+    height = lv.h[l];
+    width = lv.w[l];
+    spatial_scale = lv.scale[l];
+  }
   const RoiGeom g = roi_geometry(rois + 6 * (size_t)n, spatial_scale, aligned, clockwise, PH, PW, sampling_ratio);
   const int bins = PH * PW;
   const int spb = g.grid_h * g.grid_w;
@@ -833,6 +872,75 @@ int sm3_roi_align_rotated_backward(const float* grad_output, const float* rois, 
                                                                       height, width, pooled_h, pooled_w,
                                                                       spatial_scale, sampling_ratio, aligned,
                                                                       clockwise);
+  return launch_status();
+}
+
+
+static int fill_levels(RoiLevels& lv, const float* const* inputs, float* const* grad_inputs, const int* heights,
+                       const int* widths, const float* scales, int nlev, float finest, int32_t* levels_out) {
+  if (nlev < 1 || nlev > ROI_MAX_LEVELS || !heights || !widths || !scales || !(finest > 0.f)) return SM3_ERR_INVALID_ARG;
+  for (int i = 0; i < nlev; i++) {
+    lv.in[i] = inputs ? inputs[i] : nullptr;
+    lv.gin[i] = grad_inputs ? grad_inputs[i] : nullptr;
+    if ((inputs && !inputs[i]) || (grad_inputs && !grad_inputs[i]) || heights[i] <= 0 || widths[i] <= 0)
+      return SM3_ERR_INVALID_ARG;
+    lv.h[i] = heights[i];
+    lv.w[i] = widths[i];
+    lv.scale[i] = scales[i];
+  }
+  lv.n = nlev;
+  lv.finest = finest;
+  lv.levels_out = levels_out;
+  return SM3_OK;
+}
+
+int sm3_roi_align_rotated_multilevel_forward(const float* const* inputs, const int* heights, const int* widths,
+                                             const float* scales, int num_levels, float finest_scale,
+                                             const float* rois, float* output, int32_t* levels_out, int n_rois,
+                                             int channels, int pooled_h, int pooled_w, int sampling_ratio,
+                                             int aligned, int clockwise, int layout, sm3_stream_t stream) {
+  if (n_rois < 0 || channels <= 0 || pooled_h <= 0 || pooled_w <= 0 || (layout != 0 && layout != 1) || !inputs)
+    return SM3_ERR_INVALID_ARG;
+  if (n_rois == 0) return SM3_OK;
+  if (!rois || !output) return SM3_ERR_INVALID_ARG;
+  RoiLevels lv;
+  int rc = fill_levels(lv, inputs, nullptr, heights, widths, scales, num_levels, finest_scale, levels_out);
+  if (rc) return rc;
+  size_t lds = roi_lds_bytes(pooled_h, pooled_w, sampling_ratio);
+  hipStream_t st = (hipStream_t)stream;
+  if (layout == 0)
+    roi_align_rotated_fwd_kernel<0, 1><<<n_rois, ROI_THREADS, lds, st>>>(nullptr, rois, output, channels, 0, 0,
+                                                                         pooled_h, pooled_w, 0.f, sampling_ratio,
+                                                                         aligned, clockwise, lv);
+  else
+    roi_align_rotated_fwd_kernel<1, 1><<<n_rois, ROI_THREADS, lds, st>>>(nullptr, rois, output, channels, 0, 0,
+                                                                         pooled_h, pooled_w, 0.f, sampling_ratio,
+                                                                         aligned, clockwise, lv);
+  return launch_status();
+}
+
+int sm3_roi_align_rotated_multilevel_backward(const float* grad_output, const float* rois,
+                                              float* const* grad_inputs, const int* heights, const int* widths,
+                                              const float* scales, int num_levels, float finest_scale, int n_rois,
+                                              int channels, int pooled_h, int pooled_w, int sampling_ratio,
+                                              int aligned, int clockwise, int layout, sm3_stream_t stream) {
+  if (n_rois < 0 || channels <= 0 || pooled_h <= 0 || pooled_w <= 0 || (layout != 0 && layout != 1) || !grad_inputs)
+    return SM3_ERR_INVALID_ARG;
+  if (n_rois == 0) return SM3_OK;
+  if (!rois || !grad_output) return SM3_ERR_INVALID_ARG;
+  RoiLevels lv;
+  int rc = fill_levels(lv, nullptr, grad_inputs, heights, widths, scales, num_levels, finest_scale, nullptr);
+  if (rc) return rc;
+  size_t lds = roi_lds_bytes(pooled_h, pooled_w, sampling_ratio);
+  hipStream_t st = (hipStream_t)stream;
+  if (layout == 0)
+    roi_align_rotated_bwd_kernel<0, 1><<<n_rois, ROI_THREADS, lds, st>>>(grad_output, rois, nullptr, channels, 0, 0,
+                                                                         pooled_h, pooled_w, 0.f, sampling_ratio,
+                                                                         aligned, clockwise, lv);
+  else
+    roi_align_rotated_bwd_kernel<1, 1><<<n_rois, ROI_THREADS, lds, st>>>(grad_output, rois, nullptr, channels, 0, 0,
+                                                                         pooled_h, pooled_w, 0.f, sampling_ratio,
+                                                                         aligned, clockwise, lv);
   return launch_status();
 }
 
