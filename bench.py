@@ -133,6 +133,67 @@ def ops_microbench():
             q.grad = None
         sum((o * o).mean() for o in fpn(feats)).backward()
     out['multitask_fpn_fwd_bwd_bs2_1024'] = timeit(fpn_step, n=5)
+    # Oriented-RPN head on the 5 neck outputs (tower fwd+bwd) and the proposal glue of one image (nms_pre 2000)
+    from sm3det_amd.rpn_head import OrientedRPNHead, grid_anchors
+    rpn = OrientedRPNHead(in_channels=256, feat_channels=256, version='le90',
+                          bbox_coder=dict(type='MidpointOffsetCoder', angle_range='le90', target_means=[0.0] * 6,
+                                          target_stds=[1.0, 1.0, 1.0, 1.0, 0.5, 0.5]),
+                          test_cfg=dict(nms_pre=2000, max_per_img=2000, nms=dict(type='nms', iou_threshold=0.8),
+                                        min_bbox_size=0)).cuda()
+    rpn.init_weights()
+    lv = [torch.randn(BATCH, 256, 256 >> i, 256 >> i, device='cuda').contiguous(memory_format=torch.channels_last)
+          .requires_grad_(True) for i in range(5)]
+
+    def rpn_step():
+        for q in rpn.parameters():
+            q.grad = None
+        cls, reg = rpn(lv)
+        (sum((c * c).mean() for c in cls) + sum((r * r).mean() for r in reg)).backward()
+    out['orpn_tower_fwd_bwd_bs2_5levels'] = timeit(rpn_step, n=5)
+    with torch.no_grad():
+        cls, reg = rpn(lv)
+        anchors = grid_anchors([tuple(c.shape[-2:]) for c in cls], [4, 8, 16, 32, 64])
+        c0, r0 = [c[0] for c in cls], [r[0] for r in reg]
+        out['orpn_proposals_one_image'] = timeit(lambda: rpn._get_bboxes_single(c0, r0, anchors, (1024, 1024, 3)), n=5)
+    # RoI path: fused multi-level extractor vs the reference's per-level loop over the single-level op, 1024 RoIs
+    from sm3det_amd.roi_head import RotatedShared2FCBBoxHead, RotatedSingleRoIExtractor
+    ext = RotatedSingleRoIExtractor(dict(type='RoIAlignRotated', out_size=7, sample_num=2, clockwise=True), 256,
+                                    [4, 8, 16, 32])
+    gr = torch.Generator().manual_seed(12)
+    rr = torch.zeros(1024, 6)
+    rr[:, 0] = torch.randint(0, BATCH, (1024,), generator=gr).float()
+    rr[:, 1:3] = torch.rand(1024, 2, generator=gr) * 1024
+    rr[:, 3] = torch.exp(torch.rand(1024, generator=gr) * 4.2 + 2.0)
+    rr[:, 4] = rr[:, 3] * (0.3 + torch.rand(1024, generator=gr))
+    rr[:, 5] = (torch.rand(1024, generator=gr) - 0.5) * 3.1
+    rr = rr.cuda()
+    f4 = lv[:4]
+    out['roi_extract_fused_1024rois_fwd'] = timeit(lambda: ext(f4, rr))
+    ro = ext(f4, rr)
+    gro = torch.randn_like(ro)
+    out['roi_extract_fused_1024rois_bwd'] = timeit(lambda: torch.autograd.grad(ro, f4, gro, retain_graph=True), n=5)
+    layers = [ops.RoIAlignRotated(output_size=7, spatial_scale=1.0 / s, sampling_ratio=2, clockwise=True)
+              for s in (4, 8, 16, 32)]
+
+    def per_level_loop():  # rotate_single_level_roi_extractor.py:128-140
+        tl = ext.map_roi_levels(rr, 4)
+        res = torch.zeros(1024, 256, 7, 7, device='cuda')
+        for i in range(4):
+            inds = (tl == i).nonzero(as_tuple=False).squeeze(1)
+            if inds.numel() > 0:
+                res[inds] = layers[i](f4[i].detach(), rr[inds])
+        return res
+    out['roi_extract_per_level_loop_1024rois_fwd'] = timeit(per_level_loop)
+    head = RotatedShared2FCBBoxHead(in_channels=256, fc_out_channels=1024, roi_feat_size=7, num_classes=26,
+                                    reg_class_agnostic=True).cuda()
+    xf = ro.detach().requires_grad_(True)
+
+    def head_step():
+        for q in head.parameters():
+            q.grad = None
+        a, b = head(xf)
+        ((a * a).mean() + (b * b).mean()).backward()
+    out['shared2fc_head_fwd_bwd_1024rois'] = timeit(head_step, n=5)
     return {k: round(v, 1) for k, v in out.items()}
 
 
