@@ -344,11 +344,18 @@ def main():
     # ---- roofline of the dominant kernel: one more identical step with HIP events around every launch ---------
     roofline = None
     kernels = {}
-    # every rank runs the step (it contains the bucket all-reduces); only rank 0 records the per-launch events
+    # every rank runs the step (it contains the bucket all-reduces); only rank 0 records the per-launch events.
+    # The weight-gradient side stream is switched off for this pass: per-kernel durations must be those of the kernel
+    # alone (two kernels sharing the chip would each look slower), which is also what SM3_WGRAD_STREAM=0 + rocprofv3
+    # --kernel-trace reports (profiles/).
+    from sm3det_amd import backbone_ops as _bops
+    overlap_was = _bops.OVERLAP_WGRAD
+    _bops.OVERLAP_WGRAD = False
     if rank == 0:
         LB.PROFILE = []
     step()
     torch.cuda.synchronize()
+    _bops.OVERLAP_WGRAD = overlap_was
     if rank == 0:
         prof, LB.PROFILE = LB.PROFILE, None
         for name, flops, nbytes, e0, e1 in prof:
@@ -392,6 +399,7 @@ def main():
                                    f'randn({BATCH},3,{RES},{RES}) per GPU, random-init weights; FPN/heads excluded',
                        'global_batch': world * BATCH, 'resolution': RES, 'parallelism': f'dp{world}',
                        'grad_buckets': reducer.num_buckets, 'hip_graph': bool(use_graph),
+                       'wgrad_side_stream': bool(overlap_was),
                        'replica_checksum_spread': replica_spread},
             'loss': float(loss.detach()),
             'roofline': roofline,

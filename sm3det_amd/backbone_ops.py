@@ -12,6 +12,8 @@ Each ``torch.autograd.Function`` below is one unit of the reference's backbone
 
 Activations are token-major (T, C) fp32.  No host synchronisation happens anywhere in here.
 """
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -30,6 +32,38 @@ def _chk(t, name):
         raise SM3Error(f'{name}: expected a float32 tensor on the GPU (got {t.dtype} on {t.device}); '
                        'there is no CPU/eager fallback')
     return t.contiguous()
+
+
+# ---- weight-gradient side stream -------------------------------------------------------------------------------
+# The weight / bias gradient kernels of a block (split-K TN GEMMs, column sums, gate-parameter backward, depthwise
+# weight gradient) feed nothing in the dx chain.  They are enqueued on ONE side stream, forked after the tensors they
+# read exist and joined at the end of the block's backward, so the chip runs them underneath the latency-bound small
+# kernels of the dx chain (router, LayerNorm, combine, depthwise) and the tails of the dgrad GEMMs.  Works the same
+# eagerly and under hipGraph capture (the fork/join become graph edges).  SM3_WGRAD_STREAM=0 disables it.
+OVERLAP_WGRAD = os.environ.get('SM3_WGRAD_STREAM', '1') != '0'
+_SIDE = {}
+
+
+def _side_stream(device):
+    s = _SIDE.get(device)
+    if s is None:
+        s = _SIDE[device] = torch.cuda.Stream(device=device)
+    return s
+
+
+def _on_side(device, fn):
+    """run fn (kernel launches only) on the side stream, after everything enqueued so far on the current stream"""
+    if not OVERLAP_WGRAD:
+        return fn()
+    main, side = torch.cuda.current_stream(device), _side_stream(device)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        return fn()
+
+
+def _join_side(device):
+    if OVERLAP_WGRAD:
+        torch.cuda.current_stream(device).wait_stream(_side_stream(device))
 
 
 def _tn(dy, x, M, N, rows, **kw):
@@ -60,13 +94,17 @@ class _Linear(Function):
         dy = dy.contiguous()
         M, K = x.shape
         N = w.shape[0]
+        db = _e(N, like=x)
+
+        def wgrad():
+            colsum(dy, M, N, db)
+            return _tn(dy, x, N, K, M)
+        dw = _on_side(x.device, wgrad)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = _e(M, K, like=x)
             gemm(LB.NN, dy, w, dx, M, K, N)
-        dw = _tn(dy, x, N, K, M)
-        db = _e(N, like=x)
-        colsum(dy, M, N, db)
+        _join_side(x.device)
         return dx, dw, db
 
 
@@ -169,11 +207,11 @@ def _dw_ln_backward(dxn, dout, x, u, w49, lnw, mean, rstd, B, H, W, C):
     dwdb = _e(2, C, like=x)
     ws, nb = LB.row_ws(C, x)
     call('layernorm_bwd', dxn, u, lnw, mean, rstd, du, dwdb, T, C, 0, H, W, 0, ws, nb)
-    dx = _e(T, C, like=x)
-    call('dwconv7_fwd', du, w49, None, dout, dx, B, H, W, C, 1)  # flip=1: correlation with the reversed taps
     dwb = _e(50, C, like=x)  # [dw49 (49,C); dbias (C)] in one buffer: one fill inside the kernel wrapper
     dw49, dbdw = dwb[:49], dwb[49]
-    call('dwconv7_bwd_weight', x, du, dw49, dbdw, B, H, W, C)
+    _on_side(x.device, lambda: call('dwconv7_bwd_weight', x, du, dw49, dbdw, B, H, W, C))  # joined by the caller
+    dx = _e(T, C, like=x)
+    call('dwconv7_fwd', du, w49, None, dout, dx, B, H, W, C, 1)  # flip=1: correlation with the reversed taps
     return dx, dw49, dbdw, dwdb[0], dwdb[1]
 
 
@@ -205,13 +243,15 @@ class _DenseBlock(Function):
         ws, nb = LB.row_ws(C, x)
         call('scale_bwd_prep', dout, y, gamma, rs, H * W, dy, dgdb, T, C, ws, nb)
         dgamma, db2 = dgdb[0], dgdb[1]
-        dw2 = _tn(dy, act, C, Hd, T)
+        dev = x.device
+        dw2 = _on_side(dev, lambda: _tn(dy, act, C, Hd, T))
         dh, db1 = _e(T, Hd, like=x), _e(Hd, like=x)
         gemm(LB.NN, dy, w2, dh, T, Hd, C, epilogue=LB.EPI_GELU_BWD, aux_in=hpre, colsum_out=db1)
-        dw1 = _tn(dh, xn, Hd, C, T)
-        dxn = dy  # reuse the (T,C) buffer
+        dw1 = _on_side(dev, lambda: _tn(dh, xn, Hd, C, T))
+        dxn = _e(T, C, like=x)  # not dy's buffer: the side-stream wgrad may still be reading dy
         gemm(LB.NN, dh, w1, dxn, T, C, Hd)
         dx, dw49, dbdw, dlnw, dlnb = _dw_ln_backward(dxn, dout, x, u, w49, lnw, mean, rstd, B, H, W, C)
+        _join_side(dev)
         return dx, dw49, dbdw, dlnw, dlnb, dw1, db1, dw2, db2, dgamma, None, None, None, None, None
 
 
@@ -306,39 +346,48 @@ class _MoEBlock(Function):
         ws, nb = LB.row_ws(C, x)
         call('moe_combine_bwd', dout, yslot, token_slot, gates, gamma, rs, H * W, dyslot, dgate, dgamma, T, C, k, ws,
              nb)
-        # experts backward (every expert gets a -- possibly zero -- gradient: DDP-safe)
+        # experts backward (every expert gets a -- possibly zero -- gradient: DDP-safe); weight gradients on the side
+        # stream, the dx chain on this one
+        dev = x.device
         db2 = _e(E, C, like=x)
-        colsum(dyslot, S, C, db2, offsets=offsets, num_groups=E)
-        dw2 = _tn(dyslot, act, C, Hd, S, offsets=offsets, num_groups=E)
+
+        def wgrad2():
+            colsum(dyslot, S, C, db2, offsets=offsets, num_groups=E)
+            return _tn(dyslot, act, C, Hd, S, offsets=offsets, num_groups=E)
+        dw2 = _on_side(dev, wgrad2)
         dh, db1 = _e(S, Hd, like=x), _e(E, Hd, like=x)
         gemm(LB.NN, dyslot, w2, dh, S, Hd, C, epilogue=LB.EPI_GELU_BWD, aux_in=hpre, offsets=offsets, num_groups=E,
              colsum_out=db1)
-        dw1 = _tn(dh, xslot, Hd, C, S, offsets=offsets, num_groups=E)
-        dxslot = dyslot  # reuse
+        dw1 = _on_side(dev, lambda: _tn(dh, xslot, Hd, C, S, offsets=offsets, num_groups=E))
+        dxslot = _e(S, C, like=x)  # not dyslot's buffer: the side-stream wgrad may still be reading it
         gemm(LB.NN, dh, w1, dxslot, S, C, Hd, offsets=offsets, num_groups=E)
         # router backward
         nblk = _lib.lib().sm3_moe_router_partial_rows(T)
         dhcat, dcn, ds_part = _e(T, PC, like=x), _e(T, E, like=x), _e(nblk, like=x)
         call('moe_router_bwd', hcat, PC, P, snorm, scale, noise, T, E, k, int(train), top_idx, top_val, gates, clean,
              sigma, hnorm, dgate, dimp_load, dimp_load[E:], dhcat, dcn, ds_part)
-        if E % 4 == 0:
-            dsn = _e(P, E, like=x)
-            tiles = (P + 127) // 128
-            gemm(LB.TN, hcat, dcn, dsn, P, E, T, lda=PC, ldb=E, splits=LB.tn_splits(tiles, T))
-        else:  # tiny (P x E) product; E not a multiple of the 16-byte vector width
-            dsn = (hcat[:, :P].t() @ dcn).contiguous()
-        dwcat = _tn(dhcat, xn, PC, C, T)
-        dbcat = _e(PC, like=x)
-        colsum(dhcat, T, PC, dbcat)
-        # gate parameters: [Wp; Wn^T] rows, normalize and exp(clamp) backward in one launch
+        # gate parameters ([Wp; Wn^T] rows, normalize and exp(clamp) backward in one launch) -- side stream
         dwp, dbp, dwn = _e(P, C, like=x), _e(P, like=x), _e(C, E, like=x)
         dsim, dtemp = _e(P, E, like=x), _e(1, like=x)
-        call('moe_gate_prep_bwd', dwcat, dbcat, dsn, ds_part, nblk, sim.contiguous(), temp, clamp_max, P, C, E, dwp,
-             dbp, dwn, dsim, dtemp)
+
+        def gate_wgrad():
+            if E % 4 == 0:
+                dsn = _e(P, E, like=x)
+                tiles = (P + 127) // 128
+                gemm(LB.TN, hcat, dcn, dsn, P, E, T, lda=PC, ldb=E, splits=LB.tn_splits(tiles, T))
+            else:  # tiny (P x E) product; E not a multiple of the 16-byte vector width
+                dsn = (hcat[:, :P].t() @ dcn).contiguous()
+            dwcat = _tn(dhcat, xn, PC, C, T)
+            dbcat = _e(PC, like=x)
+            colsum(dhcat, T, PC, dbcat)
+            call('moe_gate_prep_bwd', dwcat, dbcat, dsn, ds_part, nblk, sim.contiguous(), temp, clamp_max, P, C, E,
+                 dwp, dbp, dwn, dsim, dtemp)
+        _on_side(dev, gate_wgrad)
         dxn = _e(T, C, like=x)
         gemm(LB.NN, dhcat, wcat, dxn, T, C, PC)
         call('moe_gather_add', dxslot, token_slot, dxn, T, C, k, 1)
         dx, dw49, dbdw, dlnw, dlnb = _dw_ln_backward(dxn, dout, x, u, w49, lnw, mean, rstd, B, H, W, C)
+        _join_side(dev)
         return (dx, dw49, dbdw, dlnw, dlnb, dwp, dbp, dwn, dsim, dtemp.reshape(temp.shape), dw1, db1, dw2, db2, dgamma,
                 None, None, None, None, None, None, None, None, None, None)
 
