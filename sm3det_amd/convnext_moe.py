@@ -96,11 +96,6 @@ class FFN(nn.Module):
         self.grn = None
 
 
-def _pad_rows(n):
-    """rows of the fused [Wp; Wn^T; 0] gate matrix: next multiple of 32."""
-    return (n + 31) // 32 * 32
-
-
 class MoE_layer(nn.Module):
     """Sparse MoE FFN (reference :108-248): cosine top-k gate with noisy gating, E experts, aux load loss.
 
@@ -166,17 +161,6 @@ class MoE_layer(nn.Module):
         if x.shape[0] == 1:
             return x.new_zeros(())
         return x.float().var() / (x.float().mean() ** 2 + eps)
-
-    def gate_inputs(self):
-        """Fused gate matrix [Wp; Wn^T; 0] (PC, C), bias [bp; 0], normalised sim matrix and logit scale."""
-        g = self.w_gate
-        P, E, C = g.proj_dim, self.num_experts, self.input_size
-        PC = _pad_rows(P + E)
-        pad = PC - P - E
-        wcat = torch.cat([g.cosine_projector.weight, self.w_noise.t(), self.w_noise.new_zeros(pad, C)], 0)
-        bcat = torch.cat([g.cosine_projector.bias, self.w_noise.new_zeros(PC - P)], 0)
-        snorm, scale = g.normalized_sim_and_scale()
-        return wcat.contiguous(), bcat, snorm, scale, P
 
 
 class DepthwiseConv7x7(nn.Module):

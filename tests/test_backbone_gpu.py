@@ -369,3 +369,63 @@ def test_gate_prep_and_aux_loss_vs_torch_autograd(P, C, E):
     dtot = torch.empty(2 * E, device='cuda')
     LB.call('moe_aux_loss_bwd', tot, torch.tensor([3.0], device='cuda'), E, 1e-2, dtot, dtot[E:])
     torch.testing.assert_close(dtot.cpu(), rp.grad[0], rtol=1e-3, atol=1e-9)
+
+
+# ------------------------------------------------------------------------------------------ BASELINE.json sizes
+def test_baseline_config1_plain_convnext_t_512_vs_oracle():
+    """BASELINE configs[0]: ConvNeXt-T without MoE blocks, 1x3x512x512 random tensor, forward (the reference's own
+    CPU-runnable case) -- all four outputs against the CPU oracle."""
+    from oracle import moe_oracle as MO
+    from sm3det_amd.convnext_moe import ConvNeXt_moe_MultiInput
+    torch.manual_seed(3)
+    net = ConvNeXt_moe_MultiInput(arch='tiny')
+    with torch.no_grad():
+        for n, p in net.named_parameters():
+            if n.endswith('gamma'):
+                p.fill_(0.5)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    x = torch.randn(1, 3, 512, 512, generator=torch.Generator().manual_seed(4))
+    net = net.cuda().eval()
+    with torch.no_grad():
+        outs = net(x.cuda(), ['single'])
+        ref = MO.backbone_forward(x, sd, arch='tiny')
+    assert isinstance(outs, tuple) and [tuple(o.shape) for o in outs] == [(1, 96, 128, 128), (1, 192, 64, 64),
+                                                                           (1, 384, 32, 32), (1, 768, 16, 16)]
+    for o, r in zip(outs, ref):
+        assert rel_err(o, r) < FWD_TOL
+
+
+def test_full_size_1024_bs2_size_independent_properties():
+    """BASELINE configs[1] at its real size (ConvNeXt-T e8t2, bs 2, 1024^2), where the CPU oracle would take minutes:
+    (i) per-image independence in eval mode -- the batch-of-2 forward equals the two single-image forwards (tokens are
+    routed independently, so expert-major regrouping must not leak between images);
+    (ii) routing conservation -- every MoE block dispatched exactly T*k slots and its importance sums to T;
+    (iii) one training step gives finite gradients for every parameter, including all experts."""
+    import bench
+    net = bench.build_model().cuda()
+    x = torch.randn(2, 3, 1024, 1024, generator=torch.Generator().manual_seed(6)).cuda()
+    net.eval()
+    with torch.no_grad():
+        o2, _ = net(x, ['single'])
+        oa, _ = net(x[:1], ['single'])
+        ob, _ = net(x[1:], ['single'])
+    for full, a, b in zip(o2, oa, ob):
+        assert rel_err(full[:1], a) < 1e-5 and rel_err(full[1:], b) < 1e-5
+    net.train()
+    outs, gl = net(x, ['single'])
+    res, n_moe = 256, 0
+    for i, stage in enumerate(net.stages):
+        if i > 0:
+            res //= 2
+        for blk in stage:
+            if blk.MoE_cfg is not None:
+                T = 2 * res * res
+                moe = blk.ffn
+                assert int(moe.last_expert_offsets[-1]) == T * moe.k
+                imp = moe.last_importance_load[:moe.num_experts]
+                assert abs(float(imp.sum()) / T - 1.0) < 1e-4
+                n_moe += 1
+    assert n_moe == 9
+    (sum((o * o).mean() for o in outs) + gl).backward()
+    for n, p in net.named_parameters():
+        assert p.grad is not None and bool(torch.isfinite(p.grad).all()), n
