@@ -217,6 +217,11 @@ int sm3_layernorm_fwd(const float* x, const float* w, const float* b, float eps,
                       long T, int C, int out_mode, int H, int W, sm3_stream_t stream);
 /* scratch for the column reductions of layernorm_bwd / scale_bwd_prep / moe_combine_bwd (per-block partials) */
 size_t sm3_row_reduce_workspace_bytes(int C);
+/* The three kernels reduce their partials themselves unless their reduction output (dwdb / dgamma_db / dgamma) is NULL;
+ * then the caller finishes with sm3_row_partials_reduce(workspace, sm3_row_partial_blocks(T, C), ncols, out) -- e.g. on a
+ * side stream, since the results are parameter gradients (ncols = 2C, 2C, C respectively). */
+int sm3_row_partial_blocks(long T, int C);
+int sm3_row_partials_reduce(const float* partials, int nblocks, int ncols, float* out, sm3_stream_t stream);
 int sm3_layernorm_bwd(const float* dy, const float* x, const float* w, const float* mean, const float* rstd,
                       float* dx, float* dwdb, long T, int C, int out_mode, int H, int W, int accumulate_dx,
                       void* workspace, size_t workspace_bytes, sm3_stream_t stream);

@@ -66,6 +66,13 @@ def _join_side(device):
         torch.cuda.current_stream(device).wait_stream(_side_stream(device))
 
 
+def _deferred_reduce(ws, T, C, ncols, out):
+    """column reduction of a row kernel's per-workgroup partials (parameter gradients) on the side stream"""
+    from . import _lib
+    nblk = _lib.lib().sm3_row_partial_blocks(T, C)
+    _on_side(out.device, lambda: call('row_partials_reduce', ws, nblk, ncols, out))
+
+
 def _tn(dy, x, M, N, rows, **kw):
     """dW[M,N] = dy[rows,M]^T @ x[rows,N] (split-K)."""
     groups = kw.get('num_groups', 1)
@@ -206,7 +213,8 @@ def _dw_ln_backward(dxn, dout, x, u, w49, lnw, mean, rstd, B, H, W, C):
     du = _e(T, C, like=x)
     dwdb = _e(2, C, like=x)
     ws, nb = LB.row_ws(C, x)
-    call('layernorm_bwd', dxn, u, lnw, mean, rstd, du, dwdb, T, C, 0, H, W, 0, ws, nb)
+    call('layernorm_bwd', dxn, u, lnw, mean, rstd, du, None, T, C, 0, H, W, 0, ws, nb)
+    _deferred_reduce(ws, T, C, 2 * C, dwdb)  # d(ln weight) | d(ln bias); joined by the caller
     dwb = _e(50, C, like=x)  # [dw49 (49,C); dbias (C)] in one buffer: one fill inside the kernel wrapper
     dw49, dbdw = dwb[:49], dwb[49]
     _on_side(x.device, lambda: call('dwconv7_bwd_weight', x, du, dw49, dbdw, B, H, W, C))  # joined by the caller
@@ -241,9 +249,10 @@ class _DenseBlock(Function):
         dout = dout.contiguous()
         dy, dgdb = _e(T, C, like=x), _e(2, C, like=x)
         ws, nb = LB.row_ws(C, x)
-        call('scale_bwd_prep', dout, y, gamma, rs, H * W, dy, dgdb, T, C, ws, nb)
-        dgamma, db2 = dgdb[0], dgdb[1]
         dev = x.device
+        call('scale_bwd_prep', dout, y, gamma, rs, H * W, dy, None, T, C, ws, nb)
+        _deferred_reduce(ws, T, C, 2 * C, dgdb)
+        dgamma, db2 = dgdb[0], dgdb[1]
         dw2 = _on_side(dev, lambda: _tn(dy, act, C, Hd, T))
         dh, db1 = _e(T, Hd, like=x), _e(Hd, like=x)
         gemm(LB.NN, dy, w2, dh, T, Hd, C, epilogue=LB.EPI_GELU_BWD, aux_in=hpre, colsum_out=db1)
@@ -344,8 +353,8 @@ class _MoEBlock(Function):
         # combine backward
         dyslot, dgate, dgamma = _e(S, C, like=x), _e(T, k, like=x), _e(C, like=x)
         ws, nb = LB.row_ws(C, x)
-        call('moe_combine_bwd', dout, yslot, token_slot, gates, gamma, rs, H * W, dyslot, dgate, dgamma, T, C, k, ws,
-             nb)
+        call('moe_combine_bwd', dout, yslot, token_slot, gates, gamma, rs, H * W, dyslot, dgate, None, T, C, k, ws, nb)
+        _deferred_reduce(ws, T, C, C, dgamma)
         # experts backward (every expert gets a -- possibly zero -- gradient: DDP-safe); weight gradients on the side
         # stream, the dx chain on this one
         dev = x.device

@@ -624,12 +624,30 @@ int sm3_layernorm_fwd(const float* x, const float* w, const float* b, float eps,
   return launch_status();
 }
 
+// number of per-workgroup partial rows the row kernels (layernorm_bwd, scale_bwd_prep, moe_combine_bwd) leave in the
+// workspace for (T, C); with the reduction output pointer NULL those kernels skip their own reduce and the caller
+// runs sm3_row_partials_reduce -- on another stream if it likes (the results are parameter gradients).
+int sm3_row_partial_blocks(long T, int C) {
+  if (T <= 0 || C <= 0 || (C & 3)) return 0;
+  int nb = 0;
+#define CALL(G, NV) nb = row_blocks_capped(T, G)
+  SM3_ROW_DISPATCH(C, CALL);
+#undef CALL
+  return nb;
+}
+
+int sm3_row_partials_reduce(const float* partials, int nblocks, int ncols, float* out, sm3_stream_t stream) {
+  if (!partials || !out || nblocks <= 0 || ncols <= 0) return SM3_ERR_INVALID_ARG;
+  partials_reduce_kernel<<<(ncols + 63) / 64, 256, 0, (hipStream_t)stream>>>(partials, nblocks, ncols, out);
+  return launch_status();
+}
+
 size_t sm3_row_reduce_workspace_bytes(int C) { return (size_t)ROW_MAX_BLOCKS * 2 * (C > 0 ? C : 1) * sizeof(float); }
 
 int sm3_layernorm_bwd(const float* dy, const float* x, const float* w, const float* mean, const float* rstd,
                       float* dx, float* dwdb, long T, int C, int out_mode, int H, int W, int accumulate_dx,
                       void* workspace, size_t workspace_bytes, sm3_stream_t stream) {
-  if (!dy || !x || !w || !mean || !rstd || !dx || !dwdb || !workspace || T <= 0 || C <= 0 || (C & 3))
+  if (!dy || !x || !w || !mean || !rstd || !dx || !workspace || T <= 0 || C <= 0 || (C & 3))
     return SM3_ERR_INVALID_ARG;
   if (workspace_bytes < sm3_row_reduce_workspace_bytes(C)) return SM3_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
@@ -641,7 +659,7 @@ int sm3_layernorm_bwd(const float* dy, const float* x, const float* w, const flo
   layernorm_bwd_kernel<G, NV><<<nb, 256, lds, st>>>(dy, x, w, mean, rstd, dx, part, T, C, out_mode, H, W, accumulate_dx)
   SM3_ROW_DISPATCH(C, CALL);
 #undef CALL
-  partials_reduce_kernel<<<(2 * C + 63) / 64, 256, 0, st>>>(part, nb, 2 * C, dwdb);
+  if (dwdb) partials_reduce_kernel<<<(2 * C + 63) / 64, 256, 0, st>>>(part, nb, 2 * C, dwdb);
   return launch_status();
 }
 
@@ -689,8 +707,7 @@ int sm3_dwconv7_bwd_weight(const float* x, const float* du, float* dw49, float* 
 int sm3_scale_bwd_prep(const float* dout, const float* y, const float* gamma, const float* rowscale,
                        int rows_per_scale, float* dy, float* dgamma_db, long T, int C, void* workspace,
                        size_t workspace_bytes, sm3_stream_t stream) {
-  if (!dout || !y || !gamma || !dy || !dgamma_db || !workspace || T <= 0 || C <= 0 || (C & 3))
-    return SM3_ERR_INVALID_ARG;
+  if (!dout || !y || !gamma || !dy || !workspace || T <= 0 || C <= 0 || (C & 3)) return SM3_ERR_INVALID_ARG;
   if (workspace_bytes < sm3_row_reduce_workspace_bytes(C)) return SM3_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   if (rows_per_scale <= 0) rows_per_scale = 1;
@@ -702,7 +719,7 @@ int sm3_scale_bwd_prep(const float* dout, const float* y, const float* gamma, co
   scale_bwd_prep_kernel<G, NV><<<nb, 256, lds, st>>>(dout, y, gamma, rowscale, rows_per_scale, dy, part, T, C)
   SM3_ROW_DISPATCH(C, CALL);
 #undef CALL
-  partials_reduce_kernel<<<(2 * C + 63) / 64, 256, 0, st>>>(part, nb, 2 * C, dgamma_db);
+  if (dgamma_db) partials_reduce_kernel<<<(2 * C + 63) / 64, 256, 0, st>>>(part, nb, 2 * C, dgamma_db);
   return launch_status();
 }
 
@@ -749,8 +766,8 @@ int sm3_moe_combine_bwd(const float* dout, const float* yslot, const int32_t* to
                         const float* gamma, const float* rowscale, int rows_per_scale, float* dyslot, float* dgate,
                         float* dgamma, long T, int C, int k, void* workspace, size_t workspace_bytes,
                         sm3_stream_t stream) {
-  if (!dout || !yslot || !token_slot || !gates || !gamma || !dyslot || !dgate || !dgamma || !workspace || T <= 0 ||
-      C <= 0 || (C & 3) || k < 1)
+  if (!dout || !yslot || !token_slot || !gates || !gamma || !dyslot || !dgate || !workspace || T <= 0 || C <= 0 ||
+      (C & 3) || k < 1)
     return SM3_ERR_INVALID_ARG;
   if (workspace_bytes < sm3_row_reduce_workspace_bytes(C)) return SM3_ERR_WORKSPACE;
   if (rows_per_scale <= 0) rows_per_scale = 1;
@@ -764,7 +781,7 @@ int sm3_moe_combine_bwd(const float* dout, const float* yslot, const int32_t* to
                                                       dyslot, dgate, part, T, C, k)
   SM3_ROW_DISPATCH(C, CALL);
 #undef CALL
-  partials_reduce_kernel<<<(C + 63) / 64, 256, 0, st>>>(part, nb, C, dgamma);
+  if (dgamma) partials_reduce_kernel<<<(C + 63) / 64, 256, 0, st>>>(part, nb, C, dgamma);
   return launch_status();
 }
 
