@@ -15,6 +15,8 @@
 
 namespace {
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 constexpr int OPT_CHUNK = 16384;  // elements per workgroup
 constexpr int OPT_THREADS = 256;
 
@@ -35,7 +37,15 @@ __global__ __launch_bounds__(OPT_THREADS) void grad_sumsq_kernel(TensorTable tt,
   const int64_t base = (int64_t)ck * OPT_CHUNK;
   const int64_t end = min(n, base + OPT_CHUNK);
   float s = 0.f;
-  for (int64_t i = base + threadIdx.x; i < end; i += OPT_THREADS) {
+  const int64_t len = end - base;
+  const bool vec = ((reinterpret_cast<uintptr_t>(g + base) & 15) == 0);  // 16-byte lanes when the chunk is aligned
+  const int64_t nv = vec ? (len >> 2) : 0;
+  const f32x4* __restrict__ g4 = reinterpret_cast<const f32x4*>(g + base);
+  for (int64_t i = threadIdx.x; i < nv; i += OPT_THREADS) {
+    const f32x4 x = g4[i];
+    s += (x[0] * x[0] + x[1] * x[1]) + (x[2] * x[2] + x[3] * x[3]);
+  }
+  for (int64_t i = base + 4 * nv + threadIdx.x; i < end; i += OPT_THREADS) {
     const float x = g[i];
     s += x * x;
   }
@@ -104,7 +114,33 @@ __global__ __launch_bounds__(OPT_THREADS) void adamw_multi_kernel(TensorTable tt
   const float step_size = l / bc1;
   const float inv_sqrt_bc2 = 1.f / sqrtf(bc2);
   const float decay = 1.f - l * w;
-  for (int64_t i = base + threadIdx.x; i < end; i += OPT_THREADS) {
+  // 16-byte lanes over the aligned body of the chunk (tensors come 256-byte aligned from the allocator and chunks are
+  // 64 KiB, so only views at odd offsets and the tail of the last chunk take the scalar loop below)
+  const bool vec = (((reinterpret_cast<uintptr_t>(p + base) | reinterpret_cast<uintptr_t>(g + base) |
+                      reinterpret_cast<uintptr_t>(m + base) | reinterpret_cast<uintptr_t>(v + base)) & 15) == 0);
+  const int64_t nv = vec ? ((end - base) >> 2) : 0;
+  f32x4* __restrict__ p4 = reinterpret_cast<f32x4*>(p + base);
+  const f32x4* __restrict__ g4 = reinterpret_cast<const f32x4*>(g + base);
+  f32x4* __restrict__ m4 = reinterpret_cast<f32x4*>(m + base);
+  f32x4* __restrict__ v4 = reinterpret_cast<f32x4*>(v + base);
+  for (int64_t i = threadIdx.x; i < nv; i += OPT_THREADS) {
+    const f32x4 gq = g4[i], mq = m4[i], vq = v4[i], pq = p4[i];
+    f32x4 mo, vo, po;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const float gi = gq[e] * coef;
+      const float mi = beta1 * mq[e] + (1.f - beta1) * gi;
+      const float vi = beta2 * vq[e] + (1.f - beta2) * gi * gi;
+      mo[e] = mi;
+      vo[e] = vi;
+      const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+      po[e] = pq[e] * decay - step_size * (mi / denom);
+    }
+    m4[i] = mo;
+    v4[i] = vo;
+    p4[i] = po;
+  }
+  for (int64_t i = base + 4 * nv + threadIdx.x; i < end; i += OPT_THREADS) {
     const float gi = g[i] * coef;
     const float mi = beta1 * m[i] + (1.f - beta1) * gi;
     const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
