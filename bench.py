@@ -235,7 +235,14 @@ def main():
 
     net = build_model().cuda().train()
     params = [p for p in net.parameters() if p.requires_grad]
-    reducer = BucketedGradReducer(params, bucket_mb=64.0)
+    # N>1: the backward is replayed in two segments -- stages 3+2 (93 % of the gradient bytes) first, whose buckets are
+    # all-reduced over xGMI while the backward of stages 1+0 still runs (SM3_BENCH_SPLIT=0/1 overrides; N=1 default off)
+    split = os.environ.get('SM3_BENCH_SPLIT', '1' if world > 1 else '0') == '1'
+    LATE = ('stages.2.', 'stages.3.', 'downsample_layers.2.', 'downsample_layers.3.', 'norm2.', 'norm3.')
+    named = [(n, p) for n, p in net.named_parameters() if p.requires_grad]
+    late_params = [p for n, p in reversed(named) if n.startswith(LATE)]
+    early_params = [p for n, p in reversed(named) if not n.startswith(LATE)]
+    reducer = BucketedGradReducer(params, bucket_mb=64.0, groups=[late_params, early_params] if split else None)
     reducer.broadcast_parameters(0)
     # optimizer of local_configs/main_SM3Det.py: AdamW(lr 1e-4, betas (0.9, 0.999), wd 0.05), one param group per
     # parameter (paramwise_cfg / dynamic-lr hook), grad_clip max_norm 35 -- here one fused launch with a per-tensor lr vector
@@ -286,6 +293,31 @@ def main():
             reducer.pack_all()
             return l
 
+        def seg_late():
+            """forward + backward of everything above the stage-1 output (tokens `hb`); same loss, split by term"""
+            reducer.zero_grad()
+            outs, _ = net(x, ['single'])
+            terms, hb = net._gate_loss_terms, net._boundary_tokens
+            l_late = sum(g for i, g in terms if i >= 2) / len(terms)
+            l_early = sum(g for i, g in terms if i < 2) / len(terms)
+            for i, (o, r) in enumerate(zip(outs, proj)):
+                t = (o * r).sum() * 1e-4
+                if i >= 2:
+                    l_late = l_late + t
+                else:
+                    l_early = l_early + t
+            # autograd.grad, not backward(inputs=[..., hb]): the latter would EXECUTE hb's producer node (and free its
+            # saved tensors) instead of just capturing the gradient that arrives at it
+            grads = torch.autograd.grad(l_late, [hb] + late_params, allow_unused=True)
+            for p, g in zip(late_params, grads[1:]):
+                p.grad = g
+            reducer.pack_group(0)
+            return l_late, l_early, hb, grads[0]
+
+        def seg_early(l_early, hb, ghb):
+            torch.autograd.backward([l_early, hb], grad_tensors=[torch.ones_like(l_early), ghb], inputs=early_params)
+            reducer.pack_group(1)
+
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -297,23 +329,46 @@ def main():
         cap_kw = dict(capture_error_mode='thread_local') if world > 1 else {}
         try:
             g_fb, g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_fb, **cap_kw):
-                graph_loss = fwd_bwd()
-            keep_alive = [p.grad for p in params]  # the tensors graph A writes the gradients to  # noqa: F841
+            if split:
+                net.stage_boundary = 1
+                g_fb2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_fb, **cap_kw):
+                    l_late, l_early, hb, ghb = seg_late()
+                with torch.cuda.graph(g_fb2, pool=g_fb.pool(), **cap_kw):
+                    seg_early(l_early, hb, ghb)
+                    graph_loss = (l_late + l_early).detach()
+                net.stage_boundary = None
+            else:
+                with torch.cuda.graph(g_fb, **cap_kw):
+                    graph_loss = fwd_bwd()
+            keep_alive = [p.grad for p in params]  # the tensors the graphs write the gradients to  # noqa: F841
             g_fb.replay()
+            if split:
+                g_fb2.replay()
             reducer.finalize(repack=False)  # N>1: p.grad -> slices of the reduced buckets
             opt.refresh_grad_pointers()
             with torch.cuda.graph(g_opt, pool=g_fb.pool(), **cap_kw):
                 opt.step()
 
-            def run():
-                g_fb.replay()
-                reducer.finalize(repack=False)  # world 1: no-op; world > 1: bucketed all-reduce + mean
-                g_opt.replay()
-                return graph_loss
+            if split:
+                def run():
+                    g_fb.replay()                      # forward + backward of stages 3, 2 (+ pack of their buckets)
+                    reducer.allreduce_group_async(0)   # RCCL stream: overlaps with ...
+                    g_fb2.replay()                     # ... the backward of stages 1, 0 (+ pack)
+                    reducer.allreduce_group_async(1)
+                    reducer.finalize(repack=False)
+                    g_opt.replay()
+                    return graph_loss
+            else:
+                def run():
+                    g_fb.replay()
+                    reducer.finalize(repack=False)  # world 1: no-op; world > 1: bucketed all-reduce + mean
+                    g_opt.replay()
+                    return graph_loss
         except Exception as e:  # keep the measurement alive: eager launches, all-reduces overlapped with backward
             print(f'[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly', file=sys.stderr)
             use_graph = False
+            net.stage_boundary = None
             reducer.overlap = True
             torch.cuda.synchronize()
             run = step
@@ -399,7 +454,7 @@ def main():
                                    f'randn({BATCH},3,{RES},{RES}) per GPU, random-init weights; FPN/heads excluded',
                        'global_batch': world * BATCH, 'resolution': RES, 'parallelism': f'dp{world}',
                        'grad_buckets': reducer.num_buckets, 'hip_graph': bool(use_graph),
-                       'wgrad_side_stream': bool(overlap_was),
+                       'wgrad_side_stream': bool(overlap_was), 'split_backward': bool(split and use_graph),
                        'replica_checksum_spread': replica_spread},
             'loss': float(loss.detach()),
             'roofline': roofline,

@@ -378,6 +378,11 @@ class ConvNeXt_moe(nn.Module):
         tok = ops.linear(a, w64, conv.bias)
         H, W = Hi // 4, Wi // 4
         outs, gate_losses = [], []
+        # optional (data-parallel comm/compute overlap, see bench.py): remember the token tensor leaving stage
+        # `stage_boundary` and the per-block gate losses with their stage, so a caller can run the backward in two
+        # segments (late stages first, their gradient buckets all-reduce while the early stages' backward runs)
+        boundary = getattr(self, 'stage_boundary', None)
+        self._boundary_tokens, self._gate_loss_terms = None, []
         if self.training and (noise is None or drop_scale is None):
             gen_noise, gen_drop = self._step_randomness(B, H, W, x.device)
             noise = gen_noise if noise is None else noise
@@ -400,6 +405,9 @@ class ConvNeXt_moe(nn.Module):
                 tok, gl = blk.forward_tokens(tok, B, H, W, noise=nz, drop_scale=ds)
                 if gl is not None:
                     gate_losses.append(gl)
+                    self._gate_loss_terms.append((i, gl))
+            if boundary is not None and i == boundary:
+                self._boundary_tokens = tok
             if i in self.out_indices:
                 norm_layer = getattr(self, f'norm{i}')
                 C = self.channels[i]

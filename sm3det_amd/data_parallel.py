@@ -27,25 +27,34 @@ import torch.distributed as dist
 
 
 class BucketedGradReducer:
-    def __init__(self, params, bucket_mb=64.0, process_group=None):
+    def __init__(self, params, bucket_mb=64.0, process_group=None, groups=None):
+        """groups: optional list of parameter lists (a partition of ``params``, in the order their gradients become
+        available); buckets never straddle two groups, so a whole group can be packed / all-reduced as soon as the
+        backward segment that produces it is done (``pack_group`` / ``allreduce_group_async``)."""
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError('no trainable parameters')
         cap = int(bucket_mb * 1024 * 1024)
-        # reverse order: the last layers' gradients are ready first
-        self.buckets = []  # dicts: flat (None when world == 1), params, views, pending, handle
-        cur, cur_bytes = [], 0
-        for p in reversed(self.params):
-            nbytes = p.numel() * p.element_size()
-            if cur and (cur_bytes + nbytes > cap or cur[0].dtype != p.dtype or cur[0].device != p.device):
-                self._close(cur)
-                cur, cur_bytes = [], 0
-            cur.append(p)
-            cur_bytes += nbytes
-        if cur:
-            self._close(cur)
+        if groups is None:
+            groups = [list(reversed(self.params))]  # reverse order: the last layers' gradients are ready first
+        else:
+            groups = [[p for p in g if p.requires_grad] for g in groups]
+            if sorted(id(p) for g in groups for p in g) != sorted(id(p) for p in self.params):
+                raise ValueError('groups must partition the trainable parameters')
+        self.buckets = []  # dicts: flat (None when world == 1), params, views, pending, handle, group
+        for gi, plist in enumerate(groups):
+            cur, cur_bytes = [], 0
+            for p in plist:
+                nbytes = p.numel() * p.element_size()
+                if cur and (cur_bytes + nbytes > cap or cur[0].dtype != p.dtype or cur[0].device != p.device):
+                    self._close(cur, gi)
+                    cur, cur_bytes = [], 0
+                cur.append(p)
+                cur_bytes += nbytes
+            if cur:
+                self._close(cur, gi)
         self._index = {}
         for bi, b in enumerate(self.buckets):
             for p in b['params']:
@@ -57,7 +66,7 @@ class BucketedGradReducer:
         # are replayed from a captured hipGraph, where Python hooks do not run).
         self.overlap = True
 
-    def _close(self, plist):
+    def _close(self, plist, group=0):
         flat, views = None, None
         if self.world > 1:
             total = sum(p.numel() for p in plist)
@@ -68,7 +77,7 @@ class BucketedGradReducer:
                 views.append(flat[off:off + n].view_as(p))
                 off += n
         self.buckets.append(dict(flat=flat, params=plist, views=views, pending=len(plist), handle=None,
-                                 packed=False))
+                                 packed=False, group=group))
 
     # ------------------------------------------------------------------------------------------------ step API
     def zero_grad(self):
@@ -100,6 +109,18 @@ class BucketedGradReducer:
         """Pack every bucket now (the tail of a captured forward+backward graph; finalize() then only reduces)."""
         for b in self.buckets:
             self._pack(b)
+
+    def pack_group(self, g):
+        for b in self.buckets:
+            if b['group'] == g:
+                self._pack(b)
+
+    def allreduce_group_async(self, g):
+        """issue the all-reduces of one group's (already packed) buckets; finalize() waits for them"""
+        if self.world > 1:
+            for b in self.buckets:
+                if b['group'] == g and b['handle'] is None:
+                    b['handle'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _on_grad(self, p):
         if not self._armed:

@@ -88,6 +88,74 @@ def test_bucketed_allreduce_world2_gloo():
         assert abs(mean_rank - 0.5) < 1e-6
 
 
+def _worker_groups(rank, world, port, q):
+    """two parameter groups, each packed + all-reduced as a unit (the two-segment backward of bench.py for N>1)"""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from sm3det_amd.data_parallel import BucketedGradReducer
+        model = _model(seed=100)
+        named = list(model.named_parameters())
+        late = [p for n, p in reversed(named) if n.startswith(('body.4', 'body.2'))]
+        early = [p for n, p in reversed(named) if not n.startswith(('body.4', 'body.2'))]
+        red = BucketedGradReducer(model.parameters(), bucket_mb=0.01, groups=[late, early])
+        red.overlap = False
+        assert all(b['group'] in (0, 1) for b in red.buckets)
+        assert {id(p) for b in red.buckets if b['group'] == 0 for p in b['params']} == {id(p) for p in late}
+        g = torch.Generator().manual_seed(7)
+        X, Y = torch.randn(8, 16, generator=g), torch.randn(8, 8, generator=g)
+        xs, ys = X[rank * 4:(rank + 1) * 4], Y[rank * 4:(rank + 1) * 4]
+        red.zero_grad()
+        h = model.body[:2](xs)  # boundary activation
+        loss = ((model.body[2:](h) - ys) ** 2).mean()
+        grads = torch.autograd.grad(loss, [h] + late)  # segment 1: everything above h
+        for p, gr in zip(late, grads[1:]):
+            p.grad = gr
+        red.pack_group(0)
+        red.allreduce_group_async(0)
+        torch.autograd.backward(h, grad_tensors=grads[0], inputs=[p for p in early if p is not model.unused.weight
+                                                                  and p is not model.unused.bias])  # segment 2
+        red.pack_group(1)
+        red.allreduce_group_async(1)
+        red.finalize(repack=False)
+        ref = _model(seed=100)
+        (((ref(X) - Y) ** 2).mean()).backward()
+        err = 0.0
+        for (n, a), b in zip(model.named_parameters(), ref.parameters()):
+            if b.grad is None:
+                assert torch.count_nonzero(a.grad) == 0, n
+                continue
+            err = max(err, float((a.grad - b.grad).abs().max()))
+        q.put((rank, err))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grouped_two_segment_allreduce_world2_gloo():
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_groups, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=90) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, err in res:
+        assert err < 1e-6
+
+
+def test_groups_must_partition_parameters():
+    from sm3det_amd.data_parallel import BucketedGradReducer
+    m = _model(0)
+    ps = list(m.parameters())
+    with pytest.raises(ValueError):
+        BucketedGradReducer(ps, groups=[ps[:2], ps[3:]])
+
+
 def test_single_process_reducer_is_a_noop_mean():
     from sm3det_amd.data_parallel import BucketedGradReducer
     m = _model(0)
