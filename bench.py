@@ -9,9 +9,10 @@ Metric (BASELINE.json): train imgs/sec, SM3Det ConvNeXt-T e8t2 @1024^2, bs2/GPU.
 Workload timed here (config.workload): one TRAINING STEP of the hot path = the `main_SM3Det.py` backbone
 (ConvNeXt_moe_MultiInput, ConvNeXt-T, 8 experts top-2, MoE in stages 1-3: 9 MoE + 9 dense blocks, drop_path 0.1,
 noisy gating) forward + backward in fp32 on a synthetic (2,3,1024,1024) batch per GPU, gradient all-reduce across
-ranks (bucketed) and the optimizer step (global-norm clip 35 + AdamW with one lr per parameter, one fused launch).  The detector's FPN/heads (mmdet glue, SURVEY.md
-8(f) "next" rows) are NOT part of the timed step; the rotated-detection operators of hot path (b) are reported as
-per-op timings in `ops_us`, outside `value`.
+ranks (bucketed) and the optimizer step (global-norm clip 35 + AdamW with one lr per parameter, one fused launch).
+The workload definition is the same every round.  The pieces either side of the backbone that have been built since
+(MultitaskFPN, Oriented-RPN tower + proposal glue, fused multi-level RoI extractor, Shared2FC head) and
+the rotated-detection operators of hot path (b) are reported as per-op timings in `ops_us`, outside `value`.
 
 Printed JSON line (rank 0): the contract fields + `roofline` (dominant kernel = fp32 MFMA GEMM family, per-launch
 HIP events on the launch stream) + `cpu_baseline` (the CPU oracle timed on this host, N=1 only).
