@@ -24,8 +24,8 @@ def bench(mode, M, N, K, n=10, **kw):
 shapes = [(LB.NT, 4096, 4096, 4096), (LB.NT, 8192, 8192, 1024), (LB.NT, 16384, 1536, 384), (LB.NT, 16384, 384, 1536),
           (LB.NN, 16384, 1536, 384), (LB.NT, 131072, 384, 96), (LB.NT, 131072, 96, 384), (LB.NT, 65536, 768, 192),
           (LB.NT, 2048, 768, 3072), (LB.NT, 8192, 224, 384)]
-for bk in ('16', '32'):
-    os.environ['SM3_GEMM_BK'] = bk
-    for mode, M, N, K in shapes:
-        tf, ms = bench(mode, M, N, K)
-        print(f'BK={bk} mode={mode} {M}x{N}x{K}: {ms*1e3:8.1f} us  {tf:6.1f} TF/s', flush=True)
+# SM3_GEMM_BK / SM3_GEMM_KC are read once per process by the library: run this script once per setting
+tag = f"BK={os.environ.get('SM3_GEMM_BK', 'auto')} KC={os.environ.get('SM3_GEMM_KC', 'default')}"
+for mode, M, N, K in shapes:
+    tf, ms = bench(mode, M, N, K)
+    print(f'{tag} mode={mode} {M}x{N}x{K}: {ms*1e3:8.1f} us  {tf:6.1f} TF/s', flush=True)
