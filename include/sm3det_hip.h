@@ -203,6 +203,21 @@ int sm3_rpn_decode_le90(const float* anchors, const float* deltas, const float* 
                         const float* means6, const float* stds6, float wh_ratio_clip, float* proposals,
                         float* hboxes, float* scores_out, sm3_stream_t stream);
 
+/* Box coders of the 2-stage branch (angle version 'le90'), one thread per box, reference operation order; means /
+ * stds are HOST arrays.
+ * midpoint_offset_encode: MidpointOffsetCoder.encode = bbox2delta (delta_midpointoffset_rbbox_coder.py:87-148):
+ *   proposals (n,4) x1,y1,x2,y2 + gt (n,5) -> deltas (n,6).
+ * delta_xywha_decode / _encode: DeltaXYWHAOBBoxCoder (delta_xywha_rbbox_coder.py:112-176, :180-283), class-agnostic
+ *   (n,5) deltas, add_ctr_clamp = False; norm_factor 0 = None; max_h/max_w 0 = no max_shape clamp. */
+int sm3_midpoint_offset_encode_le90(const float* proposals, const float* gt, int n, const float* means6,
+                                    const float* stds6, float* deltas, sm3_stream_t stream);
+int sm3_delta_xywha_decode_le90(const float* rois, const float* deltas, int n, const float* means5,
+                                const float* stds5, float wh_ratio_clip, float norm_factor, int edge_swap,
+                                int proj_xy, int max_h, int max_w, float* out, sm3_stream_t stream);
+int sm3_delta_xywha_encode_le90(const float* proposals, const float* gt, int n, const float* means5,
+                                const float* stds5, float norm_factor, int edge_swap, int proj_xy, float* deltas,
+                                sm3_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * Stem: Conv2d(3,C0,k=4,s=4) (convnext_moe.py:783-791) as patchify + NT GEMM.  x (B,3,H,W) NCHW ->
  * a (B*H/4*W/4, 64), columns c*16+kh*4+kw (= weight.view(C0,48) order), columns 48..63 zero. */

@@ -12,6 +12,7 @@ from oracle.ref_moe import REF_ROOT, _Registry, _mod
 _PKG = '_sm3det_ref_pkg_bbox'
 T_FILE = os.path.join(REF_ROOT, 'mmrotate', 'core', 'bbox', 'transforms.py')
 C_FILE = os.path.join(REF_ROOT, 'mmrotate', 'core', 'bbox', 'coder', 'delta_midpointoffset_rbbox_coder.py')
+X_FILE = os.path.join(REF_ROOT, 'mmrotate', 'core', 'bbox', 'coder', 'delta_xywha_rbbox_coder.py')
 
 
 def available():
@@ -19,12 +20,13 @@ def available():
 
 
 def load():
-    """-> (transforms module, coder module)"""
+    """-> (transforms module, MidpointOffset coder module, DeltaXYWHA coder module)"""
     if not available():
         raise FileNotFoundError(T_FILE)
     tn, cn = f'{_PKG}.transforms', f'{_PKG}.coder.delta_midpointoffset_rbbox_coder'
-    if cn in sys.modules:
-        return sys.modules[tn], sys.modules[cn]
+    xn = f'{_PKG}.coder.delta_xywha_rbbox_coder'
+    if xn in sys.modules:
+        return sys.modules[tn], sys.modules[cn], sys.modules[xn]
     jit = lambda *a, **k: (lambda f: f)  # noqa: E731
     shims = {
         'cv2': _mod('cv2'),
@@ -42,7 +44,7 @@ def load():
     sys.modules.update(shims)
     try:
         mods = []
-        for name, path in ((tn, T_FILE), (cn, C_FILE)):
+        for name, path in ((tn, T_FILE), (cn, C_FILE), (xn, X_FILE)):
             spec = importlib.util.spec_from_file_location(name, path)
             mod = importlib.util.module_from_spec(spec)
             sys.modules[name] = mod

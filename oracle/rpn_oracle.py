@@ -81,6 +81,103 @@ def delta2bbox(rois, deltas, means=(0.,) * 6, stds=(1.,) * 6, wh_ratio_clip=16 /
     return poly2obb_le90(cp + center)
 
 
+def obb2poly_le90(rboxes):
+    """transforms.py:474-499"""
+    N = rboxes.shape[0]
+    if N == 0:
+        return rboxes.new_zeros((rboxes.size(0), 8))
+    x_ctr, y_ctr, width, height, angle = (rboxes.select(1, k) for k in range(5))
+    tl_x, tl_y, br_x, br_y = -width * 0.5, -height * 0.5, width * 0.5, height * 0.5
+    rects = torch.stack([tl_x, br_x, br_x, tl_x, tl_y, tl_y, br_y, br_y], dim=0).reshape(2, 4, N).permute(2, 0, 1)
+    sin, cos = torch.sin(angle), torch.cos(angle)
+    M = torch.stack([cos, -sin, sin, cos], dim=0).reshape(2, 2, N).permute(2, 0, 1)
+    polys = M.matmul(rects).permute(2, 1, 0).reshape(-1, N).transpose(1, 0)
+    polys[:, ::2] += x_ctr.unsqueeze(1)
+    polys[:, 1::2] += y_ctr.unsqueeze(1)
+    return polys.contiguous()
+
+
+def midpoint_bbox2delta(proposals, gt, means=(0.,) * 6, stds=(1.,) * 6):
+    """delta_midpointoffset_rbbox_coder.py:87-148 (version le90)"""
+    proposals, gt = proposals.float(), gt.float()
+    px = (proposals[..., 0] + proposals[..., 2]) * 0.5
+    py = (proposals[..., 1] + proposals[..., 3]) * 0.5
+    pw = proposals[..., 2] - proposals[..., 0]
+    ph = proposals[..., 3] - proposals[..., 1]
+    hbb, poly = obb2xyxy_le90(gt), obb2poly_le90(gt)
+    gx = (hbb[..., 0] + hbb[..., 2]) * 0.5
+    gy = (hbb[..., 1] + hbb[..., 3]) * 0.5
+    gw = hbb[..., 2] - hbb[..., 0]
+    gh = hbb[..., 3] - hbb[..., 1]
+    x_coor, y_coor = poly[:, 0::2], poly[:, 1::2]
+    y_min, _ = torch.min(y_coor, dim=1, keepdim=True)
+    x_max, _ = torch.max(x_coor, dim=1, keepdim=True)
+    _x_coor = x_coor.clone()
+    _x_coor[torch.abs(y_coor - y_min) > 0.1] = -1000
+    ga, _ = torch.max(_x_coor, dim=1)
+    _y_coor = y_coor.clone()
+    _y_coor[torch.abs(x_coor - x_max) > 0.1] = -1000
+    gb, _ = torch.max(_y_coor, dim=1)
+    deltas = torch.stack([(gx - px) / pw, (gy - py) / ph, torch.log(gw / pw), torch.log(gh / ph), (ga - gx) / gw,
+                          (gb - gy) / gh], dim=-1)
+    return deltas.sub_(deltas.new_tensor(means).unsqueeze(0)).div_(deltas.new_tensor(stds).unsqueeze(0))
+
+
+def xywha_bbox2delta(proposals, gt, means, stds, norm_factor=None, edge_swap=False, proj_xy=False):
+    """delta_xywha_rbbox_coder.py:112-176 (angle_range le90)"""
+    px, py, pw, ph, pa = proposals.float().unbind(dim=-1)
+    gx, gy, gw, gh, ga = gt.float().unbind(dim=-1)
+    if proj_xy:
+        dx = (torch.cos(pa) * (gx - px) + torch.sin(pa) * (gy - py)) / pw
+        dy = (-torch.sin(pa) * (gx - px) + torch.cos(pa) * (gy - py)) / ph
+    else:
+        dx, dy = (gx - px) / pw, (gy - py) / ph
+    if edge_swap:
+        dtheta1 = norm_angle(ga - pa, 'le90')
+        dtheta2 = norm_angle(ga - pa + np.pi / 2, 'le90')
+        first = torch.abs(dtheta1) < torch.abs(dtheta2)
+        da = torch.where(first, dtheta1, dtheta2)
+        dw = torch.log(torch.where(first, gw, gh) / pw)
+        dh = torch.log(torch.where(first, gh, gw) / ph)
+    else:
+        da = norm_angle(ga - pa, 'le90')
+        dw, dh = torch.log(gw / pw), torch.log(gh / ph)
+    if norm_factor:
+        da /= norm_factor * np.pi
+    deltas = torch.stack([dx, dy, dw, dh, da], dim=-1)
+    return deltas.sub_(deltas.new_tensor(means).unsqueeze(0)).div_(deltas.new_tensor(stds).unsqueeze(0))
+
+
+def xywha_delta2bbox(rois, deltas, means, stds, max_shape=None, wh_ratio_clip=16 / 1000, norm_factor=None,
+                     edge_swap=False, proj_xy=False):
+    """delta_xywha_rbbox_coder.py:180-283 (angle_range le90, add_ctr_clamp False, (N,5) deltas)"""
+    dd = deltas * deltas.new_tensor(stds).view(1, -1) + deltas.new_tensor(means).view(1, -1)
+    dx, dy, dw, dh, da = (dd[:, k::5] for k in range(5))
+    if norm_factor:
+        da = da * (norm_factor * np.pi)
+    px, py, pw, ph, pa = (rois[:, k].unsqueeze(1).expand_as(dx) for k in range(5))
+    dx_width, dy_height = pw * dx, ph * dy
+    max_ratio = np.abs(np.log(wh_ratio_clip))
+    dw = dw.clamp(min=-max_ratio, max=max_ratio)
+    dh = dh.clamp(min=-max_ratio, max=max_ratio)
+    gw, gh = pw * dw.exp(), ph * dh.exp()
+    if proj_xy:
+        gx = dx * pw * torch.cos(pa) - dy * ph * torch.sin(pa) + px
+        gy = dx * pw * torch.sin(pa) + dy * ph * torch.cos(pa) + py
+    else:
+        gx, gy = px + dx_width, py + dy_height
+    ga = norm_angle(pa + da, 'le90')
+    if max_shape is not None:
+        gx = gx.clamp(min=0, max=max_shape[1] - 1)
+        gy = gy.clamp(min=0, max=max_shape[0] - 1)
+    if edge_swap:
+        w_regular = torch.where(gw > gh, gw, gh)
+        h_regular = torch.where(gw > gh, gh, gw)
+        theta_regular = norm_angle(torch.where(gw > gh, ga, ga + np.pi / 2), 'le90')
+        return torch.stack([gx, gy, w_regular, h_regular, theta_regular], dim=-1).view_as(deltas)
+    return torch.stack([gx, gy, gw, gh, ga], dim=-1).view(deltas.size())
+
+
 def batched_nms(boxes, scores, idxs, iou_threshold):
     """mmcv batched_nms (type 'nms', below split_thr): offset trick + the plain-C NMS oracle; returns keep"""
     from oracle import ops_oracle as OO

@@ -43,6 +43,9 @@ def signatures():
         'sm3_conv3x3_nhwc_fwd': (I, [P, P, P, P, I, I, I, I, I, I, I, P, S, P]),
         'sm3_relu_bwd': (I, [P, P, P, LL, P]),
         'sm3_sigmoid_f32': (I, [P, P, LL, P]),
+        'sm3_midpoint_offset_encode_le90': (I, [P, P, I, P, P, P, P]),
+        'sm3_delta_xywha_decode_le90': (I, [P, P, I, P, P, F, F, I, I, I, I, P, P]),
+        'sm3_delta_xywha_encode_le90': (I, [P, P, I, P, P, F, I, I, P, P]),
         'sm3_rpn_decode_le90': (I, [P, P, P, P, I, P, P, F, P, P, P, P]),
         'sm3_conv3x3_nhwc_bwd_input': (I, [P, P, P, I, I, I, I, I, I, P, S, P]),
         'sm3_conv3x3_nhwc_bwd_weight_workspace_bytes': (S, [I, I, I, I, I, I]),

@@ -43,8 +43,17 @@ class MidpointOffsetCoder:
         self._stds = (ctypes.c_float * 6)(*self.stds)
 
     def encode(self, bboxes, gt_bboxes):
-        raise NotImplementedError('bbox2delta belongs to the target-assignment half (mmdet sampler/assigner) and is '
-                                  'not part of this round')
+        """reference :33-51 -> bbox2delta (:87-148): (N,4) proposals + (N,5) gt boxes -> (N,6) regression targets"""
+        if self.version != 'le90':
+            raise NotImplementedError("only angle version 'le90' (every SM3Det config) is implemented")
+        _lib.require_gpu(bboxes, gt_bboxes)
+        assert bboxes.size(0) == gt_bboxes.size(0) and bboxes.size(-1) == 4 and gt_bboxes.size(-1) == 5
+        props, gt = bboxes.float().contiguous(), gt_bboxes.float().contiguous()
+        out = torch.empty(props.shape[0], 6, device=props.device)
+        _lib.check(_lib.lib().sm3_midpoint_offset_encode_le90(LB._p(props), LB._p(gt), props.shape[0], self._means,
+                                                              self._stds, LB._p(out), _lib.stream_ptr()),
+                   'midpoint_offset_encode_le90')
+        return out
 
     def decode(self, bboxes, pred_bboxes, max_shape=None, wh_ratio_clip=16 / 1000, order=None, scores=None):
         """(N,4) anchors + (N,6) deltas -> (n,5) oriented boxes; with ``order`` (int64 permutation prefix) only the
@@ -64,6 +73,63 @@ class MidpointOffsetCoder:
                                          LB._p(order), n, self._means, self._stds, float(wh_ratio_clip),
                                          LB._p(props), LB._p(hb), LB._p(so), _lib.stream_ptr()), 'rpn_decode_le90')
         return (props, hb) if scores is None else (props, hb, so)
+
+
+class DeltaXYWHAOBBoxCoder:
+    """Mirror of ``mmrotate/core/bbox/coder/delta_xywha_rbbox_coder.py`` (class :11-108, ``bbox2delta`` :112-176,
+    ``delta2bbox`` :180-283) for angle range 'le90', class-agnostic (N,5) deltas and ``add_ctr_clamp=False`` -- the RoI
+    head's coder in main_SM3Det.py (edge_swap=True, proj_xy=True, stds (0.1,0.1,0.2,0.2,0.1))."""
+
+    def __init__(self, target_means=(0., 0., 0., 0., 0.), target_stds=(1., 1., 1., 1., 1.), angle_range='oc',
+                 norm_factor=None, edge_swap=False, proj_xy=False, add_ctr_clamp=False, ctr_clamp=32):
+        import ctypes
+        if angle_range != 'le90':
+            raise NotImplementedError("only angle_range 'le90' (every SM3Det config) is implemented")
+        if add_ctr_clamp:
+            raise NotImplementedError('add_ctr_clamp (YOLOF only) is not implemented')
+        self.means, self.stds = tuple(float(v) for v in target_means), tuple(float(v) for v in target_stds)
+        self.angle_range, self.norm_factor = angle_range, norm_factor
+        self.edge_swap, self.proj_xy = bool(edge_swap), bool(proj_xy)
+        self.add_ctr_clamp, self.ctr_clamp = add_ctr_clamp, ctr_clamp
+        self._means = (ctypes.c_float * 5)(*self.means)
+        self._stds = (ctypes.c_float * 5)(*self.stds)
+
+    def encode(self, bboxes, gt_bboxes):
+        _lib.require_gpu(bboxes, gt_bboxes)
+        assert bboxes.size(0) == gt_bboxes.size(0) and bboxes.size(-1) == 5 and gt_bboxes.size(-1) == 5
+        props, gt = bboxes.float().contiguous(), gt_bboxes.float().contiguous()
+        out = torch.empty_like(props)
+        _lib.check(_lib.lib().sm3_delta_xywha_encode_le90(LB._p(props), LB._p(gt), props.shape[0], self._means,
+                                                          self._stds, float(self.norm_factor or 0.0),
+                                                          int(self.edge_swap), int(self.proj_xy), LB._p(out),
+                                                          _lib.stream_ptr()), 'delta_xywha_encode_le90')
+        return out
+
+    def decode(self, bboxes, pred_bboxes, max_shape=None, wh_ratio_clip=16 / 1000):
+        _lib.require_gpu(bboxes, pred_bboxes)
+        assert pred_bboxes.size(0) == bboxes.size(0)
+        if pred_bboxes.size(-1) != 5 or bboxes.size(-1) != 5:
+            raise NotImplementedError('per-class deltas (reg_class_agnostic=False) are not used by the SM3Det config')
+        rois, deltas = bboxes.float().contiguous(), pred_bboxes.float().contiguous()
+        out = torch.empty_like(rois)
+        mh, mw = (int(max_shape[0]), int(max_shape[1])) if max_shape is not None else (0, 0)
+        _lib.check(_lib.lib().sm3_delta_xywha_decode_le90(LB._p(rois), LB._p(deltas), rois.shape[0], self._means,
+                                                          self._stds, float(wh_ratio_clip),
+                                                          float(self.norm_factor or 0.0), int(self.edge_swap),
+                                                          int(self.proj_xy), mh, mw, LB._p(out), _lib.stream_ptr()),
+                   'delta_xywha_decode_le90')
+        return out
+
+
+def rbbox2roi(bbox_list):
+    """mmrotate/core/bbox/transforms.py rbbox2roi: list of per-image (n,5+) boxes -> (sum n, 6) [batch_ind, box]"""
+    rois = []
+    for i, b in enumerate(bbox_list):
+        if b.size(0) > 0:
+            rois.append(torch.cat([b.new_full((b.size(0), 1), i), b[:, :5]], dim=-1))
+        else:
+            rois.append(b.new_zeros((0, 6)))
+    return torch.cat(rois, 0)
 
 
 def grid_anchors(featmap_sizes, strides, scales=(8,), ratios=(0.5, 1.0, 2.0), device='cuda'):

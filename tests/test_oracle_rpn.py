@@ -31,7 +31,7 @@ def test_oracle_matches_live_reference_functions():
     from oracle import ref_rpn
     if not ref_rpn.available():
         pytest.skip('/root/reference not present (GPU box)')
-    T, C = ref_rpn.load()
+    T, C, X = ref_rpn.load()
     MG, fx = _fixture()
     a, d = MG.seeded_case(3000)
     ref = C.delta2bbox(a, d, fx['means'], fx['stds'], 16 / 1000, 'le90')
@@ -40,6 +40,23 @@ def test_oracle_matches_live_reference_functions():
     assert torch.equal(T.obb2xyxy(ref, 'le90'), RO.obb2xyxy_le90(got))
     assert torch.equal(T.poly2obb(torch.randn(64, 8, generator=torch.Generator().manual_seed(1)), 'le90'),
                        RO.poly2obb_le90(torch.randn(64, 8, generator=torch.Generator().manual_seed(1))))
+
+
+def test_coder_oracles_match_fixture_and_live_reference():
+    MG, fx = _fixture()
+    props, gt, rois, deltas = MG.seeded_boxes()
+    assert torch.equal(RO.midpoint_bbox2delta(props, gt, fx['means'], fx['stds']), fx['midpoint_encode'])
+    for (es, pj), ref in fx['xywha'].items():
+        assert torch.equal(RO.xywha_bbox2delta(rois, gt, MG.X_MEANS, MG.X_STDS, None, es, pj), ref['encode'])
+        assert torch.equal(RO.xywha_delta2bbox(rois, deltas, MG.X_MEANS, MG.X_STDS, None, 16 / 1000, None, es, pj),
+                           ref['decode'])
+        assert torch.equal(RO.xywha_delta2bbox(rois, deltas, MG.X_MEANS, MG.X_STDS, (512, 640), 16 / 1000, None, es,
+                                               pj), ref['decode_clamped'])
+    from oracle import ref_rpn
+    if ref_rpn.available():
+        T, C, X = ref_rpn.load()
+        assert torch.equal(C.bbox2delta(props, gt, fx['means'], fx['stds'], 'le90'), fx['midpoint_encode'])
+        assert torch.equal(T.obb2poly(gt, 'le90'), RO.obb2poly_le90(gt))
 
 
 def test_proposals_oracle_properties():

@@ -138,3 +138,29 @@ def test_gather_dict_values_pinned_upload():
     lst = gather_dict_values(data, ['sar'], ignore_tensor=True, uploader=up)['sar']
     assert isinstance(lst, list) and len(lst) == 3 and torch.equal(lst[2].cpu(), data[2]['sar'])
     assert all(s[0].is_pinned() for s in up._staging.values())
+
+
+def test_box_coders_match_reference_fixture():
+    """MidpointOffsetCoder.encode and DeltaXYWHAOBBoxCoder.encode/decode kernels vs the reference-generated fixture."""
+    from sm3det_amd.rpn_head import DeltaXYWHAOBBoxCoder, MidpointOffsetCoder, rbbox2roi
+    MG, fx = _fixture()
+    props, gt, rois, deltas = MG.seeded_boxes()
+    mc = MidpointOffsetCoder(target_means=fx['means'], target_stds=fx['stds'], angle_range='le90')
+    torch.testing.assert_close(mc.encode(props.cuda(), gt.cuda()).cpu(), fx['midpoint_encode'], rtol=2e-5, atol=2e-5)
+    for (es, pj), ref in fx['xywha'].items():
+        xc = DeltaXYWHAOBBoxCoder(target_means=MG.X_MEANS, target_stds=MG.X_STDS, angle_range='le90', edge_swap=es,
+                                  proj_xy=pj)
+        enc = xc.encode(rois.cuda(), gt.cuda()).cpu()
+        # the angle target wraps at +-pi/2: compare modulo the wrap (in units of the std-normalised delta)
+        torch.testing.assert_close(enc[:, :4], ref['encode'][:, :4], rtol=2e-5, atol=2e-4)
+        wrap = math.pi / MG.X_STDS[4]
+        d = (enc[:, 4] - ref['encode'][:, 4] + wrap / 2) % wrap - wrap / 2
+        assert float(d.abs().max()) < 1e-3
+        for key, ms in (('decode', None), ('decode_clamped', (512, 640))):
+            got = xc.decode(rois.cuda(), deltas.cuda(), max_shape=ms).cpu()
+            near_square = (ref[key][:, 2] - ref[key][:, 3]).abs() < 1e-3 * ref[key][:, 2]
+            torch.testing.assert_close(got[~near_square, :4], ref[key][~near_square, :4], rtol=2e-5, atol=2e-3)
+            dd = (got[:, 4] - ref[key][:, 4] + math.pi / 2) % math.pi - math.pi / 2
+            assert float(dd[~near_square].abs().max()) < 1e-4
+    r = rbbox2roi([gt[:3].cuda(), gt[:0].cuda(), gt[3:5].cuda()])
+    assert tuple(r.shape) == (5, 6) and r[:, 0].tolist() == [0.0, 0.0, 0.0, 2.0, 2.0]
