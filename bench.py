@@ -452,7 +452,7 @@ def main():
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'main_SM3Det.py backbone (ConvNeXt_moe_MultiInput tiny, 8 experts top-2, 9 MoE + 9 '
                                    'dense blocks) fwd+bwd + bucketed grad all-reduce + grad-clip(35)+AdamW (per-parameter lr); synthetic '
-                                   f'randn({BATCH},3,{RES},{RES}) per GPU, random-init weights; FPN/heads excluded',
+                                   f'randn({BATCH},3,{RES},{RES}) per GPU, random-init weights; neck/heads timed separately in ops_us',
                        'global_batch': world * BATCH, 'resolution': RES, 'parallelism': f'dp{world}',
                        'grad_buckets': reducer.num_buckets, 'hip_graph': bool(use_graph),
                        'wgrad_side_stream': bool(overlap_was), 'split_backward': bool(split and use_graph),
