@@ -195,6 +195,27 @@ def ops_microbench():
         a, b = head(xf)
         ((a * a).mean() + (b * b).mean()).backward()
     out['shared2fc_head_fwd_bwd_1024rois'] = timeit(head_step, n=5)
+    # the pieces chained as the detector chains them for the 2-stage branch (no losses / targets: those are mmdet):
+    # backbone -> neck -> RPN tower -> proposals (no grad) -> RoI extractor -> Shared2FC, forward + backward, bs 2
+    from sm3det_amd.rpn_head import rbbox2roi
+    bb = build_model().cuda().train()
+    img = torch.randn(BATCH, 3, RES, RES, device='cuda')
+    mods = (bb, fpn, rpn, head)
+
+    def slice_step():
+        for m in mods:
+            for q in m.parameters():
+                q.grad = None
+        feats_, gl_ = bb(img, ['single'])
+        pyr = fpn(feats_)
+        cls_, reg_ = rpn(pyr)
+        props = rpn.get_bboxes(cls_, reg_, cfg=dict(nms_pre=2000, max_per_img=512,
+                                                    nms=dict(type='nms', iou_threshold=0.8), min_bbox_size=0))
+        rois_ = rbbox2roi(props)
+        a, b = head(ext(pyr[:4], rois_))
+        (gl_ + (a * a).mean() + (b * b).mean() + sum((c * c).mean() for c in cls_)
+         + sum((r * r).mean() for r in reg_)).backward()
+    out['detector_slice_fwd_bwd_bs2_1024'] = timeit(slice_step, n=3)
     return {k: round(v, 1) for k, v in out.items()}
 
 
