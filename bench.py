@@ -78,18 +78,6 @@ def cpu_baseline():
         return time.perf_counter() - t0
 
     run(1, 128)  # warm-up (allocator, MKL threads)
-    # torch's CPU kernels do not scale to every hardware thread of a large host (128 threads ran this step 4x slower
-    # than 8 on the dev box): time a small step at a few thread counts and keep the fastest, so the baseline is the
-    # best this host's CPU does, and `cores` is what was actually used
-    ncpu = os.cpu_count() or 1
-    best = (None, float('inf'))
-    for nt in sorted({min(c, ncpu) for c in (8, 16, 32, 64, ncpu)}):
-        torch.set_num_threads(nt)
-        run(1, 256)
-        t = run(1, 256)
-        if t < best[1]:
-            best = (nt, t)
-    torch.set_num_threads(best[0])
     b, res, n = 1, 512, 3
     dts = [run(b, res) for _ in range(n)]  # ~15 s of CPU work in total
     dt = sum(dts) / n
