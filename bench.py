@@ -78,13 +78,12 @@ def cpu_baseline():
         return time.perf_counter() - t0
 
     run(1, 128)  # warm-up (allocator, MKL threads)
-    b, res, n = 1, 512, 3
-    dts = [run(b, res) for _ in range(n)]  # ~15 s of CPU work in total
-    dt = sum(dts) / n
+    b, res = 1, 512
+    dt = run(b, res)
     imgs_1024 = b * (res / RES) ** 2
     return dict(value=imgs_1024 / dt, unit='imgs/sec', cores=torch.get_num_threads(), kind='port',
-                sample=f'{n} training steps (fwd+bwd) of the CPU oracle on {b}x3x{res}x{res} '
-                       f'({sum(dts):.1f} s in total, mean {dt:.1f} s per step), scaled by pixel count to 1024^2 images')
+                sample=f'1 training step (fwd+bwd) of the CPU oracle on {b}x3x{res}x{res} ({dt:.1f} s), '
+                       f'scaled by pixel count to 1024^2 images')
 
 
 def ops_microbench():
