@@ -96,3 +96,30 @@ def test_head_state_dict_schema():
         assert torch.equal(v, ref[k])
     head.init_weights()
     assert float(head.rpn_cls.bias.abs().max()) == 0.0
+
+
+def test_host_side_roi_helpers_on_cpu():
+    """map_roi_levels (rotate_single_level_roi_extractor.py:66-84) and rbbox2roi are plain torch host logic."""
+    from oracle import roi_oracle
+    from sm3det_amd.roi_head import RotatedShared2FCBBoxHead, RotatedSingleRoIExtractor
+    from sm3det_amd.rpn_head import rbbox2roi
+    ext = RotatedSingleRoIExtractor(dict(type='RoIAlignRotated', out_size=7, sample_num=2, clockwise=True), 256,
+                                    [4, 8, 16, 32])
+    assert ext.num_inputs == 4 and ext.output_size == (7, 7) and ext.sampling_ratio == 2 and ext.clockwise
+    g = torch.Generator().manual_seed(2)
+    rois = torch.rand(500, 6, generator=g)
+    rois[:, 3:5] = torch.exp(rois[:, 3:5] * 5 + 1.5)
+    lv = ext.map_roi_levels(rois, 4)
+    assert torch.equal(lv, roi_oracle.map_roi_levels(rois, 4)) and set(lv.tolist()) == {0, 1, 2, 3}
+    # level boundaries of the FPN paper rule with finest_scale 56
+    edge = torch.tensor([[0, 0, 0, 111.9, 111.9, 0], [0, 0, 0, 112.1, 112.1, 0], [0, 0, 0, 447.9, 447.9, 0],
+                         [0, 0, 0, 448.1, 448.1, 0], [0, 0, 0, 5000.0, 5000.0, 0]])
+    assert ext.map_roi_levels(edge, 4).tolist() == [0, 1, 2, 3, 3]
+    r = rbbox2roi([torch.ones(2, 6), torch.zeros(0, 6), torch.full((1, 5), 2.0)])
+    assert tuple(r.shape) == (3, 6) and r[:, 0].tolist() == [0.0, 0.0, 2.0] and r[2, 1:].tolist() == [2.0] * 5
+    with pytest.raises(NotImplementedError):
+        RotatedSingleRoIExtractor(dict(type='RoIAlign'), 256, [4])
+    with pytest.raises(NotImplementedError):
+        RotatedShared2FCBBoxHead(with_avg_pool=True)
+    head = RotatedShared2FCBBoxHead(num_classes=26, reg_class_agnostic=False)
+    assert head.fc_reg.out_features == 130 and head.fc_cls.out_features == 27
