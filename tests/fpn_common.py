@@ -35,3 +35,33 @@ def check_run(fx, sl, outs, grads, dinputs, tol_fwd, tol_bwd):
             assert d is None or float(d.abs().max()) == 0.0
         else:
             assert rel_err(d, r) < tol_bwd
+
+
+def coder_round_trip_cases(n=3000, seed=3):
+    """(gt, anchors, rois): oriented boxes in regular le90 form (w >= h, away from squares and from axis alignment, where
+    the midpoint-offset representation is ambiguous by the reference's own 0.1 px vertex tolerance), horizontal anchors
+    around their hull, perturbed oriented RoIs -- for the encode -> decode round-trip properties."""
+    import math
+    g = torch.Generator().manual_seed(seed)
+    gt = torch.rand(n, 5, generator=g)
+    gt[:, :2] = gt[:, :2] * 800 + 100
+    gt[:, 2] = gt[:, 2] * 200 + 40
+    gt[:, 3] = gt[:, 2] * (0.3 + 0.6 * torch.rand(n, generator=g))
+    sign = torch.where(torch.rand(n, generator=g) < 0.5, -1.0, 1.0)
+    gt[:, 4] = sign * (0.15 + torch.rand(n, generator=g) * (math.pi / 2 - 0.3))
+    c, s = torch.cos(gt[:, 4]).abs(), torch.sin(gt[:, 4]).abs()
+    xb, yb = gt[:, 2] / 2 * c + gt[:, 3] / 2 * s, gt[:, 2] / 2 * s + gt[:, 3] / 2 * c
+    hull = torch.stack([gt[:, 0] - xb, gt[:, 1] - yb, gt[:, 0] + xb, gt[:, 1] + yb], 1)
+    anchors = hull + torch.randn(n, 4, generator=g) * 8
+    rois = gt.clone()
+    rois[:, :2] += torch.randn(n, 2, generator=g) * 10
+    rois[:, 2:4] *= 0.7 + 0.6 * torch.rand(n, 2, generator=g)
+    rois[:, 4] = (torch.rand(n, generator=g) - 0.5) * math.pi * 0.98
+    return gt, anchors, rois
+
+
+def assert_boxes_close(a, b, tol_xywh, tol_angle):
+    import math
+    assert float((a[:, :4] - b[:, :4]).abs().max()) < tol_xywh
+    d = (a[:, 4] - b[:, 4] + math.pi / 2) % math.pi - math.pi / 2
+    assert float(d.abs().max()) < tol_angle

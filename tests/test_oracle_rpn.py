@@ -123,3 +123,16 @@ def test_host_side_roi_helpers_on_cpu():
         RotatedShared2FCBBoxHead(with_avg_pool=True)
     head = RotatedShared2FCBBoxHead(num_classes=26, reg_class_agnostic=False)
     assert head.fc_reg.out_features == 130 and head.fc_cls.out_features == 27
+
+
+def test_coder_round_trips_on_the_oracle():
+    """size-independent property: decode(encode(gt)) == gt for both coders (regular-form boxes)"""
+    from tests.fpn_common import assert_boxes_close, coder_round_trip_cases
+    gt, anchors, rois = coder_round_trip_cases()
+    stds6 = (1., 1., 1., 1., 0.5, 0.5)
+    back = RO.delta2bbox(anchors, RO.midpoint_bbox2delta(anchors, gt, (0.,) * 6, stds6), (0.,) * 6, stds6)
+    assert_boxes_close(back, gt, 1e-3, 1e-5)
+    m5, s5 = (0.,) * 5, (0.1, 0.1, 0.2, 0.2, 0.1)
+    for es, pj in ((True, True), (False, False)):
+        d = RO.xywha_bbox2delta(rois, gt, m5, s5, None, es, pj)
+        assert_boxes_close(RO.xywha_delta2bbox(rois, d, m5, s5, None, 16 / 1000, None, es, pj), gt, 5e-4, 1e-5)

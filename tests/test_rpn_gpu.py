@@ -164,3 +164,18 @@ def test_box_coders_match_reference_fixture():
             assert float(dd[~near_square].abs().max()) < 1e-4
     r = rbbox2roi([gt[:3].cuda(), gt[:0].cuda(), gt[3:5].cuda()])
     assert tuple(r.shape) == (5, 6) and r[:, 0].tolist() == [0.0, 0.0, 0.0, 2.0, 2.0]
+
+
+def test_coder_round_trips_on_the_device():
+    """decode(encode(gt)) == gt through the kernels (10x the oracle's own round-trip error as tolerance)"""
+    from sm3det_amd.rpn_head import DeltaXYWHAOBBoxCoder, MidpointOffsetCoder
+    from tests.fpn_common import assert_boxes_close, coder_round_trip_cases
+    gt, anchors, rois = coder_round_trip_cases()
+    mc = MidpointOffsetCoder(target_means=[0.0] * 6, target_stds=list(STDS), angle_range='le90')
+    back, _ = mc.decode(anchors.cuda(), mc.encode(anchors.cuda(), gt.cuda()))
+    assert_boxes_close(back.cpu(), gt, 1e-2, 1e-4)
+    for es, pj in ((True, True), (False, False)):
+        xc = DeltaXYWHAOBBoxCoder(target_means=[0.0] * 5, target_stds=[0.1, 0.1, 0.2, 0.2, 0.1], angle_range='le90',
+                                  edge_swap=es, proj_xy=pj)
+        back = xc.decode(rois.cuda(), xc.encode(rois.cuda(), gt.cuda()))
+        assert_boxes_close(back.cpu(), gt, 5e-3, 1e-4)
