@@ -1,0 +1,51 @@
+"""Import the REFERENCE dynamic-lr hook (``mmrotate/core/hook/dynamic_lr.py``) unmodified from /root/reference.  TEST
+INFRASTRUCTURE ONLY (pins ``sm3det_amd.optim.DynamicLrPolicy`` on CPU).  Stand-ins during the import: ``mmcv.is_list_of``,
+``mmcv.runner`` / ``mmcv.runner.hooks(.hook)`` with an ``LrUpdaterHook`` that only stores ``by_epoch`` /
+``warmup_iters`` (the fields ``get_dynamic_lr`` reads) and an identity ``HOOKS`` registry."""
+import importlib.util
+import os
+import sys
+
+from oracle.ref_moe import REF_ROOT, _Registry, _mod
+
+REF_FILE = os.path.join(REF_ROOT, 'mmrotate', 'core', 'hook', 'dynamic_lr.py')
+
+
+class _LrUpdaterHook:
+    def __init__(self, by_epoch=True, warmup=None, warmup_iters=0, warmup_ratio=0.1, warmup_by_epoch=False):
+        self.by_epoch, self.warmup, self.warmup_iters = by_epoch, warmup, warmup_iters
+        self.base_lr, self.regular_lr = [], []
+
+
+def available():
+    return os.path.exists(REF_FILE)
+
+
+def load():
+    if not available():
+        raise FileNotFoundError(REF_FILE)
+    name = '_sm3det_ref_dynamic_lr'
+    if name in sys.modules:
+        return sys.modules[name]
+    hooks = _mod('mmcv.runner.hooks', LrUpdaterHook=_LrUpdaterHook)
+    shims = {
+        'mmcv': _mod('mmcv', is_list_of=lambda seq, t: isinstance(seq, list) and all(isinstance(x, t) for x in seq)),
+        'mmcv.runner': _mod('mmcv.runner', hooks=hooks, BaseRunner=object),
+        'mmcv.runner.hooks': hooks,
+        'mmcv.runner.hooks.hook': _mod('mmcv.runner.hooks.hook', HOOKS=_Registry(), Hook=object),
+    }
+    shims['mmcv'].runner = shims['mmcv.runner']
+    saved = {k: sys.modules.get(k) for k in shims}
+    sys.modules.update(shims)
+    try:
+        spec = importlib.util.spec_from_file_location(name, REF_FILE)
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[name] = mod
+        spec.loader.exec_module(mod)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    return mod
