@@ -141,9 +141,9 @@ class MoE_layer(nn.Module):
 
     def _save_to_state_dict(self, destination, prefix, keep_vars):
         super()._save_to_state_dict(destination, prefix, keep_vars)
-        for fused, ref in self._FUSED.items():
-            t = destination.pop(prefix + fused)
-            for e in range(self.num_experts):
+        fused = {ref: destination.pop(prefix + name) for name, ref in self._FUSED.items()}
+        for e in range(self.num_experts):  # the reference's key order: expert-major, conv1 w/b then conv2 w/b
+            for ref, t in fused.items():
                 destination[f'{prefix}experts.{e}.{ref}'] = t[e]
 
     def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
