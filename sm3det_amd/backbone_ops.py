@@ -330,11 +330,11 @@ class _MoEBlock(Function):
                               token_slot, xslot, hpre, act, yslot, w49, lnw, wcat, snorm, scale, w1, w2, gamma, rs,
                               noise, sim, temp, tot)
         ctx.meta = (B, H, W, P, k, train, float(clamp_max), float(loss_coef))
-        ctx.mark_non_differentiable(tot, offsets)
-        return out, loss.reshape(()), tot, offsets
+        ctx.mark_non_differentiable(tot, offsets, top_idx)
+        return out, loss.reshape(()), tot, offsets, top_idx
 
     @staticmethod
-    def backward(ctx, dout, dloss, _dtot, _doff):
+    def backward(ctx, dout, dloss, _dtot, _doff, _dtop):
         from . import _lib
         (x, u, mean, rstd, xn, hcat, top_idx, top_val, gates, clean, sigma, hnorm, offsets, token_slot, xslot, hpre,
          act, yslot, w49, lnw, wcat, snorm, scale, w1, w2, gamma, rs, noise, sim, temp, tot) = ctx.saved_tensors
@@ -404,6 +404,6 @@ class _MoEBlock(Function):
 def moe_block(x, w49, bdw, lnw, lnb, wp, bp, wn, sim, temp, w1, b1, w2, b2, gamma, rs, noise, eps, B, H, W, k, train,
               clamp_max, loss_coef=1e-2):
     """Returns (out (T,C), aux loss (scalar), [importance | load] (2E, non-differentiable), expert slot offsets
-    (E+1, int32, non-differentiable))."""
+    (E+1, int32, non-differentiable), top-(k+1) expert indices per token (T, min(k+1,E), int32, non-differentiable))."""
     return _MoEBlock.apply(x, w49, bdw, lnw, lnb, wp, bp, wn, sim, temp, w1, b1, w2, b2, gamma, rs, noise, eps, B, H,
                            W, k, train, clamp_max, loss_coef)

@@ -134,6 +134,7 @@ class MoE_layer(nn.Module):
         self.loss_coef = 1e-2  # reference :226 (forward(x, loss_coef=1e-2))
         self.last_expert_offsets = None  # device int32 (E+1): expert loads of the last forward (no sync)
         self.last_importance_load = None  # device fp32 (2E): [importance | load] of the last forward
+        self.last_top_idx = None  # device int32 (T, min(k+1,E)): the routing of the last forward, best first
 
     # ---- reference key schema <-> fused storage ---------------------------------------------------------
     _FUSED = {'w1': 'pointwise_conv1.weight', 'b1': 'pointwise_conv1.bias',
@@ -263,13 +264,14 @@ class ConvNeXtBlock(nn.Module):
         train = bool(moe.training and moe.noisy_gating)
         if train and noise is None:
             noise = torch.randn(x.shape[0], moe.num_experts, device=x.device)  # torch.randn_like(clean) :203
-        out, loss, tot, offsets = ops.moe_block(
+        out, loss, tot, offsets, top_idx = ops.moe_block(
             x, w49, self.depthwise_conv.bias, self.norm.weight, self.norm.bias, g.cosine_projector.weight,
             g.cosine_projector.bias, moe.w_noise, g.sim_matrix, g.temperature, moe.w1, moe.b1, moe.w2, moe.b2,
             self.gamma, rs, noise if train else None, self.norm.eps, B, H, W, moe.k, train, g.clamp_max,
             moe.loss_coef)  # aux loss (:234-238) comes out of the block: coef * (cv^2(importance) + cv^2(load))
         moe.last_expert_offsets = offsets
         moe.last_importance_load = tot
+        moe.last_top_idx = top_idx
         return out, loss
 
     def forward(self, x):

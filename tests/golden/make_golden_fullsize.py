@@ -1,0 +1,131 @@
+"""Generate tests/golden/full_*.pt: the REFERENCE backbone module
+(/root/reference/mmrotate/models/backbones/convnext_moe.py, imported unmodified through oracle/ref_moe.py) run at the
+BASELINE.json sizes -- config #2 (ConvNeXt-T, 8 experts top-2) at 1x and 2x3x1024x1024, config #4 (16 experts) at
+1x3x1024x1024 -- train-mode forward + backward with injected randomness.
+
+Run in the build container only (the GPU box has no /root/reference); ~1 minute per case on 8 cores:
+
+    python tests/golden/make_golden_fullsize.py [case ...]
+
+Only seeds and compressed results are stored (see tests/fullsize_common.py); every tensor the replaying test needs
+is regenerated from the seeds.  The gate-noise seed of each case is the best of a few candidates by smallest top-k
+margin of the reference's routing: with ~1e5 routed tokens some k-th / (k+1)-th logit pairs are always within a few
+1e-6 of each other, and an fp32 implementation with another summation order may legitimately order them the other
+way; choosing the candidate with the widest minimum margin keeps such flips rare (the fixture still lists the
+fragile tokens so a replay can recognise one).
+"""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import ref_moe  # noqa: E402
+from tests import fullsize_common as FC  # noqa: E402
+
+N_NOISE_CANDIDATES = int(os.environ.get('SM3_GOLDEN_CANDIDATES', '24'))
+
+
+class _FixedDrop(torch.nn.Module):
+    def __init__(self, rs):
+        super().__init__()
+        self.rs = rs
+
+    def forward(self, x):
+        return x * self.rs.view(-1, 1, 1, 1)
+
+
+class _Recorder:
+    """records the routing of every MoE block: patches Tensor.topk (reference :207) and torch.randn_like (:203)"""
+
+    def __init__(self, noise, E, k):
+        self.noise, self.E, self.k = iter(noise), E, k
+        self.topk = []
+
+    def __enter__(self):
+        self._topk, self._randn_like = torch.Tensor.topk, torch.randn_like
+        rec = self
+
+        def topk(t, kk, *a, **kw):
+            r = rec._topk(t, kk, *a, **kw)
+            if t.dim() == 2 and t.shape[1] == rec.E and kk == min(rec.k + 1, rec.E):
+                rec.topk.append((r[0].detach().clone(), r[1].detach().clone()))
+            return r
+        torch.Tensor.topk = topk
+        torch.randn_like = lambda t, *a, **kw: next(rec.noise).to(t.dtype)
+        return self
+
+    def __exit__(self, *exc):
+        torch.Tensor.topk, torch.randn_like = self._topk, self._randn_like
+        return False
+
+
+def routing_summary(rec, k):
+    out = []
+    for vals, idx in rec.topk:
+        gap = (vals[:, k - 1] - vals[:, k]).double()
+        rel = gap / (vals[:, k - 1].abs().double() + vals[:, k].abs().double() + 1.0)
+        frag = (rel < FC.FRAGILE_REL_GAP).nonzero().squeeze(1)
+        out.append(dict(topk=idx[:, :k].to(torch.uint8), min_rel_gap=float(rel.min()),
+                        fragile=frag.to(torch.int32), fragile_rel_gap=rel[frag].float(),
+                        runner_up=idx[frag, k].to(torch.uint8)))
+    return out
+
+
+def make(case):
+    c = FC.CASES[case]
+    cfg, B, seed = c['cfg'], c['batch'], c['seed']
+    E, k = cfg['num_experts'], cfg['top_k']
+    torch.manual_seed(0)
+    net = ref_moe.build_reference_backbone(**cfg)
+    sd = FC.seeded_state_dict(net.state_dict(), seed)
+    net.load_state_dict(sd, strict=True)
+    net.train()
+    blocks = [b for st in net.stages for b in st]
+    # candidate noise seeds: forward only, keep the one whose routing has the widest minimum top-k margin
+    best = None
+    for cand in range(N_NOISE_CANDIDATES):
+        ns = seed * 100 + cand
+        x, noise, drop = FC.make_inputs(case, noise_seed=ns)
+        for b, rs in zip(blocks, drop):
+            b.drop_path = _FixedDrop(rs)
+        t0 = time.time()
+        with torch.no_grad(), _Recorder(noise, E, k) as rec:
+            net(x, ['single'])
+        m = min(r['min_rel_gap'] for r in routing_summary(rec, k))
+        print(f'{case}: noise seed {ns}: min relative top-k margin {m:.2e} ({time.time() - t0:.1f} s)', flush=True)
+        if best is None or m > best[0]:
+            best = (m, ns)
+    ns = best[1]
+    x, noise, drop = FC.make_inputs(case, noise_seed=ns)
+    for b, rs in zip(blocks, drop):
+        b.drop_path = _FixedDrop(rs)
+    t0 = time.time()
+    with _Recorder(noise, E, k) as rec:
+        outs, gl = net(x, ['single'])
+        L = FC.loss_of(outs, gl, seed)
+        L.backward()
+    dt = time.time() - t0
+    routing = routing_summary(rec, k)
+    # importance / load of every MoE block, recomputed from the recorded routing is not possible for `load` (needs the
+    # Normal-CDF term), so take the gate loss as the scalar witness and the per-expert token counts as the routing one
+    counts = [torch.bincount(r['topk'].long().view(-1), minlength=E) for r in routing]
+    fx = dict(case=case, cfg=cfg, batch=B, res=c['res'], seed=seed, noise_seed=ns,
+              outs=[FC.summarise_output(i, o) for i, o in enumerate(outs)],
+              gate_loss=float(gl.detach()), loss=float(L.detach()),
+              routing=routing, expert_counts=counts,
+              grads=FC.pack_grads({kk: p.grad for kk, p in net.named_parameters() if p.grad is not None}),
+              torch_version=torch.__version__, reference_seconds=dt, reference_threads=torch.get_num_threads())
+    path = os.path.join(FC.GOLDEN, case + '.pt')
+    torch.save(fx, path)
+    print(f'{case}: wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB); reference fwd+bwd {dt:.1f} s on '
+          f'{torch.get_num_threads()} threads; gate_loss {fx["gate_loss"]:.6f}; min margin {best[0]:.2e}; '
+          f'fragile tokens {[int(r["fragile"].numel()) for r in routing]}', flush=True)
+
+
+if __name__ == '__main__':
+    assert ref_moe.available(), 'needs /root/reference'
+    for name in (sys.argv[1:] or list(FC.CASES)):
+        make(name)
