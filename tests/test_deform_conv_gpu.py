@@ -119,3 +119,35 @@ def test_shape_errors_raise():
         deform_conv2d(x, torch.zeros(3, 18, 8, 8, device='cuda'), w, 1, 1, 1, 1, 1, False, 2)
     with pytest.raises(RuntimeError):  # wrong offset channels
         deform_conv2d(x, torch.zeros(3, 10, 8, 8, device='cuda'), w, 1, 1, 1, 1, 1, False, 3)
+
+
+def test_deform_conv_bench_shape_2x256x128x128_vs_compiled_reference():
+    """SURVEY.md 8(d) DeformConv2d shape (the one bench.py times): x (2,256,128,128), 3x3, 256 -> 256, offsets randn*2;
+    forward, input/offset gradients and weight gradient vs the reference's CPU op."""
+    try:
+        from oracle import build_ref
+        ref = build_ref.load_ref()
+    except Exception:
+        pytest.skip('oracle/_ref .so did not travel')
+    from sm3det_amd import mmcv_ext as ext
+    g = torch.Generator().manual_seed(5)
+    B, C, H, W, k = 2, 256, 128, 128, 3
+    x = torch.randn(B, C, H, W, generator=g)
+    off = torch.randn(B, 2 * k * k, H, W, generator=g) * 2
+    w = torch.randn(C, C, k, k, generator=g) * 0.02
+    go = torch.randn(B, C, H, W, generator=g)
+    args = (k, k, 1, 1, 1, 1, 1, 1, 1, 1)
+    out_r = torch.zeros(B, C, H, W)
+    ref.deform_conv_forward(x, w, off, out_r, torch.zeros(0), torch.zeros(0), *args, 2)
+    gi_r, goff_r, gw_r = torch.zeros_like(x), torch.zeros_like(off), torch.zeros_like(w)
+    ref.deform_conv_backward_input(x, off, go.clone(), gi_r, goff_r, w, torch.zeros(0), *args, 2)
+    ref.deform_conv_backward_parameters(x, off, go.clone(), gw_r, torch.zeros(0), torch.zeros(0), *args, 1.0, 2)
+    xc, oc, wc, goc = x.cuda(), off.cuda(), w.cuda(), go.cuda()
+    out = torch.zeros(B, C, H, W, device='cuda')
+    e = torch.zeros(0, device='cuda')
+    ext.deform_conv_forward(xc, wc, oc, out, e, e, *args, 2)
+    gi, goff, gw = torch.zeros_like(xc), torch.zeros_like(oc), torch.zeros_like(wc)
+    ext.deform_conv_backward_input(xc, oc, goc, gi, goff, wc, e, *args, 2)
+    ext.deform_conv_backward_parameters(xc, oc, goc, gw, e, e, *args, 1.0, 2)
+    assert rel(out, out_r) < 1e-4
+    assert rel(gi, gi_r) < 1e-3 and rel(goff, goff_r) < 1e-3 and rel(gw, gw_r) < 1e-3

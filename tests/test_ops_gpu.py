@@ -259,3 +259,52 @@ def test_cpu_tensors_are_rejected():
         mmcv_ext.box_iou_rotated(torch.zeros(1, 5), torch.zeros(1, 5), torch.zeros(1), 0, False)
     with pytest.raises(NotImplementedError):
         mmcv_ext.roi_align_forward()
+
+
+# ----------------------------------------------------------------------------------- the shapes bench.py times
+def test_nms_rotated_bench_shape_10000_vs_oracle_and_compiled_reference():
+    """the exact inputs of bench.py's `nms_rotated_10000` line: keep list bit-exact vs the C oracle and vs the
+    reference's own CPU op (oracle/_ref) when its .so travelled."""
+    ops, O = _ops(), _oracle()
+    d, s = synth.rotated_boxes(10000, 7), synth.unique_scores(10000, 8)
+    _, keep = ops.nms_rotated(dev(d), dev(s), 0.1)
+    exp = O.nms_rotated(d, s, 0.1)
+    assert np.array_equal(keep.cpu().numpy(), exp), (len(exp), keep.numel())
+    ref = _ref_or_none()
+    if ref is not None:
+        kr = ref.nms_rotated_cpu(torch.from_numpy(d), torch.from_numpy(s), 0.1)
+        assert np.array_equal(keep.cpu().numpy(), kr.numpy())
+    # clustered (dense-overlap) variant of the same size
+    d, s = synth.rotated_boxes(10000, 9, cluster=True), synth.unique_scores(10000, 10)
+    _, keep = ops.nms_rotated(dev(d), dev(s), 0.1)
+    assert np.array_equal(keep.cpu().numpy(), O.nms_rotated(d, s, 0.1))
+
+
+@pytest.mark.parametrize('channels_last', [False, True])
+def test_roi_align_rotated_bench_shape_256x256_level(channels_last):
+    """bench.py's RoIAlignRotated lines: 512 RoIs x 256 ch x 7x7 x s2 on the REAL stride-4 level (256x256 map) of one
+    1024^2 image, forward and backward, NCHW and NHWC features."""
+    ops, O = _ops(), _oracle()
+    rng = np.random.RandomState(3)
+    x = rng.randn(1, 256, 256, 256).astype(np.float32)
+    rois = synth.rois_for_level(512, 6, batch=1, extent=1024.0)
+    xt = dev(x).requires_grad_(True)
+    xin = xt.contiguous(memory_format=torch.channels_last) if channels_last else xt
+    layer = ops.RoIAlignRotated(output_size=7, spatial_scale=0.25, sampling_ratio=2, clockwise=True)
+    y = layer(xin, dev(rois))
+    exp = O.roi_align_rotated_forward(x, rois, 7, 7, 0.25, 2, True, True)
+    got = y.detach().cpu().numpy()
+    assert np.allclose(got, exp, rtol=1e-5, atol=1e-6), np.abs(got - exp).max()
+    go = rng.randn(*exp.shape).astype(np.float32)
+    y.backward(dev(go))
+    gexp = O.roi_align_rotated_backward(go, rois, x.shape, 7, 7, 0.25, 2, True, True)
+    ggot = xt.grad.cpu().numpy()
+    assert np.allclose(ggot, gexp, rtol=1e-4, atol=1e-4), np.abs(ggot - gexp).max()
+
+
+def test_box_iou_rotated_bench_shape_2000x64():
+    ops, O = _ops(), _oracle()
+    b1, b2 = synth.rotated_boxes(2000, 0), synth.rotated_boxes(64, 1)
+    got = ops.box_iou_rotated(dev(b1), dev(b2)).cpu().numpy()
+    exp = O.box_iou_rotated(b1, b2, 0)
+    assert np.abs(got - exp).max() <= 1e-6 and np.array_equal(got > 0, exp > 0)
