@@ -19,6 +19,13 @@ re-declares the entry points the way ``pytorch/pybind.cpp`` does for these ops.
 Output: ``oracle/_ref/sm3det_ref_ops.so`` (git-ignored, NOT gpurun-ignored: it
 travels to the GPU box, where ``/root/reference`` does not exist).
 
+Also compiled (``py_compile``, bytecode only -- no source text is copied) into
+``oracle/_ref/pyc``: the reference's own PYTHON wrappers of these ops,
+``mmcv/mmcv/ops/{box_iou_rotated,nms,roi_align_rotated,deform_conv}.py`` plus the two
+helper files they import (``mmcv/mmcv/utils/{ext_loader,misc}.py``), so that the GPU
+tests can drive the REFERENCE's unmodified wrappers into ``sm3det_amd.mmcv_ext`` on a box
+where ``/root/reference`` does not exist (``oracle/ref_mmcv_ops.py`` loads them).
+
 Usage:  python oracle/build_ref.py          (no-op when the .so is up to date or
                                              /root/reference is absent)
 """
@@ -76,12 +83,38 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
 '''
 
 
+PY_UNITS = {  # module name in the shim package -> path under /root/reference/mmcv/mmcv
+    'mmcv.utils.ext_loader': 'utils/ext_loader.py',
+    'mmcv.utils.misc': 'utils/misc.py',
+    'mmcv.ops.box_iou_rotated': 'ops/box_iou_rotated.py',
+    'mmcv.ops.nms': 'ops/nms.py',
+    'mmcv.ops.roi_align_rotated': 'ops/roi_align_rotated.py',
+    'mmcv.ops.deform_conv': 'ops/deform_conv.py',
+}
+PYC = os.path.join(OUT, 'pyc')
+
+
+def build_pyc():
+    """bytecode of the reference's python wrappers -> oracle/_ref/pyc/<module>.pyc (needs /root/reference)"""
+    import py_compile
+    root = os.path.join(REF_ROOT, 'mmcv', 'mmcv')
+    if not os.path.isdir(root):
+        return None
+    os.makedirs(PYC, exist_ok=True)
+    for mod, rel in PY_UNITS.items():
+        src, dst = os.path.join(root, rel), os.path.join(PYC, mod + '.pyc')
+        if not os.path.exists(dst) or os.path.getmtime(dst) < os.path.getmtime(src):
+            py_compile.compile(src, cfile=dst, dfile=f'<reference>/mmcv/mmcv/{rel}', doraise=True)
+    return PYC
+
+
 def so_path():
     return os.path.join(OUT, NAME + '.so')
 
 
 def build(verbose=False):
     """Compile oracle/_ref if the reference tree is present. Returns the .so path or None."""
+    build_pyc()
     if not os.path.isdir(CSRC):
         return so_path() if os.path.exists(so_path()) else None
     if os.path.exists(so_path()):
