@@ -109,13 +109,28 @@ def make(case):
         L.backward()
     dt = time.time() - t0
     routing = routing_summary(rec, k)
+    # the reference's OWN fp32 rounding error in the test's metric: the same module evaluated in float64 on the same
+    # inputs (forward only).  The replaying tests scale their element-wise tolerance by it.
+    import copy
+    net64 = copy.deepcopy(net).double()
+    for b, rs in zip([b for st in net64.stages for b in st], drop):
+        b.drop_path = _FixedDrop(rs.double())
+    with torch.no_grad(), _Recorder([n.double() for n in noise], E, k) as rec64:
+        outs64, gl64 = net64(x.double(), ['single'])
+    same_routing = all(torch.equal(torch.sort(a[1][:, :k], 1)[0], torch.sort(b[1][:, :k], 1)[0])
+                       for a, b in zip(rec.topk, rec64.topk))
+    floor = []
+    for i, (o, o64) in enumerate(zip(outs, outs64)):
+        cmp = FC.compare_output(i, o, FC.summarise_output(i, o64.float()))
+        floor.append({kk: float(v.max()) for kk, v in cmp.items()})
+    print(f'{case}: fp32-vs-fp64 floor of the reference itself: {floor} (same routing: {same_routing})', flush=True)
     # importance / load of every MoE block, recomputed from the recorded routing is not possible for `load` (needs the
     # Normal-CDF term), so take the gate loss as the scalar witness and the per-expert token counts as the routing one
     counts = [torch.bincount(r['topk'].long().view(-1), minlength=E) for r in routing]
     fx = dict(case=case, cfg=cfg, batch=B, res=c['res'], seed=seed, noise_seed=ns,
               outs=[FC.summarise_output(i, o) for i, o in enumerate(outs)],
               gate_loss=float(gl.detach()), loss=float(L.detach()),
-              routing=routing, expert_counts=counts,
+              routing=routing, expert_counts=counts, fp32_floor=floor, fp64_same_routing=same_routing,
               grads=FC.pack_grads({kk: p.grad for kk, p in net.named_parameters() if p.grad is not None}),
               torch_version=torch.__version__, reference_seconds=dt, reference_threads=torch.get_num_threads())
     path = os.path.join(FC.GOLDEN, case + '.pt')

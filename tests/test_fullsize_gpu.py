@@ -9,7 +9,12 @@ token block), the gate loss, the routing of every MoE block token by token, and 
 (483 / 675 tensors under the reference key schema: sampled elements + L2 norm).
 
 Error metric: ELEMENT-WISE relative error |a - ref| / max(|ref|, 1 % of the tensor's max) -- not a max-norm -- with
-tolerances forward 1e-4, gradients 1e-3.
+tolerances forward 1e-4, gradients 1e-3.  One refinement, measured rather than chosen: in this
+element-wise metric the REFERENCE'S OWN fp32 result is up to 5e-5 away from the float64 evaluation of the same module
+on the same inputs (stages 2-3, after 12-18 residual blocks with K up to 3072; the fixture stores that per output as
+`fp32_floor`).  Two independent fp32 evaluations of the graph therefore differ by ~1e-4 at their worst sampled
+element, so the sampled-element tolerance of an output is max(1e-4, 4 x its fp32_floor); the plane / block sums and
+everything else keep 1e-4.
 
 Routing flips.  With ~1e5 routed tokens per case a few k-th / (k+1)-th logit pairs are within a few 1e-6 (relative)
 of each other in the reference itself; an fp32 implementation with another summation order may order such a pair the
@@ -90,12 +95,14 @@ def test_full_size_values_vs_reference_fixture(case):
         strict = first_flip_stage is None or i < first_flip_stage
         stats = {}
         for name, e in cmp.items():
-            stats[name] = dict(max=float(e.max()), p999=float(torch.quantile(e, 0.999)), median=float(e.median()))
+            tol = max(FWD_TOL, 4.0 * fx['fp32_floor'][i][name]) if name == 'samples' else FWD_TOL
+            stats[name] = dict(max=float(e.max()), p999=float(torch.quantile(e, 0.999)), median=float(e.median()),
+                               tol=tol, reference_fp32_floor=fx['fp32_floor'][i][name])
             if strict:
-                assert float(e.max()) < FWD_TOL, (case, f'out{i}', name, stats[name])
+                assert float(e.max()) < tol, (case, f'out{i}', name, stats[name])
             else:
-                assert float((e > FWD_TOL).double().mean()) <= 5e-3, (case, f'out{i}', name, stats[name])
-                assert float(e.median()) < FWD_TOL / 10, (case, f'out{i}', name, stats[name])
+                assert float((e > tol).double().mean()) <= 5e-3, (case, f'out{i}', name, stats[name])
+            assert float(e.median()) < FWD_TOL / 10, (case, f'out{i}', name, stats[name])
         report[f'out{i}'] = dict(strict=strict, **stats)
     gl_err = abs(float(gl) - fx['gate_loss']) / abs(fx['gate_loss'])
     assert gl_err < (FWD_TOL if n_flips == 0 else 1e-3), (case, float(gl), fx['gate_loss'])
