@@ -149,7 +149,7 @@ typedef struct sm3_gemm_desc {
   int32_t lda, ldb, ldc;
   const int32_t* group_offsets;
   int32_t num_groups;
-  int32_t splits; /* TN only: split-K factor per group */
+  int32_t splits; /* split-K slices: TN per group (0 = automatic); NT/NN 0 = automatic (few output tiles, long K), 1 = off */
   int64_t stride_b, stride_bias;
   const float* bias;
   const float* aux_in;
@@ -159,7 +159,14 @@ typedef struct sm3_gemm_desc {
   int32_t rows_per_scale;
   int32_t ld_aux;
   float* colsum_out; /* EPI_GELU_BWD only, may be NULL */
+  int32_t* counters; /* ticket counters of the in-kernel split-K fix-up: sm3_gemm_f32_counter_slots() int32, ZERO on entry,
+                        left zero on exit; one array per stream that may run GEMMs concurrently.  NULL: no in-kernel
+                        fix-up (TN slices are then reduced by a second pass, NT/NN never slice K) */
+  int32_t tuning;    /* 0 in production.  Benchmarking override: bits 0-3 tile+1 (0 128x128, 1 128x96, 2 96x128,
+                        3 128x192, 4 192x128, 5 64x128), bits 4-7 k-step (1 = 16, 2 = 32), bits 8-15 slices,
+                        bit 16 TN: always reduce by the second pass */
 } sm3_gemm_desc;
+int sm3_gemm_f32_counter_slots(void);
 size_t sm3_gemm_f32_workspace_bytes(const sm3_gemm_desc* desc);
 int sm3_gemm_f32(const sm3_gemm_desc* desc, void* workspace, size_t workspace_bytes, sm3_stream_t stream);
 /* out[g][n] = sum over rows of group g of x[r][n]  (bias gradients); out is overwritten */

@@ -21,7 +21,7 @@ class GemmDesc(ctypes.Structure):
         ('stride_b', ctypes.c_int64), ('stride_bias', ctypes.c_int64),
         ('bias', P), ('aux_in', P), ('aux_out', P), ('gamma', P), ('rowscale', P),
         ('rows_per_scale', ctypes.c_int32), ('ld_aux', ctypes.c_int32),
-        ('colsum_out', P),
+        ('colsum_out', P), ('counters', P), ('tuning', ctypes.c_int32),
     ]
 
 
@@ -29,6 +29,7 @@ def signatures():
     D = ctypes.POINTER(GemmDesc)
     LL = ctypes.c_long
     return {
+        'sm3_gemm_f32_counter_slots': (I, []),
         'sm3_gemm_f32_workspace_bytes': (S, [D]),
         'sm3_gemm_f32': (I, [D, P, S, P]),
         'sm3_colsum_f32': (I, [P, I, I, I, P, I, P, P]),
@@ -113,10 +114,28 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+_COUNTERS = {}
+TUNING = 0  # benchmarking override forwarded to sm3_gemm_desc.tuning (scripts/gemm_sweep2.py); 0 in production
+
+
+def gemm_counters(device):
+    """The zeroed ticket-counter array of the in-kernel split-K fix-up for torch's CURRENT stream on `device` (GEMMs on
+    one stream run in order and may share it; the weight-gradient side stream gets its own).  The kernels leave it
+    zeroed, so it is filled exactly once, when it is created."""
+    from . import _lib
+    key = (device.index if device.index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream(device).cuda_stream)
+    t = _COUNTERS.get(key)
+    if t is None:
+        t = _COUNTERS[key] = torch.zeros(_lib.lib().sm3_gemm_f32_counter_slots(), dtype=torch.int32, device=device)
+    return t
+
+
 def gemm(mode, A, B, C, M, N, K, *, epilogue=EPI_NONE, bias=None, aux_in=None, aux_out=None, gamma=None,
-         rowscale=None, rows_per_scale=1, offsets=None, num_groups=1, splits=1, lda=None, ldb=None, ldc=None,
+         rowscale=None, rows_per_scale=1, offsets=None, num_groups=1, splits=0, lda=None, ldb=None, ldc=None,
          ld_aux=None, colsum_out=None):
-    """Enqueue one GEMM of the family on torch's current stream.  All tensors fp32, on the current device."""
+    """Enqueue one GEMM of the family on torch's current stream.  All tensors fp32, on the current device.
+    splits: 0 = let the library choose the split-K factor, 1 = none."""
     from . import _lib
     L = _lib.lib()
     d = GemmDesc()
@@ -144,10 +163,11 @@ def gemm(mode, A, B, C, M, N, K, *, epilogue=EPI_NONE, bias=None, aux_in=None, a
     d.rows_per_scale = rows_per_scale
     d.ld_aux = ld_aux or N
     d.colsum_out = _p(colsum_out)
+    d.counters = _p(gemm_counters(C.device))
+    d.tuning = TUNING
     ws = None
-    nbytes = 0
-    if mode == TN or colsum_out is not None:
-        nbytes = L.sm3_gemm_f32_workspace_bytes(ctypes.byref(d))
+    nbytes = L.sm3_gemm_f32_workspace_bytes(ctypes.byref(d))
+    if nbytes:
         ws = _lib.workspace(nbytes, C.device)
     rows = K if mode == TN else M
     tag = 'gemm_f32_' + ('nt', 'nn', 'tn')[mode]
@@ -167,13 +187,6 @@ def colsum(x, M, N, out, offsets=None, num_groups=1, ld=None):
     with _Prof('colsum_f32', M * N, 4.0 * M * N):
         _lib.check(L.sm3_colsum_f32(_p(x), ld or N, M, N, _p(offsets), num_groups, _p(out), _lib.stream_ptr()),
                    'colsum_f32')
-
-
-def tn_splits(tiles, rows, target_blocks=1024):
-    """split-K factor so a weight-gradient GEMM fills the 256 CUs (>= ~4 blocks per CU) without tiny K chunks."""
-    s = max(1, target_blocks // max(tiles, 1))
-    s = min(s, max(1, rows // 256))
-    return int(s)
 
 
 def row_ws(C, like):

@@ -77,9 +77,7 @@ def _tn(dy, x, M, N, rows, **kw):
     """dW[M,N] = dy[rows,M]^T @ x[rows,N] (split-K)."""
     groups = kw.get('num_groups', 1)
     out = _e(groups, M, N, like=dy) if groups > 1 or kw.get('offsets') is not None else _e(M, N, like=dy)
-    tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    splits = LB.tn_splits(tiles * groups, max(rows // groups, 1))
-    gemm(LB.TN, dy, x, out, M, N, rows, splits=splits, **kw)
+    gemm(LB.TN, dy, x, out, M, N, rows, **kw)  # split-K factor and fix-up chosen by the library
     return out
 
 
@@ -382,8 +380,7 @@ class _MoEBlock(Function):
         def gate_wgrad():
             if E % 4 == 0:
                 dsn = _e(P, E, like=x)
-                tiles = (P + 127) // 128
-                gemm(LB.TN, hcat, dcn, dsn, P, E, T, lda=PC, ldb=E, splits=LB.tn_splits(tiles, T))
+                gemm(LB.TN, hcat, dcn, dsn, P, E, T, lda=PC, ldb=E)
             else:  # tiny (P x E) product; E not a multiple of the 16-byte vector width
                 dsn = (hcat[:, :P].t() @ dcn).contiguous()
             dwcat = _tn(dhcat, xn, PC, C, T)

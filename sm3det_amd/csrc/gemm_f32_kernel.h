@@ -1,0 +1,623 @@
+// gemm_f32_kernel.h -- the fp32 GEMM kernel template of libsm3det_hip.so (gfx950 matrix cores,
+// v_mfma_f32_32x32x2_f32: exact f32 FMA chain, 157 TFLOP/s peak; there is no TF32/xf32 on CDNA4).
+//
+// One template covers every dense contraction of the SM3Det backbone hot path (reference:
+// mmrotate/models/backbones/convnext_moe.py FFN.forward :397-405, the expert loop :244, CosineTopKGate projection :101,
+// stem / downsample convs as patch GEMMs :533-558,783-791), their backward, and the 3x3 NHWC convolutions of the neck
+// and heads as implicit GEMMs (GATHER):
+//
+//   MODE_NT : C[M,N] = A[M,K] . B[N,K]^T        (nn.Linear forward: x @ W^T)
+//   MODE_NN : C[M,N] = A[M,K] . B[K,N]          (dgrad: dY @ W)
+//   MODE_TN : C[M,N] = A[Kt,M]^T . B[Kt,N]      (wgrad: dY^T @ X, reduction over token rows)
+//
+// Grouped (MoE experts): rows of A/C (NT, NN) or the reduction rows (TN) are partitioned into `num_groups` contiguous
+// segments by a DEVICE prefix array `offsets[G+1]` (expert-major slot order); group g uses weight block g.  The
+// tile->group map is computed in the kernel, so ragged expert loads never sync the host (the reference does `.cpu()`
+// per MoE block: convnext_moe.py:259).
+//
+// Tiling: 256 threads = 4 waves arranged WM x WN, each wave owns TI x TJ MFMA tiles of 32x32 (block tile
+// BM = 32*WM*TI, BN = 32*WN*TJ).  Shapes instantiated: 128x128 (2,2,2,2), 128x96 (4,1,1,3), 96x128 (1,4,3,1),
+// 128x192 (2,2,2,3), 192x128 (2,2,3,2), 64x128 (2,2,1,2): the ConvNeXt channel widths 96 / 192 are not multiples of
+// 128 and a 128-wide tile wastes a quarter of its MFMA work on them.  Operands are staged k-major in LDS so that one
+// conflict-free ds_read_b32 per lane fetches exactly the A[i][k] / B[k][j] fragment of the 32x32x2 instruction
+// (lanes 0-31: row k, lanes 32-63: row k+1); two register sets software-pipeline the loop (loads of tile kt+2 and LDS
+// writes of tile kt+1 interleaved between the MFMAs of tile kt, one barrier per k-step).
+//
+// Split-K with an in-kernel fix-up (all modes): blockIdx.z slices K; every slice writes its accumulators as a
+// fragment-ordered slab (thread-major 16-byte stores), publishes it with ONE agent-scope release + ticket, and the
+// last-arriving block of a tile sums the slabs in slice order (deterministic) and runs the epilogue -- no second
+// kernel, no second pass over the output (cdna_hip_programming.md, in-launch split-K recipe).  The ticket counters
+// are a caller-provided zeroed array that the kernel leaves zeroed.
+#pragma once
+#include "common.h"
+
+namespace sm3gemm {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int MODE_NT = 0, MODE_NN = 1, MODE_TN = 2;
+constexpr int NTHREADS = 256;
+// EPI codes (must match include/sm3det_hip.h)
+constexpr int EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_BIAS_SCALE_RES = 3, EPI_GELU_BWD = 4;
+constexpr int EPI_BIAS_RELU = 5;
+
+struct GemmParams {
+  const float* A;
+  const float* B;
+  float* C;
+  int M, N, K;  // TN: M,N = output dims, K = total reduction rows (ignored when grouped: offsets decide)
+  int lda, ldb, ldc;
+  // grouping
+  const int32_t* offsets;  // device, num_groups+1 (NULL => one group covering all rows)
+  int num_groups;
+  long strideB;     // elements between consecutive groups' B blocks (NT/NN)
+  long strideBias;  // elements between groups' bias vectors
+  long strideC;     // TN: elements between (group, split) outputs (= M*N)
+  // split-K
+  int splits;          // slices of K per tile (TN: per group)
+  int fixup;           // 1: fragment-ordered slabs + in-kernel last-arriver reduction; 0: slice z -> C + z*strideC, reduced later
+  int kTilesPerSplit;  // NT/NN: k-tiles per slice
+  float* slabs;        // fixup: [tile][split][BM*BN]
+  int* counters;       // fixup: one ticket counter per tile, zero on entry, zero on exit
+  // epilogue operands
+  const float* bias;      // [N] (per group)
+  const float* aux_in;    // EPI_GELU_BWD: gelu'(h)[M,N];  EPI_BIAS_SCALE_RES: residual[M,N]
+  float* aux_out;         // EPI_BIAS_GELU: gelu'(h)[M,N]; EPI_BIAS_SCALE_RES: y[M,N]
+  float* colpart;         // EPI_GELU_BWD: per-row-tile column sums [row tiles][N] (bias gradient partials) or NULL
+  const float* gamma;     // [N] layer scale
+  const float* rowscale;  // [M / rows_per_scale] (stochastic-depth keep/keep_prob per image) or NULL
+  int rows_per_scale;
+  int ld_aux;
+  // GATHER (implicit-GEMM 3x3 convolution over NHWC tokens, padding 1): the gathered operand has `cC` channels per tap,
+  // its rows live on an (sH, sW) grid per image; the GEMM's own rows (NT/NN: A/C rows, TN: reduction rows) live on an
+  // (rH, rW) grid.  cT = 0: source = row * cS + d - 1 (forward / weight gradient);  cT = 1: source = (row - d + 1) / cS
+  // where divisible (input gradient = transposed convolution).  cInv: (kt * cInv) >> 16 == kt / (cC / BK).
+  int cC, sH, sW, rH, rW, cS, cT;
+  unsigned cInv, mRW, mRH;  // mRW/mRH: ceil(2^32 / rW), ceil(2^32 / rH) for exact umulhi division of row indices
+};
+
+template <int WM_, int WN_, int TI_, int TJ_>
+struct Tile {
+  static constexpr int WM = WM_, WN = WN_, TI = TI_, TJ = TJ_;
+  static constexpr int BM = 32 * WM_ * TI_, BN = 32 * WN_ * TJ_;
+  static_assert(WM_ * WN_ == 4, "4 waves per workgroup");
+};
+using T128x128 = Tile<2, 2, 2, 2>;
+using T128x96 = Tile<4, 1, 1, 3>;
+using T96x128 = Tile<1, 4, 3, 1>;
+using T128x192 = Tile<2, 2, 2, 3>;
+using T192x128 = Tile<2, 2, 3, 2>;
+using T64x128 = Tile<2, 2, 1, 2>;
+
+// resident workgroups per CU the launch bounds ask for (VGPR budget 512 / waves-per-SIMD)
+template <class TL, int BK>
+constexpr int occupancy() {
+  return (TL::TI * TL::TJ >= 6 || BK == 32) ? 2 : 4;
+}
+
+// exact n / d for n * d < 2^32 with m = floor(2^32 / d) + 1 (d >= 2); d == 1 passes through
+__device__ __forceinline__ unsigned fast_div(unsigned n, unsigned d, unsigned m) { return d == 1 ? n : __umulhi(n, m); }
+
+// source coordinate of one axis for tap offset dd in {0,1,2}; returns -1 when the tap falls outside / between pixels
+__device__ __forceinline__ int gather_coord(int r, int dd, int stride, int transposed, int lim) {
+  if (!transposed) {
+    const int v = r * stride + dd - 1;
+    return (v >= 0 && v < lim) ? v : -1;
+  }
+  const int t = r - dd + 1;  // stride is 1 or 2 (checked on the host)
+  const int q = stride == 2 ? (t >> 1) : t;
+  const bool ok = t >= 0 && (stride == 1 || (t & 1) == 0) && q < lim;
+  return ok ? q : -1;
+}
+
+// GELU(erf) and its derivative share one exponential: y = h*Phi(h), y' = Phi(h) + h*phi(h).  The forward epilogue stores
+// y' so the backward epilogue is a single multiply (no transcendental on the dgrad critical path).
+// Phi through erfc(u) = t*(a1 + t*(a2 + ... a5 t))*exp(-u^2), t = 1/(1 + p u), u = |h|/sqrt(2) (Abramowitz & Stegun
+// 7.1.26, |error| <= 1.5e-7 on erf, i.e. <= 7.5e-8 on Phi -- fp32 rounding level): ~16 VALU ops per element instead of
+// ~55 for ocml's erff + expf.
+__device__ __forceinline__ void gelu_erf_both(float h, float& y, float& dy) {
+  const float e = __expf(-0.5f * h * h);  // exp(-u^2)
+  const float u = fabsf(h) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, u, 1.0f));
+  float q = fmaf(1.061405429f, t, -1.453152027f);
+  q = fmaf(q, t, 1.421413741f);
+  q = fmaf(q, t, -0.284496736f);
+  q = fmaf(q, t, 0.254829592f);
+  const float half_erfc = 0.5f * q * t * e;  // 0.5 * erfc(u) = Phi(-|h|)
+  const float cdf = h >= 0.f ? 1.0f - half_erfc : half_erfc;
+  const float pdf = 0.39894228040143267794f * e;
+  y = h * cdf;
+  dy = fmaf(h, pdf, cdf);
+}
+
+// LDS bytes of one instantiation
+template <int MODE, int BK, class TL>
+constexpr int smem_floats() {
+  constexpr int PADT = (BK == 32) ? 1 : 2;
+  constexpr int lda = (MODE != MODE_TN) ? TL::BM + PADT : TL::BM + 4;
+  constexpr int ldb = (MODE == MODE_NT) ? TL::BN + PADT : TL::BN + 4;
+  return 2 * BK * (lda + ldb);
+}
+
+template <int MODE, int EPI, int BK, class TL, int GATHER>
+__global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kernel(GemmParams p) {
+  constexpr int BM = TL::BM, BN = TL::BN, TI = TL::TI, TJ = TL::TJ, WN = TL::WN, WM = TL::WM;
+  // A tile is written transposed (k-contiguous source) in NT/NN, directly (k-major source) in TN; B transposed in NT.
+  // Leading dim of a transposed tile: the 4-byte scatter writes of one half-wave must hit 32 distinct banks:
+  // BK=32 -> 8 k-quads x 4 rows need LD = 1 (mod 8); BK=16 -> 4 k-quads x 8 rows need LD = 2 (mod 8).
+  constexpr bool A_TRANS = (MODE != MODE_TN);
+  constexpr bool B_TRANS = (MODE == MODE_NT);
+  constexpr int PADT = (BK == 32) ? 1 : 2;
+  constexpr int LDA_S = A_TRANS ? BM + PADT : BM + 4;
+  constexpr int LDB_S = B_TRANS ? BN + PADT : BN + 4;
+  constexpr int A_STAGE = BK * LDA_S, B_STAGE = BK * LDB_S;
+  __shared__ __attribute__((aligned(16))) float smem[2 * (A_STAGE + B_STAGE)];
+  float* As = smem;                // [2][BK][LDA_S]
+  float* Bs = smem + 2 * A_STAGE;  // [2][BK][LDB_S]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm0 = (wave / WN) * (TI * 32);
+  const int wn0 = (wave % WN) * (TJ * 32);
+  const int l31 = lane & 31;
+  const int lh = lane >> 5;
+
+  // ---- XCD-aware remap of the linear block id (speed only): consecutive logical tiles share an XCD ----------
+  const int ntn = (p.N + BN - 1) / BN;
+  int bid = blockIdx.x;
+  {
+    const int nblk = gridDim.x;
+    const int q = nblk / kNumXCD, r = nblk % kNumXCD;
+    const int xcd = bid % kNumXCD, idx = bid / kNumXCD;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tile_n = bid % ntn;
+  const int tile_m = bid / ntn;
+
+  // ---- group / row-range / k-slice resolution ---------------------------------------------------------------
+  int g = 0, split = 0;
+  int row0, row_end;  // NT/NN: rows of A and C handled by this block; TN: reduction rows [row0,row_end)
+  int m0;             // first output row of this tile
+  if (MODE == MODE_TN) {
+    g = blockIdx.z / p.splits;
+    split = blockIdx.z - g * p.splits;
+    int seg0 = 0, seg1 = p.K;
+    if (p.offsets) {
+      seg0 = p.offsets[g];
+      seg1 = p.offsets[g + 1];
+    }
+    const int cnt = seg1 - seg0;
+    int chunk = (cnt + p.splits - 1) / p.splits;
+    chunk = (chunk + BK - 1) / BK * BK;
+    row0 = min(seg1, seg0 + split * chunk);
+    row_end = min(seg1, row0 + chunk);
+    m0 = tile_m * BM;
+  } else {
+    split = blockIdx.z;
+    if (p.offsets) {
+      int base = 0;
+      bool found = false;
+      for (int gg = 0; gg < p.num_groups; gg++) {
+        const int o0 = p.offsets[gg], o1 = p.offsets[gg + 1];
+        const int nt = (o1 - o0 + BM - 1) / BM;
+        if (tile_m < base + nt) {
+          g = gg;
+          row0 = o0 + (tile_m - base) * BM;
+          row_end = o1;
+          found = true;
+          break;
+        }
+        base += nt;
+      }
+      if (!found) return;  // surplus block of a ragged launch (all slices of it leave: no ticket is ever drawn)
+    } else {
+      row0 = tile_m * BM;
+      row_end = p.M;
+      if (row0 >= row_end) return;
+    }
+    m0 = row0;
+  }
+  const int n0 = tile_n * BN;
+  const float* __restrict__ Ag = p.A;
+  const float* __restrict__ Bg = p.B + (MODE == MODE_TN ? 0 : (long)g * p.strideB);
+
+  int nk, kbase = 0;  // k-tiles of this block, first k-tile
+  if (MODE == MODE_TN) {
+    nk = (max(row_end - row0, 0) + BK - 1) / BK;
+  } else {
+    nk = p.K / BK;
+    if (p.splits > 1) {
+      kbase = split * p.kTilesPerSplit;
+      nk = max(0, min(p.kTilesPerSplit, nk - kbase));
+    }
+  }
+
+  // ---- loaders ----------------------------------------------------------------------------------------------
+  // transposed loader (source rows k-contiguous): thread -> (row t_r + T_ROWS i, k quad t_kq)
+  constexpr int KQ = BK / 4;
+  constexpr int T_ROWS = NTHREADS / KQ;
+  const int t_kq = tid % KQ, t_r = tid / KQ;
+  // direct loader (source k-major) of an operand with R columns: quad index tid + 256 i -> (k row, column quad)
+  constexpr int PA = A_TRANS ? (BM + T_ROWS - 1) / T_ROWS : (BK * (BM / 4) + NTHREADS - 1) / NTHREADS;
+  constexpr int PB = B_TRANS ? (BN + T_ROWS - 1) / T_ROWS : (BK * (BN / 4) + NTHREADS - 1) / NTHREADS;
+  constexpr int NP = PA + PB;  // pieces (one 16-byte load per thread each) per k-tile
+  constexpr int KP = BK / 2;   // k-pairs = MFMA groups per k-tile
+  static_assert(NP <= KP, "piece schedule: one load and one store slot per k-pair");
+
+  // Per-thread source pointers and LDS offsets, computed once.  Out-of-range rows / columns are CLAMPED to a valid
+  // address instead of branched around (the garbage they bring only reaches output rows/columns the epilogue masks);
+  // reduction rows past the segment end in TN are zeroed by a select after the load.
+  const float* pa[PA];
+  const float* pb[PB];
+  int sa[PA], sb[PB];    // LDS offset of the piece (negative: this thread has no element in the piece)
+  int ka[PA], kb[PB];    // direct loader: k row of the piece
+  int gy[PA], gx[PA];    // GATHER (NT/NN): grid coordinates of this thread's A rows
+  int tn_tap = 0;        // GATHER (TN): the tap this N-tile belongs to (cC % BN == 0)
+#pragma unroll
+  for (int i = 0; i < PA; i++) {
+    gy[i] = gx[i] = 0;
+    ka[i] = 0;
+    if (A_TRANS) {
+      const int rl = t_r + T_ROWS * i;
+      sa[i] = (rl < BM) ? (4 * t_kq) * LDA_S + rl : -1;
+      const int r = min(row0 + min(rl, BM - 1), row_end - 1);
+      if (GATHER) {
+        const unsigned t = fast_div((unsigned)r, (unsigned)p.rW, p.mRW);
+        gx[i] = r - (int)t * p.rW;
+        const unsigned b = fast_div(t, (unsigned)p.rH, p.mRH);
+        gy[i] = (int)t - (int)b * p.rH;
+        pa[i] = Ag + (long)b * p.sH * p.sW * p.cC + 4 * t_kq;
+      } else {
+        pa[i] = Ag + (long)r * p.lda + 4 * t_kq + (long)kbase * BK;
+      }
+    } else {
+      constexpr int QR = BM / 4;
+      const int idx = tid + NTHREADS * i;
+      const int kk = idx / QR, cq = idx - kk * QR;
+      ka[i] = kk;
+      sa[i] = (kk < BK) ? kk * LDA_S + 4 * cq : -1;
+      pa[i] = Ag + min(m0 + 4 * cq, p.M - 4);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < PB; i++) {
+    kb[i] = 0;
+    if (B_TRANS) {
+      const int rl = t_r + T_ROWS * i;
+      sb[i] = (rl < BN) ? (4 * t_kq) * LDB_S + rl : -1;
+      const int n = min(n0 + min(rl, BN - 1), p.N - 1);
+      pb[i] = Bg + (long)n * p.ldb + 4 * t_kq + (long)kbase * BK;
+    } else {
+      constexpr int QR = BN / 4;
+      const int idx = tid + NTHREADS * i;
+      const int kk = idx / QR, cq = idx - kk * QR;
+      kb[i] = kk;
+      sb[i] = (kk < BK) ? kk * LDB_S + 4 * cq : -1;
+      const int nc = min(n0 + 4 * cq, p.N - 4);
+      if (MODE == MODE_TN) {
+        if (GATHER) {
+          tn_tap = n0 / p.cC;
+          pb[i] = Bg + (nc - tn_tap * p.cC);  // channel offset inside the tap; the row part is added per load
+        } else {
+          pb[i] = Bg + nc;
+        }
+      } else {  // NN: B[K,N] rows are k
+        pb[i] = Bg + (long)min(kk, BK - 1) * p.ldb + nc + (GATHER ? 0 : (long)kbase * BK * p.ldb);
+      }
+    }
+  }
+  // piece q in [0, NP): q < PA -> A piece q, else B piece q - PA
+  auto load_piece = [&](f32x4 (&ra)[PA], f32x4 (&rb)[PB], int q, int kt) {
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    if (q < PA) {
+      if (MODE == MODE_TN) {
+        const int kr = row0 + kt * BK + ka[q];
+        const int krc = min(kr, row_end - 1);
+        f32x4 v = *reinterpret_cast<const f32x4*>(pa[q] + (long)krc * p.lda);
+        ra[q] = kr < row_end ? v : zero4;
+      } else if (GATHER) {
+        const int kg = kt + kbase;
+        const int tap = (int)(((unsigned)kg * p.cInv) >> 16);  // k-tile -> tap (uniform), channel offset inside it
+        const int c0 = kg * BK - tap * p.cC;
+        const int sy = gather_coord(gy[q], tap / 3, p.cS, p.cT, p.sH);
+        const int sx = gather_coord(gx[q], tap % 3, p.cS, p.cT, p.sW);
+        const long off = ((long)max(sy, 0) * p.sW + max(sx, 0)) * p.cC + c0;
+        f32x4 v = *reinterpret_cast<const f32x4*>(pa[q] + off);
+        ra[q] = (sy >= 0 && sx >= 0) ? v : zero4;
+      } else {
+        ra[q] = *reinterpret_cast<const f32x4*>(pa[q] + kt * BK);
+      }
+    } else {
+      const int i = q - PA;
+      if (MODE == MODE_TN) {
+        const int kr = row0 + kt * BK + kb[i];
+        const int krc = min(kr, row_end - 1);
+        if (GATHER) {
+          // reduction row = output position (b, oy, ox); B row = the input pixel this N-tile's tap reads for it
+          const unsigned t = fast_div((unsigned)krc, (unsigned)p.rW, p.mRW);
+          const int ox = krc - (int)t * p.rW;
+          const unsigned b = fast_div(t, (unsigned)p.rH, p.mRH);
+          const int oy = (int)t - (int)b * p.rH;
+          const int sy = gather_coord(oy, tn_tap / 3, p.cS, p.cT, p.sH);
+          const int sx = gather_coord(ox, tn_tap % 3, p.cS, p.cT, p.sW);
+          const bool ok = kr < row_end && sy >= 0 && sx >= 0;
+          const long off = (((long)b * p.sH + max(sy, 0)) * p.sW + max(sx, 0)) * p.cC;
+          f32x4 v = *reinterpret_cast<const f32x4*>(pb[i] + off);
+          rb[i] = ok ? v : zero4;
+        } else {
+          f32x4 v = *reinterpret_cast<const f32x4*>(pb[i] + (long)krc * p.ldb);
+          rb[i] = kr < row_end ? v : zero4;
+        }
+      } else if (MODE == MODE_NT) {
+        rb[i] = *reinterpret_cast<const f32x4*>(pb[i] + kt * BK);
+      } else if (GATHER) {
+        // NN gather (input gradient): B row k = (tap, co) lives at W[co][tap][:]  (ldb = 9 * Cin, + tap * N columns)
+        const int kg = kt + kbase;
+        const int tap = (int)(((unsigned)kg * p.cInv) >> 16);
+        const int c0 = kg * BK - tap * p.cC;
+        rb[i] = *reinterpret_cast<const f32x4*>(pb[i] + (long)c0 * p.ldb + tap * p.N);
+      } else {
+        rb[i] = *reinterpret_cast<const f32x4*>(pb[i] + (long)kt * BK * p.ldb);
+      }
+    }
+  };
+  auto store_piece = [&](const f32x4 (&ra)[PA], const f32x4 (&rb)[PB], int q, int buf) {
+    if (q < PA) {
+      float* a_s = As + buf * A_STAGE;
+      if (sa[q] >= 0) {
+        if (A_TRANS) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) a_s[sa[q] + j * LDA_S] = ra[q][j];
+        } else {
+          *reinterpret_cast<f32x4*>(a_s + sa[q]) = ra[q];
+        }
+      }
+    } else {
+      const int i = q - PA;
+      float* b_s = Bs + buf * B_STAGE;
+      if (sb[i] >= 0) {
+        if (B_TRANS) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) b_s[sb[i] + j * LDB_S] = rb[i][j];
+        } else {
+          *reinterpret_cast<f32x4*>(b_s + sb[i]) = rb[i];
+        }
+      }
+    }
+  };
+
+  f32x16 acc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; i++)
+#pragma unroll
+    for (int j = 0; j < TJ; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  // Two register sets: while tile kt is multiplied out of LDS, the global loads of tile kt+2 are ISSUED into one set
+  // (first k-pairs) and tile kt+1 -- loaded one iteration earlier, long landed -- is WRITTEN to the other LDS buffer
+  // from the other set (last k-pairs), one piece between each group of MFMAs.  The matrix pipe never waits for address
+  // arithmetic, a vmcnt drain or the LDS write pass; one barrier per k-step remains.
+  f32x4 sa0[PA], sb0[PB], sa1[PA], sb1[PB];
+  if (nk > 0) {
+#pragma unroll
+    for (int q = 0; q < NP; q++) load_piece(sa0, sb0, q, 0);
+#pragma unroll
+    for (int q = 0; q < NP; q++) store_piece(sa0, sb0, q, 0);
+#pragma unroll
+    for (int q = 0; q < NP; q++) load_piece(sa0, sb0, q, min(1, nk - 1));
+  }
+  __syncthreads();
+
+  auto k_step = [&](f32x4 (&ca)[PA], f32x4 (&cb)[PB], f32x4 (&na)[PA], f32x4 (&nb)[PB], int kt) {
+    // ca/cb hold tile kt+1 (to be stored), na/nb receive tile kt+2
+    const int buf = kt & 1;
+    // branch-free on purpose: a conditional around a load makes hipcc drain vmcnt(0) at the join, serialising the
+    // pipeline.  Past the end the last tile is simply re-loaded / re-stored into the idle buffer (never read).
+    const int kt_load = min(kt + 2, nk - 1);
+    const float* a_s = As + buf * A_STAGE + wm0 + l31;
+    const float* b_s = Bs + buf * B_STAGE + wn0 + l31;
+    float a[TI], b[TJ];
+#pragma unroll
+    for (int i = 0; i < TI; i++) a[i] = a_s[lh * LDA_S + 32 * i];
+#pragma unroll
+    for (int j = 0; j < TJ; j++) b[j] = b_s[lh * LDB_S + 32 * j];
+#pragma unroll
+    for (int kk = 0; kk < KP; kk++) {
+      float xa[TI], xb[TJ];
+#pragma unroll
+      for (int i = 0; i < TI; i++) xa[i] = 0.f;
+#pragma unroll
+      for (int j = 0; j < TJ; j++) xb[j] = 0.f;
+      if (kk + 1 < KP) {  // fragment reads of the NEXT k-pair go out before this k-pair's MFMAs
+        const int krow = 2 * (kk + 1) + lh;
+#pragma unroll
+        for (int i = 0; i < TI; i++) xa[i] = a_s[krow * LDA_S + 32 * i];
+#pragma unroll
+        for (int j = 0; j < TJ; j++) xb[j] = b_s[krow * LDB_S + 32 * j];
+      }
+      if (kk < NP) load_piece(na, nb, kk, kt_load);
+      if (kk >= KP - NP) store_piece(ca, cb, kk - (KP - NP), buf ^ 1);
+      __builtin_amdgcn_sched_barrier(0);  // everything above is issued before this k-pair's MFMAs
+      // operands swapped on purpose: D = (B fragment) x (A fragment) = the TRANSPOSED 32x32 tile, so that each lane
+      // ends up with 4 consecutive output COLUMNS of one row -> 16-byte epilogue loads/stores
+#pragma unroll
+      for (int i = 0; i < TI; i++)
+#pragma unroll
+        for (int j = 0; j < TJ; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j], a[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TI; i++) a[i] = xa[i];
+#pragma unroll
+      for (int j = 0; j < TJ; j++) b[j] = xb[j];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+  };
+  for (int kt = 0; kt < nk; kt += 2) {
+    k_step(sa0, sb0, sa1, sb1, kt);
+    if (kt + 1 < nk) k_step(sa1, sb1, sa0, sb0, kt + 1);
+  }
+
+  // ---- split-K fix-up: publish this slice, the last arriver of the tile sums all slices in order ------------
+  if (p.splits > 1 && p.fixup) {
+    constexpr int NF = TI * TJ * 4;  // float4 fragments per thread
+    const long tile_id = (MODE == MODE_TN ? (long)g * gridDim.x : 0) + bid;
+    float* tile_slabs = p.slabs + tile_id * p.splits * (long)(BM * BN);
+    f32x4* mine = reinterpret_cast<f32x4*>(tile_slabs + (long)split * (BM * BN));
+#pragma unroll
+    for (int i = 0; i < TI; i++)
+#pragma unroll
+      for (int j = 0; j < TJ; j++)
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+          mine[((i * TJ + j) * 4 + q) * NTHREADS + tid] =
+              f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its slab stores have left the CU
+    __syncthreads();
+    int* flag = reinterpret_cast<int*>(smem);  // the k-loop ended with a barrier: LDS is free
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const int ticket = __hip_atomic_fetch_add(p.counters + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *flag = (ticket == p.splits - 1);
+    }
+    __syncthreads();
+    if (!*flag) return;
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __hip_atomic_store(p.counters + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TI; i++)
+#pragma unroll
+      for (int j = 0; j < TJ; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    for (int s = 0; s < p.splits; s++) {  // slice order, whoever arrived last: deterministic sum
+      const f32x4* sl = reinterpret_cast<const f32x4*>(tile_slabs + (long)s * (BM * BN));
+      f32x4 v[NF];
+#pragma unroll
+      for (int f = 0; f < NF; f++) v[f] = sl[f * NTHREADS + tid];
+#pragma unroll
+      for (int i = 0; i < TI; i++)
+#pragma unroll
+        for (int j = 0; j < TJ; j++)
+#pragma unroll
+          for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) acc[i][j][4 * q + e] += v[(i * TJ + j) * 4 + q][e];
+    }
+    __syncthreads();  // `flag` word is reused by the column-sum scratch below
+  }
+
+  // ---- epilogue ---------------------------------------------------------------------------------------------
+  // acc[i][j][4q + e]: row = wm0 + 32 i + l31 ; col = wn0 + 32 j + 8 q + 4 lh + e   (e = 0..3 contiguous)
+  float* __restrict__ Cg = p.C;
+  long c_base = 0;
+  int m_lim;
+  if (p.splits > 1 && !p.fixup) c_base = (long)blockIdx.z * p.strideC;  // raw slice z of a later reduce pass
+  else if (MODE == MODE_TN) c_base = (long)g * p.strideC;
+  m_lim = (MODE == MODE_TN) ? p.M : row_end;
+  const float* bias = (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_SCALE_RES || EPI == EPI_BIAS_RELU)
+                          ? p.bias + (long)g * p.strideBias
+                          : nullptr;
+  f32x4 csum[TJ][4];
+  if (EPI == EPI_GELU_BWD) {
+#pragma unroll
+    for (int j = 0; j < TJ; j++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) csum[j][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int i = 0; i < TI; i++) {
+    const int row = m0 + wm0 + 32 * i + l31;
+    if (row >= m_lim) continue;
+    float rsc = 1.f;
+    if (EPI == EPI_BIAS_SCALE_RES && p.rowscale) rsc = p.rowscale[row / p.rows_per_scale];
+#pragma unroll
+    for (int j = 0; j < TJ; j++) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int col = n0 + wn0 + 32 * j + 8 * q + 4 * lh;
+        if (col >= p.N) continue;
+        f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+        float* cp = Cg + c_base + (long)row * p.ldc + col;
+        const long ai = (long)row * p.ld_aux + col;
+        if (EPI == EPI_NONE) {
+          *reinterpret_cast<f32x4*>(cp) = v;
+        } else if (EPI == EPI_BIAS) {
+          *reinterpret_cast<f32x4*>(cp) = v + *reinterpret_cast<const f32x4*>(bias + col);
+        } else if (EPI == EPI_BIAS_RELU) {
+          f32x4 o = v + *reinterpret_cast<const f32x4*>(bias + col);
+#pragma unroll
+          for (int e = 0; e < 4; e++) o[e] = fmaxf(o[e], 0.f);
+          *reinterpret_cast<f32x4*>(cp) = o;
+        } else if (EPI == EPI_BIAS_GELU) {
+          const f32x4 h = v + *reinterpret_cast<const f32x4*>(bias + col);
+          f32x4 y, dy;
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            float ye, de;
+            gelu_erf_both(h[e], ye, de);
+            y[e] = ye;
+            dy[e] = de;
+          }
+          *reinterpret_cast<f32x4*>(p.aux_out + ai) = dy;
+          *reinterpret_cast<f32x4*>(cp) = y;
+        } else if (EPI == EPI_BIAS_SCALE_RES) {
+          const f32x4 y = v + *reinterpret_cast<const f32x4*>(bias + col);
+          *reinterpret_cast<f32x4*>(p.aux_out + ai) = y;
+          const f32x4 sc = *reinterpret_cast<const f32x4*>(p.gamma + col) * rsc;
+          *reinterpret_cast<f32x4*>(cp) = *reinterpret_cast<const f32x4*>(p.aux_in + ai) + sc * y;
+        } else if (EPI == EPI_GELU_BWD) {
+          const f32x4 o = v * *reinterpret_cast<const f32x4*>(p.aux_in + ai);
+          *reinterpret_cast<f32x4*>(cp) = o;
+          csum[j][q] += o;
+        }
+      }
+    }
+  }
+  if (EPI == EPI_GELU_BWD) {
+    if (p.colpart) {  // uniform branch: column sums of this row tile -> colpart[tile_m][n]
+      // rows live across the 32 lanes of each half-wave: xor-shuffle tree inside the half, then the WM waves that share
+      // a column range meet in LDS (WM x BN floats; the k-loop / fix-up ended with a barrier, so LDS is free)
+      float* red = smem;  // [4 waves][TJ*32]
+#pragma unroll
+      for (int j = 0; j < TJ; j++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          f32x4 s = csum[j][q];
+#pragma unroll
+          for (int o = 16; o > 0; o >>= 1)
+#pragma unroll
+            for (int e = 0; e < 4; e++) s[e] += __shfl_xor(s[e], o, 64);
+          if (l31 == 0) *reinterpret_cast<f32x4*>(red + wave * (TJ * 32) + 32 * j + 8 * q + 4 * lh) = s;
+        }
+      __syncthreads();
+      if (tid < BN && n0 + tid < p.N) {
+        const int wn = tid / (TJ * 32), c = tid - wn * (TJ * 32);
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; w++) t += red[(w * WN + wn) * (TJ * 32) + c];
+        p.colpart[(long)tile_m * p.N + n0 + tid] = t;
+      }
+    }
+  }
+}
+
+// launchers (one translation unit per mode: gemm_f32.hip = NT, gemm_f32_nn.hip, gemm_f32_tn.hip)
+// tile: 0 128x128, 1 128x96, 2 96x128, 3 128x192, 4 192x128, 5 64x128 ; bk: 16 | 32 ; returns SM3_* code
+int launch_nt(const GemmParams& p, int epi, int tile, int bk, int gather, dim3 grid, hipStream_t st);
+int launch_nn(const GemmParams& p, int epi, int tile, int bk, int gather, dim3 grid, hipStream_t st);
+int launch_tn(const GemmParams& p, int tile, int bk, int gather, dim3 grid, hipStream_t st);
+
+inline void tile_dims(int tile, int& bm, int& bn) {
+  static const int d[6][2] = {{128, 128}, {128, 96}, {96, 128}, {128, 192}, {192, 128}, {64, 128}};
+  bm = d[tile][0];
+  bn = d[tile][1];
+}
+
+}  // namespace sm3gemm

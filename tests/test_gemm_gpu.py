@@ -166,3 +166,144 @@ def test_gemm_throughput_report():
     torch.cuda.synchronize()
     ms2 = t0.elapsed_time(t1) / 20
     print(f'torch.matmul (rocBLAS/hipBLASLt) same shape: {ms2 * 1e3:.1f} us, {2 * M * N * K / ms2 / 1e9:.1f} TFLOP/s')
+
+
+# ------------------------------------------------------------------------------------------ tile shapes / split-K fix-up
+def _tune(tile=None, bk=None, splits=0, fixup=False):
+    """sm3_gemm_desc.tuning word (include/sm3det_hip.h)"""
+    return ((tile + 1) if tile is not None else 0) | ({None: 0, 16: 1, 32: 2}[bk] << 4) | (splits << 8) | (int(fixup) << 16)
+
+
+class _tuned:
+    def __init__(self, **kw):
+        self.word = _tune(**kw)
+
+    def __enter__(self):
+        LB = _mods()
+        self.old, LB.TUNING = LB.TUNING, self.word
+
+    def __exit__(self, *exc):
+        _mods().TUNING = self.old
+
+
+@pytest.mark.parametrize('mode,tile,bk', [
+    ('nt', 0, 16), ('nt', 0, 32), ('nt', 1, 16), ('nt', 1, 32), ('nt', 3, 16), ('nt', 5, 16), ('nt', 5, 32),
+    ('nn', 0, 16), ('nn', 1, 16), ('nn', 1, 32), ('nn', 3, 16), ('nn', 5, 32),
+    ('tn', 0, 16), ('tn', 0, 32), ('tn', 1, 16), ('tn', 2, 16), ('tn', 2, 32), ('tn', 3, 16), ('tn', 4, 16)])
+@pytest.mark.parametrize('splits', [1, 3])
+def test_every_tile_shape_and_k_step_with_and_without_split_k_fixup(mode, tile, bk, splits):
+    """every instantiated (tile, k-step) of each mode on a shape with ragged edges in M and N, without split-K and with
+    the in-kernel last-arriver fix-up (3 slices), against fp64."""
+    LB = _mods()
+    M, N, K = 333, 292, 448  # M, N not multiples of any tile edge; K = 14 k-tiles of 32
+    with _tuned(tile=tile, bk=bk, splits=splits):
+        if mode == 'nt':
+            A, B, bias = _rand(M, K, seed=1), _rand(N, K, seed=2), _rand(N, seed=3)
+            C = torch.full((M, N), float('nan'), device='cuda')
+            LB.gemm(LB.NT, A, B, C, M, N, K, epilogue=LB.EPI_BIAS, bias=bias)
+            _close(C, A.double() @ B.double().t() + bias.double())
+        elif mode == 'nn':
+            A, B = _rand(M, K, seed=4), _rand(K, N, seed=5)
+            C = torch.full((M, N), float('nan'), device='cuda')
+            LB.gemm(LB.NN, A, B, C, M, N, K)
+            _close(C, A.double() @ B.double())
+        else:
+            Kt, Mo, No = 1111, 292, 332
+            A, B = _rand(Kt, Mo, seed=6), _rand(Kt, No, seed=7)
+            for fix in (False, True):
+                C = torch.full((Mo, No), float('nan'), device='cuda')
+                LB.TUNING = _tune(tile=tile, bk=bk, splits=splits, fixup=fix)
+                LB.gemm(LB.TN, A, B, C, Mo, No, Kt)
+                _close(C, A.double().t() @ B.double())
+    # the ticket counters are left zeroed
+    assert int(LB.gemm_counters(torch.device('cuda', torch.cuda.current_device())).abs().sum()) == 0
+
+
+def test_default_tile_choice_for_convnext_widths():
+    """N = 96 / 192 / 288 (ConvNeXt-T stage widths, gate projection) take the exact-width tiles by default; results
+    still equal fp64 and the GELU / scale-residual / GELU-backward epilogues work on them."""
+    LB = _mods()
+    for M, N, K in [(1000, 96, 384), (777, 192, 768), (515, 288, 768), (300, 96, 3072)]:
+        A, B, bias = _rand(M, K, seed=N), _rand(N, K, seed=N + 1) * 0.1, _rand(N, seed=N + 2)
+        res, gamma = _rand(M, N, seed=N + 3), _rand(N, seed=N + 4)
+        y, out = torch.empty(M, N, device='cuda'), torch.empty(M, N, device='cuda')
+        LB.gemm(LB.NT, A, B, out, M, N, K, epilogue=LB.EPI_BIAS_SCALE_RES, bias=bias, aux_in=res, aux_out=y,
+                gamma=gamma)
+        y64 = A.double() @ B.double().t() + bias.double()
+        _close(y, y64)
+        _close(out, res.double() + gamma.double()[None] * y64)
+        # NN with GELU-backward epilogue + fused column sums on the same widths
+        dY, W, hp = _rand(M, K, seed=N + 5), _rand(K, N, seed=N + 6) * 0.1, _rand(M, N, seed=N + 7)
+        dH, db = torch.empty(M, N, device='cuda'), torch.empty(N, device='cuda')
+        LB.gemm(LB.NN, dY, W, dH, M, N, K, epilogue=LB.EPI_GELU_BWD, aux_in=hp, colsum_out=db)
+        ref = (dY.double() @ W.double()) * hp.double()
+        _close(dH, ref)
+        _close(db, ref.sum(0), tol=2e-4)
+    for Kt, M, N in [(5000, 96, 384), (5000, 384, 96), (3000, 192, 768), (3000, 768, 192), (4000, 224, 384)]:
+        A, B = _rand(Kt, M, seed=M), _rand(Kt, N, seed=N)
+        C = torch.empty(M, N, device='cuda')
+        LB.gemm(LB.TN, A, B, C, M, N, Kt)
+        _close(C, A.double().t() @ B.double())
+
+
+@pytest.mark.parametrize('splits', [2, 5, 8])
+def test_split_k_fixup_with_every_epilogue_and_ragged_groups(splits):
+    """NT / NN launches sliced along K with the last-arriver fix-up: the epilogue (bias+GELU with its second output,
+    GELU-backward with fused per-expert column sums) runs once, in the last block, on the summed accumulators; ragged
+    expert segments incl. empty ones; repeated launches reuse the self-resetting counters."""
+    LB = _mods()
+    E, counts = 8, [300, 0, 129, 1, 128, 500, 64, 7]
+    C_, Hd = 384, 1536
+    S = sum(counts)
+    offs = torch.tensor(np.concatenate([[0], np.cumsum(counts)]), dtype=torch.int32, device='cuda')
+    X, W1, b1 = _rand(S, C_, seed=20), _rand(E, Hd, C_, seed=21) * 0.05, _rand(E, Hd, seed=22)
+    ref = torch.cat([X[offs[e]:offs[e + 1]].double() @ W1[e].double().t() + b1[e].double() for e in range(E)])
+    for rep in range(2):
+        hpre, act = torch.zeros(S, Hd, device='cuda'), torch.zeros(S, Hd, device='cuda')
+        with _tuned(splits=splits):
+            LB.gemm(LB.NT, X, W1, act, S, Hd, C_, epilogue=LB.EPI_BIAS_GELU, bias=b1, aux_out=hpre, offsets=offs,
+                    num_groups=E)
+        _close(act, torch.nn.functional.gelu(ref), tol=2e-4)
+    dY, W2 = _rand(S, C_, seed=24), _rand(E, C_, Hd, seed=25) * 0.05
+    dHg, dbg = torch.zeros(S, Hd, device='cuda'), torch.full((E, Hd), float('nan'), device='cuda')
+    with _tuned(splits=splits):
+        LB.gemm(LB.NN, dY, W2, dHg, S, Hd, C_, epilogue=LB.EPI_GELU_BWD, aux_in=hpre, offsets=offs, num_groups=E,
+                colsum_out=dbg)
+    refg = torch.cat([dY[offs[e]:offs[e + 1]].double() @ W2[e].double() for e in range(E)]) * hpre.double()
+    _close(dHg, refg)
+    _close(dbg, torch.stack([refg[offs[e]:offs[e + 1]].sum(0) for e in range(E)]), tol=2e-4)
+    # grouped TN: the second reduce pass (default) and the in-kernel fix-up give the same sums
+    dH = _rand(S, Hd, seed=23)
+    outs = []
+    for fix in (False, True):
+        dW = torch.full((E, Hd, C_), float('nan'), device='cuda')
+        with _tuned(splits=splits, fixup=fix):
+            LB.gemm(LB.TN, dH, X, dW, Hd, C_, S, offsets=offs, num_groups=E)
+        outs.append(dW)
+    refw = torch.stack([dH[offs[e]:offs[e + 1]].double().t() @ X[offs[e]:offs[e + 1]].double() for e in range(E)])
+    _close(outs[0], refw)
+    _close(outs[1], refw)
+    assert int(LB.gemm_counters(torch.device('cuda', torch.cuda.current_device())).abs().sum()) == 0
+
+
+def test_automatic_split_k_on_few_tile_long_k_shapes_is_deterministic():
+    """the stage-3 dense FFN shapes (96 / 384 output tiles on 256 CUs) slice K automatically; two launches give
+    bit-identical results (slices are summed in slice order, whichever block arrives last)."""
+    LB = _mods()
+    for M, N, K in [(2048, 768, 3072), (2048, 3072, 768), (8192, 384, 1536)]:
+        A, B, bias = _rand(M, K, seed=1), _rand(N, K, seed=2) * 0.05, _rand(N, seed=3)
+        C1, C2 = torch.empty(M, N, device='cuda'), torch.empty(M, N, device='cuda')
+        LB.gemm(LB.NT, A, B, C1, M, N, K, epilogue=LB.EPI_BIAS, bias=bias)
+        LB.gemm(LB.NT, A, B, C2, M, N, K, epilogue=LB.EPI_BIAS, bias=bias)
+        assert torch.equal(C1, C2)
+        _close(C1, A.double() @ B.double().t() + bias.double())
+
+
+@pytest.mark.parametrize('splits', [9, 28, 341])
+def test_tn_many_slices_separate_reduce(splits):
+    LB = _mods()
+    Kt, M, N = 131072 // 4, 96, 384
+    A, B = _rand(Kt, M, seed=6), _rand(Kt, N, seed=7)
+    C = torch.empty(M, N, device='cuda')
+    LB.gemm(LB.TN, A, B, C, M, N, Kt, splits=splits)
+    _close(C, A.double().t() @ B.double())
