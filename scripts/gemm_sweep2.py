@@ -15,9 +15,9 @@ from sm3det_amd import _lib_backbone as LB  # noqa: E402
 E = 8
 
 
-def tune(tile=None, bk=None, splits=0, separate=False):
+def tune(tile=None, bk=None, splits=0, separate=False, staged=False):  # staged: historical A/B, now always on
     # bit 16 = TN in-kernel fix-up; `separate` (the default path) is the absence of it
-    return ((tile + 1) if tile is not None else 0) | ({None: 0, 16: 1, 32: 2}[bk] << 4) | (splits << 8) | (int(not separate) << 16)
+    return ((tile + 1) if tile is not None else 0) | ({None: 0, 16: 1, 32: 2}[bk] << 4) | (splits << 8) | (int(not separate) << 16) | (int(staged) << 17)
 
 
 # (mode, M, N, K, groups, epilogue, count per step)
@@ -50,6 +50,14 @@ SHAPES = [
 
 def candidates(mode, M, N, K, quick):
     out = [dict()]
+    if '--staged' in sys.argv:  # A/B of the LDS-staged epilogue on the default configuration and its neighbours
+        if mode == 'tn':
+            return [dict(separate=True), dict(separate=True, staged=True)]
+        for t in (0, 1, 5):
+            for bk in (16, 32):
+                out.append(dict(tile=t, bk=bk, splits=1))
+                out.append(dict(tile=t, bk=bk, splits=1, staged=True))
+        return out + [dict(staged=True)]
     if mode == 'tn':
         for t in (0, 1, 2, 3, 4):
             for bk in ((16, 32) if t < 3 else (16,)):

@@ -224,7 +224,6 @@ Cfg choose_cfg(const sm3_gemm_desc* d) {
       const double pc = (double)tiles / kNumCU;
       const double occ = pc < 1.0 ? 1.2 : (pc < 2.0 ? 1.0 + 0.2 * (2.0 - pc) : 1.0);
       double cost = quant_cost(tiles) * handicap[i] * waste * occ;
-      if (d->K <= 192 && cand[i] == 5 && d->epilogue == EPI_BIAS_GELU) cost *= 0.95;  // short K + heavy epilogue
       if (c.tile < 0 || cost < best - 1e-9) { best = cost; c.tile = cand[i]; best_tiles = tiles; }
     }
     if (t_tile >= 0) c.tile = t_tile;

@@ -307,3 +307,47 @@ def test_tn_many_slices_separate_reduce(splits):
     C = torch.empty(M, N, device='cuda')
     LB.gemm(LB.TN, A, B, C, M, N, Kt, splits=splits)
     _close(C, A.double().t() @ B.double())
+
+
+@pytest.mark.parametrize('tile,bk', [(0, 16), (0, 32), (1, 16), (1, 32), (3, 16), (5, 16), (5, 32)])
+def test_every_epilogue_kind_on_every_tile(tile, bk):
+    """the LDS-staged (row-contiguous, full-cache-line) epilogue against fp64 for every epilogue kind on every NT / NN
+    tile shape, ragged M / N, grouped rows, with and without the split-K fix-up in front of it"""
+    LB = _mods()
+    E, counts = 4, [150, 0, 77, 130]
+    S = sum(counts)
+    offs = torch.tensor(np.concatenate([[0], np.cumsum(counts)]), dtype=torch.int32, device='cuda')
+    C_, Hd = 192, 292
+    X, W1, b1 = _rand(S, C_, seed=20), _rand(E, Hd, C_, seed=21) * 0.1, _rand(E, Hd, seed=22)
+    ref = torch.cat([X[offs[e]:offs[e + 1]].double() @ W1[e].double().t() + b1[e].double() for e in range(E)])
+    for splits in (1, 2):
+        hpre, act = torch.zeros(S, Hd, device='cuda'), torch.zeros(S, Hd, device='cuda')
+        with _tuned(tile=tile, bk=bk, splits=splits):
+            LB.gemm(LB.NT, X, W1, act, S, Hd, C_, epilogue=LB.EPI_BIAS_GELU, bias=b1, aux_out=hpre, offsets=offs,
+                    num_groups=E)
+        _close(act, torch.nn.functional.gelu(ref), tol=2e-4)
+        dY, W2 = _rand(S, C_, seed=24), _rand(E, C_, Hd, seed=25) * 0.1
+        dHg, dbg = torch.zeros(S, Hd, device='cuda'), torch.full((E, Hd), float('nan'), device='cuda')
+        with _tuned(tile=tile, bk=bk, splits=splits):
+            LB.gemm(LB.NN, dY, W2, dHg, S, Hd, C_, epilogue=LB.EPI_GELU_BWD, aux_in=hpre, offsets=offs, num_groups=E,
+                    colsum_out=dbg)
+        refg = torch.cat([dY[offs[e]:offs[e + 1]].double() @ W2[e].double() for e in range(E)]) * hpre.double()
+        _close(dHg, refg)
+        _close(dbg, torch.stack([refg[offs[e]:offs[e + 1]].sum(0) for e in range(E)]), tol=2e-4)
+    M, N, K = 333, 292, 448
+    A, B, bias = _rand(M, K, seed=1), _rand(N, K, seed=2) * 0.1, _rand(N, seed=3)
+    res, gamma = _rand(M, N, seed=4), _rand(N, seed=5)
+    rs = torch.tensor([0.0, 1.0 / 0.9, 1.0], device='cuda')
+    y, out = torch.empty(M, N, device='cuda'), torch.empty(M, N, device='cuda')
+    with _tuned(tile=tile, bk=bk):
+        LB.gemm(LB.NT, A, B, out, M, N, K, epilogue=LB.EPI_BIAS_SCALE_RES, bias=bias, aux_in=res, aux_out=y,
+                gamma=gamma, rowscale=rs, rows_per_scale=128)
+        y64 = A.double() @ B.double().t() + bias.double()
+        _close(y, y64)
+        sc = rs.double().repeat_interleave(128)[:M, None] * gamma.double()[None]
+        _close(out, res.double() + sc * y64)
+        for epi, f in ((LB.EPI_NONE, lambda t: t - bias.double()), (LB.EPI_BIAS, lambda t: t),
+                       (LB.EPI_BIAS_RELU, lambda t: t.clamp_min(0))):
+            C = torch.full((M, N), float('nan'), device='cuda')
+            LB.gemm(LB.NT, A, B, C, M, N, K, epilogue=epi, bias=bias if epi != LB.EPI_NONE else None)
+            _close(C, f(y64))
