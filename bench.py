@@ -344,8 +344,13 @@ def main():
     local_rank = local_rank % torch.cuda.device_count() if backend != 'nccl' else local_rank
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
-    if world > 1:
+    # SM3_BENCH_FORCE_DIST=1: initialise the process group and run the bucket / collective / split-backward flow even
+    # with ONE rank (the all-reduces are identities) -- the multi-GPU code path on a 1-GPU box (tests/test_dp_rccl_gpu.py)
+    force_dist = os.environ.get('SM3_BENCH_FORCE_DIST') == '1' and world == 1
+    multi = world > 1 or force_dist
+    if multi:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
         if backend == 'nccl':
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
         else:
@@ -359,13 +364,14 @@ def main():
     params = [p for p in net.parameters() if p.requires_grad]
     # N>1: the backward is replayed in two segments -- stages 3+2 (93 % of the gradient bytes) first, whose buckets are
     # all-reduced over xGMI while the backward of stages 1+0 still runs (SM3_BENCH_SPLIT=0/1 overrides; N=1 default off)
-    split = os.environ.get('SM3_BENCH_SPLIT', '1' if world > 1 else '0') == '1'
+    split = os.environ.get('SM3_BENCH_SPLIT', '1' if multi else '0') == '1'
     LATE = ('stages.2.', 'stages.3.', 'downsample_layers.2.', 'downsample_layers.3.', 'norm2.', 'norm3.')
     named = [(n, p) for n, p in net.named_parameters() if p.requires_grad]
     late_params = [p for n, p in reversed(named) if n.startswith(LATE)]
     early_params = [p for n, p in reversed(named) if not n.startswith(LATE)]
-    reducer = BucketedGradReducer(params, bucket_mb=64.0, groups=[late_params, early_params] if split else None)
-    reducer.broadcast_parameters(0)
+    reducer = BucketedGradReducer(params, bucket_mb=64.0, groups=[late_params, early_params] if split else None,
+                                  force_comm=force_dist)
+    reducer.broadcast_parameters(0, module=net)
     # optimizer of local_configs/main_SM3Det.py: AdamW(lr 1e-4, betas (0.9, 0.999), wd 0.05), one param group per
     # parameter (paramwise_cfg / dynamic-lr hook), grad_clip max_norm 35 -- here one fused launch with a per-tensor lr vector
     from sm3det_amd.optim import MultiTensorAdamW
@@ -391,7 +397,7 @@ def main():
         return loss
 
     def fence():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -448,7 +454,7 @@ def main():
         torch.cuda.current_stream().wait_stream(side)
         fence()
         # N>1: RCCL's watchdog thread may touch the HIP runtime while this thread captures -> thread-local capture mode
-        cap_kw = dict(capture_error_mode='thread_local') if world > 1 else {}
+        cap_kw = dict(capture_error_mode='thread_local') if multi else {}
         try:
             g_fb, g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             if split:
@@ -503,7 +509,7 @@ def main():
         loss = run()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([dt], device='cuda', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -511,7 +517,7 @@ def main():
     value = world * BATCH * args.steps / dt
     # replicas must stay bit-identical (same averaged gradients on every rank): spread of a parameter checksum
     replica_spread = 0.0
-    if world > 1:
+    if multi:
         chk = torch.stack([p.detach().double().sum() for p in params]).sum().reshape(1)
         lo, hi = chk.clone(), chk.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
@@ -577,6 +583,7 @@ def main():
                        'global_batch': world * BATCH, 'resolution': RES, 'parallelism': f'dp{world}',
                        'grad_buckets': reducer.num_buckets, 'hip_graph': bool(use_graph),
                        'wgrad_side_stream': bool(overlap_was), 'split_backward': bool(split and use_graph),
+                       'dist_backend': (backend if multi else None), 'collective_avg': bool(reducer._avg),
                        'replica_checksum_spread': replica_spread},
             'loss': float(loss.detach()),
             'roofline': roofline,
@@ -589,7 +596,7 @@ def main():
         else:
             result['cpu_baseline'] = None
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -14,8 +14,10 @@ distributed.py:13-87 -> torch DDP's C++ reducer, 25 MiB buckets, mmrotate/apis/t
   ~28.  Buckets are filled in reverse parameter order (= the order backward produces gradients); the moment the
   last gradient of a bucket exists it is packed (one multi-tensor copy) and all-reduced asynchronously on RCCL's own
   stream, overlapping the remaining backward kernels;
-* ``finalize()`` waits for the outstanding collectives, applies the 1/world_size mean in one pass per bucket and
-  re-points every ``p.grad`` at its slice of the reduced bucket (no copy back), so any optimizer sees the mean;
+* the collectives AVERAGE in flight (``ReduceOp.AVG`` on RCCL; backends without it -- gloo in the CPU tests -- sum and
+  ``finalize()`` divides), so no extra 0.56 GB pass over the buckets follows them; ``finalize()`` waits for the
+  outstanding collectives and re-points every ``p.grad`` at its slice of the reduced bucket (no copy back), so any
+  optimizer sees the mean;
 * world_size == 1: nothing is allocated or launched; ``p.grad`` stays the tensor autograd produced;
 * ``allreduce_scalars()`` fuses any number of logging scalars into ONE small all-reduce.
 
@@ -27,12 +29,20 @@ import torch.distributed as dist
 
 
 class BucketedGradReducer:
-    def __init__(self, params, bucket_mb=64.0, process_group=None, groups=None):
-        """groups: optional list of parameter lists (a partition of ``params``, in the order their gradients become
+    def __init__(self, params, bucket_mb=64.0, process_group=None, groups=None, force_comm=False):
+        """params: ANY trainable parameters whose gradients are to be averaged -- the backbone's, or the whole detector's
+        (backbone + neck + heads), exactly what the reference hands to DDP.
+        groups: optional list of parameter lists (a partition of ``params``, in the order their gradients become
         available); buckets never straddle two groups, so a whole group can be packed / all-reduced as soon as the
-        backward segment that produces it is done (``pack_group`` / ``allreduce_group_async``)."""
+        backward segment that produces it is done (``pack_group`` / ``allreduce_group_async``).
+        force_comm: run the bucket + collective path even in a 1-rank group (the collectives are then identities); used
+        to exercise RCCL initialisation, stream hand-over and hipGraph coexistence on a single-GPU box."""
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.comm = self.world > 1 or (bool(force_comm) and dist.is_initialized())
+        # average inside the collective where the backend can (RCCL); otherwise sum and divide in finalize()
+        self._avg = bool(self.comm and dist.get_backend(process_group) == 'nccl')
+        self._op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError('no trainable parameters')
@@ -68,7 +78,7 @@ class BucketedGradReducer:
 
     def _close(self, plist, group=0):
         flat, views = None, None
-        if self.world > 1:
+        if self.comm:
             total = sum(p.numel() for p in plist)
             flat = torch.zeros(total, dtype=plist[0].dtype, device=plist[0].device)
             views, off = [], 0
@@ -92,7 +102,7 @@ class BucketedGradReducer:
 
     def _pack(self, b):
         """gradients of one bucket -> its flat buffer (parameters without a gradient contribute zeros)."""
-        if b['packed'] or self.world == 1:
+        if b['packed'] or not self.comm:
             return
         src, dst = [], []
         for p, v in zip(b['params'], b['views']):
@@ -117,33 +127,34 @@ class BucketedGradReducer:
 
     def allreduce_group_async(self, g):
         """issue the all-reduces of one group's (already packed) buckets; finalize() waits for them"""
-        if self.world > 1:
+        if self.comm:
             for b in self.buckets:
                 if b['group'] == g and b['handle'] is None:
-                    b['handle'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                    b['handle'] = dist.all_reduce(b['flat'], op=self._op, group=self.group, async_op=True)
 
     def _on_grad(self, p):
         if not self._armed:
             return
         b = self.buckets[self._index[p]]
         b['pending'] -= 1
-        if b['pending'] == 0 and self.world > 1 and self.overlap:
+        if b['pending'] == 0 and self.comm and self.overlap:
             self._pack(b)
-            b['handle'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            b['handle'] = dist.all_reduce(b['flat'], op=self._op, group=self.group, async_op=True)
 
     def finalize(self, repack=True):
         """Wait for the in-flight collectives (packing + launching any bucket whose last gradient never arrived), turn
         the sums into means and point every ``p.grad`` at its reduced slice.  ``repack=False``: the flats were filled by
         a replayed graph that ended in ``pack_all()`` -- only reduce."""
-        if self.world > 1:
+        if self.comm:
             for b in self.buckets:
                 if b['handle'] is None:
                     if repack:
                         self._pack(b)
-                    b['handle'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                    b['handle'] = dist.all_reduce(b['flat'], op=self._op, group=self.group, async_op=True)
             for b in self.buckets:
                 b['handle'].wait()
-                b['flat'].div_(self.world)
+                if not self._avg and self.world > 1:
+                    b['flat'].div_(self.world)
                 b['handle'] = None
                 for p, v in zip(b['params'], b['views']):
                     p.grad = v
@@ -158,11 +169,21 @@ class BucketedGradReducer:
             t /= self.world
         return t
 
-    def broadcast_parameters(self, src=0):
-        """rank-0 parameters/buffers to everyone (torch DDP does this at construction)."""
+    def broadcast_parameters(self, src=0, module=None, extra=()):
+        """rank-src state to everyone (torch DDP does this at construction): the trainable parameters, plus -- when
+        ``module`` is given -- every parameter (frozen stages included) and buffer of it, plus any ``extra`` tensors."""
         if self.world > 1:
-            for p in self.params:
-                dist.broadcast(p.data, src=src, group=self.group)
+            seen, todo = set(), []
+            sources = [self.params, extra]
+            if module is not None:
+                sources += [module.parameters(), module.buffers()]
+            for src_list in sources:
+                for t in src_list:
+                    if id(t) not in seen:
+                        seen.add(id(t))
+                        todo.append(t)
+            for t in todo:
+                dist.broadcast(t.data, src=src, group=self.group)
 
     def remove_hooks(self):
         for h in self._hooks:
