@@ -25,17 +25,31 @@ constexpr int LDS_PATCH = PH * PW * PS;           // floats (77.4 KB -> two work
 constexpr int TH_B = 8;                           // weight-gradient kernel: 8-row tiles (65.7 KB of LDS)
 constexpr int LDS_PATCH_B = (TH_B + 6) * PW * PS;
 
+// ROWS x 22 pixels x 8 quads; out-of-image pixels are zero (padding=3).  All of a thread's 16-byte loads are ISSUED
+// before the first LDS store (one wait for the batch instead of one L2/HBM round trip per loop iteration: the
+// workgroup's prologue was the longest phase of the kernel, ~15 dependent round trips with 2 workgroups per CU).
 template <int ROWS>
 __device__ __forceinline__ void load_patch(const float* __restrict__ x, int b, int H, int W, int C, int y0, int x0,
                                            int c0, float* patch) {
-  // ROWS x 22 pixels x 8 quads; out-of-image pixels are zero (padding=3)
-  for (int idx = threadIdx.x; idx < ROWS * PW * (CB / 4); idx += 256) {
+  constexpr int TOTAL = ROWS * PW * (CB / 4);
+  constexpr int NIT = (TOTAL + 255) / 256;
+  f32x4 v[NIT];
+#pragma unroll
+  for (int i = 0; i < NIT; i++) {
+    const int idx = threadIdx.x + 256 * i;
     const int q = idx & 7, px = idx >> 3;
     const int py = px / PW, pxx = px - py * PW;
     const int iy = y0 - 3 + py, ix = x0 - 3 + pxx;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = ld4(x + (((long)b * H + iy) * W + ix) * C + c0 + 4 * q);
-    st4(patch + px * PS + 4 * q, v);
+    const bool ok = idx < TOTAL && iy >= 0 && iy < H && ix >= 0 && ix < W;
+    // clamped address + select: no branch around the load, so the compiler keeps the whole batch in flight
+    const int cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);
+    const f32x4 t = ld4(x + (((long)b * H + cy) * W + cx) * C + c0 + 4 * q);
+    v[i] = ok ? t : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int i = 0; i < NIT; i++) {
+    const int idx = threadIdx.x + 256 * i;
+    if (idx < TOTAL) st4(patch + (idx >> 3) * PS + 4 * (idx & 7), v[i]);
   }
 }
 
@@ -64,32 +78,46 @@ __global__ __launch_bounds__(256) void dwconv7_lds_fwd_kernel(const float* __res
   for (int r = 0; r < 2; r++)
 #pragma unroll
     for (int c = 0; c < 4; c++) acc[r][c] = bv;
-  // Patch row ry+ir feeds output row 0 through tap row ky=ir and output row 1 through ky=ir-1.  The row loop is kept
-  // rolled (a full unroll hoists all 98 tap loads and spills); the 7 taps of the NEXT tap row are fetched from L1/L2
-  // while the FMAs of this one run.
+  // Patch row ry+ir feeds output row 0 through tap row ky=ir (ir < 7) and output row 1 through ky=ir-1 (ir > 0).  The
+  // first and last patch rows are peeled (they feed one output row only), the six middle rows run as a rolled loop (a
+  // full unroll hoists all 98 tap loads and spills) with the 7 taps of the NEXT tap row fetched from L1/L2 while the
+  // FMAs of this one run.
   f32x4 wprev[7], wcur[7], wnext[7];
 #pragma unroll
-  for (int kx = 0; kx < 7; kx++) {
-    wcur[kx] = ld4(taps + (long)(tb + ts * kx) * C + 4 * cq);
-    wprev[kx] = wcur[kx];
+  for (int kx = 0; kx < 7; kx++) wcur[kx] = ld4(taps + (long)(tb + ts * kx) * C + 4 * cq);
+  auto patch_row = [&](int ir, f32x4 (&in)[10]) {
+    const float* prow = patch + ((ry + ir) * PW + rx) * PS + 4 * cq;
+#pragma unroll
+    for (int c = 0; c < 10; c++) in[c] = ld4(prow + c * PS);
+  };
+  {  // ir = 0: output row 0, tap row 0
+#pragma unroll
+    for (int kx = 0; kx < 7; kx++) wnext[kx] = ld4(taps + (long)(tb + ts * (7 + kx)) * C + 4 * cq);
+    f32x4 in[10];
+    patch_row(0, in);
+#pragma unroll
+    for (int kx = 0; kx < 7; kx++)
+#pragma unroll
+      for (int c = 0; c < 4; c++) acc[0][c] += in[c + kx] * wcur[kx];
+#pragma unroll
+    for (int kx = 0; kx < 7; kx++) {
+      wprev[kx] = wcur[kx];
+      wcur[kx] = wnext[kx];
+    }
   }
 #pragma unroll 1
-  for (int ir = 0; ir < 8; ir++) {
+  for (int ir = 1; ir < 7; ir++) {
     const int kn = ir + 1 < 7 ? ir + 1 : 6;  // clamped: branch-free prefetch
 #pragma unroll
     for (int kx = 0; kx < 7; kx++) wnext[kx] = ld4(taps + (long)(tb + ts * (kn * 7 + kx)) * C + 4 * cq);
     f32x4 in[10];
-    const float* prow = patch + ((ry + ir) * PW + rx) * PS + 4 * cq;
-#pragma unroll
-    for (int c = 0; c < 10; c++) in[c] = ld4(prow + c * PS);
-    const float m0 = ir < 7 ? 1.f : 0.f, m1 = ir > 0 ? 1.f : 0.f;  // rows 7 / 0 have no tap for output row 0 / 1
+    patch_row(ir, in);
 #pragma unroll
     for (int kx = 0; kx < 7; kx++) {
-      const f32x4 w0 = wcur[kx] * m0, w1 = wprev[kx] * m1;
 #pragma unroll
       for (int c = 0; c < 4; c++) {
-        acc[0][c] += in[c + kx] * w0;
-        acc[1][c] += in[c + kx] * w1;
+        acc[0][c] += in[c + kx] * wcur[kx];
+        acc[1][c] += in[c + kx] * wprev[kx];
       }
     }
 #pragma unroll
@@ -97,6 +125,14 @@ __global__ __launch_bounds__(256) void dwconv7_lds_fwd_kernel(const float* __res
       wprev[kx] = wcur[kx];
       wcur[kx] = wnext[kx];
     }
+  }
+  {  // ir = 7: output row 1, tap row 6 (= wprev after the last rotation)
+    f32x4 in[10];
+    patch_row(7, in);
+#pragma unroll
+    for (int kx = 0; kx < 7; kx++)
+#pragma unroll
+      for (int c = 0; c < 4; c++) acc[1][c] += in[c + kx] * wprev[kx];
   }
 #pragma unroll
   for (int r = 0; r < 2; r++)
@@ -137,10 +173,20 @@ __global__ __launch_bounds__(256) void dwconv7_lds_bwd_weight_kernel(const float
     const int y0 = ty * TH_B, x0 = tx * TW;
     __syncthreads();  // previous tile fully consumed
     load_patch<TH_B + 6>(x, b, H, W, C, y0, x0, c0, patch);
-    for (int idx = threadIdx.x; idx < TH_B * TW * (CB / 4); idx += 256) {
-      const int q = idx & 7, px = idx >> 3;
-      const int py = px >> 4, pxx = px & 15;
-      st4(dut + px * CB + 4 * q, ld4(du + (((long)b * H + y0 + py) * W + x0 + pxx) * C + c0 + 4 * q));
+    {
+      constexpr int NG = TH_B * TW * (CB / 4) / 256;  // 4 loads per thread, all issued before the stores
+      f32x4 gv[NG];
+#pragma unroll
+      for (int i = 0; i < NG; i++) {
+        const int idx = threadIdx.x + 256 * i;
+        const int q = idx & 7, px = idx >> 3;
+        gv[i] = ld4(du + (((long)b * H + y0 + (px >> 4)) * W + x0 + (px & 15)) * C + c0 + 4 * q);
+      }
+#pragma unroll
+      for (int i = 0; i < NG; i++) {
+        const int idx = threadIdx.x + 256 * i;
+        st4(dut + (idx >> 3) * CB + 4 * (idx & 7), gv[i]);
+      }
     }
     __syncthreads();
     if (active) {

@@ -3,12 +3,13 @@
 // Reference semantics (mmrotate/models/backbones/convnext_moe.py): CosineTopKGate.forward :99-106,
 // MoE_layer.noisy_top_k_gating :194-223, _prob_in_top_k :152-174, _gates_to_load :149-150.
 //
-// Work split: one workgroup = one wavefront = 64 tokens, one token per lane.  The 64 x P tile of projected features is
-// brought into LDS with coalesced 16-byte loads (row stride P+1 floats: every lane then walks its own row without
-// bank conflicts), the similarity matrix sits next to it and is read as a broadcast, and the O(E) routing arithmetic
-// (noise, top-(k+1), softmax, Normal-CDF load) runs per lane.  The backward builds its dh rows in the same LDS tile
-// and streams them out coalesced.  (A thread-per-token version reading strided 4-byte rows from global memory and
-// launched as T/256 workgroups took 158 us at T = 8192.)
+// Work split: one workgroup = one wavefront = 16 tokens, FOUR lanes per token.  The 16 x P tile of projected features
+// is brought into LDS with coalesced 16-byte loads (row stride P+1 floats), the similarity matrix sits next to it; the
+// four lanes of a token split the O(P*E) loops over P (p = sub, sub+4, ...) and meet through two xor-shuffles, the O(E)
+// routing arithmetic (noise, top-(k+1), softmax, Normal-CDF load) runs redundantly in all four.  The backward builds
+// its dh rows in the same LDS tile and streams them out coalesced.  History: a thread-per-token version reading strided
+// rows from global memory took 158 us at T = 8192; one token per lane (64 per wave) left the stage-2 / stage-3 launches
+// with 128 / 32 wavefronts on 256 CUs (47 / 72 us per launch, pure latency); four lanes per token quadruple the waves.
 #include "common.h"
 
 namespace {
@@ -28,12 +29,14 @@ __device__ __forceinline__ float normal_cdf(float z) { return 0.5f * (1.0f + erf
 __device__ __forceinline__ float normal_pdf(float z) { return 0.39894228040143267794f * __expf(-0.5f * z * z); }
 __device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(__expf(x)); }  // torch threshold 20
 
-constexpr int RT_TOKENS = 64;  // tokens per workgroup (= one wavefront)
+constexpr int RT_THREADS = 64;  // one wavefront per workgroup
+constexpr int LPT = 4;          // lanes per token
+constexpr int RT_TOKENS = RT_THREADS / LPT;  // tokens per workgroup
 
 // cooperative, coalesced copy of the [64 tokens][P] feature tile into LDS (row stride P+1)
 __device__ __forceinline__ void load_h_tile(const float* __restrict__ hcat, int ldh, int P, int t0, int T, float* hs) {
   const int nq = P >> 2, ldt = P + 1;
-  for (int i = threadIdx.x; i < RT_TOKENS * nq; i += RT_TOKENS) {
+  for (int i = threadIdx.x; i < RT_TOKENS * nq; i += RT_THREADS) {
     const int r = i / nq, q = i - r * nq;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (t0 + r < T) v = ld4(hcat + (long)(t0 + r) * ldh + 4 * q);
@@ -46,22 +49,23 @@ __device__ __forceinline__ void load_h_tile(const float* __restrict__ hcat, int 
 // Outputs per token: top_idx/top_val (m = min(k+1,E), descending), gates (k, softmax of the top k), clean (E),
 // sigma (E, train only), hnorm; per-workgroup partial sums [importance (E) | load (E)] to `partials`.
 template <int ET>
-__global__ __launch_bounds__(RT_TOKENS) void moe_router_fwd_kernel(
+__global__ __launch_bounds__(RT_THREADS) void moe_router_fwd_kernel(
     const float* __restrict__ hcat, int ldh, int P, const float* __restrict__ snorm, const float* __restrict__ scale_p,
     const float* __restrict__ noise, int T, int E, int k, int train, int32_t* __restrict__ top_idx,
     float* __restrict__ top_val, float* __restrict__ gates, float* __restrict__ clean_o, float* __restrict__ sigma_o,
     float* __restrict__ hnorm_o, float* __restrict__ partials) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* s_s = sm;                         // snorm, row stride ET (zero padded), 16-byte aligned rows
-  float* hs = sm + (long)P * ET;           // [64][P+1]
-  for (int i = threadIdx.x; i < P * ET; i += RT_TOKENS) {
+  float* hs = sm + (long)P * ET;           // [16][P+1]
+  for (int i = threadIdx.x; i < P * ET; i += RT_THREADS) {
     const int p = i / ET, e = i - p * ET;
     s_s[i] = e < E ? snorm[p * E + e] : 0.f;
   }
   const int t0 = blockIdx.x * RT_TOKENS;
   load_h_tile(hcat, ldh, P, t0, T, hs);
   __syncthreads();
-  const int t = t0 + threadIdx.x;
+  const int tl = threadIdx.x / LPT, sub = threadIdx.x % LPT;  // token of the tile, lane of the token
+  const int t = t0 + tl;
   const bool tv = t < T;
   const int m = min(k + 1, E);
   const float scale = *scale_p;
@@ -70,18 +74,21 @@ __global__ __launch_bounds__(RT_TOKENS) void moe_router_fwd_kernel(
 #pragma unroll
   for (int e = 0; e < ET; e++) impv[e] = ldv[e] = 0.f;
   if (tv) {
-    const float* hrow = hs + threadIdx.x * (P + 1);
+    const float* hrow = hs + tl * (P + 1);
     float dot[ET];
 #pragma unroll
     for (int e = 0; e < ET; e++) dot[e] = 0.f;
     float nn = 0.f;
-    for (int p = 0; p < P; p++) {
+    for (int p = sub; p < P; p += LPT) {
       const float hv = hrow[p];
       nn += hv * hv;
       const float* srow = s_s + p * ET;
 #pragma unroll
       for (int e = 0; e < ET; e++) dot[e] += hv * srow[e];
     }
+    nn = group_sum<LPT>(nn);  // the 4 lanes of a token are adjacent: xor 1, 2 (all lanes of the group are in `tv`)
+#pragma unroll
+    for (int e = 0; e < ET; e++) dot[e] = group_sum<LPT>(dot[e]);
     const float hn = sqrtf(nn);
     const float inv = 1.0f / fmaxf(hn, 1e-12f);  // F.normalize eps
     const float* h = hcat + (long)t * ldh;
@@ -148,21 +155,26 @@ __global__ __launch_bounds__(RT_TOKENS) void moe_router_fwd_kernel(
         ldv[e] = gg > 0.f ? 1.f : 0.f;  // _gates_to_load :149-150
       }
     }
+    if (sub == 0) {
 #pragma unroll
-    for (int j = 0; j < ET; j++) {
-      if (j < m) {
-        top_idx[(long)t * m + j] = tii[j];
-        top_val[(long)t * m + j] = tvv[j];
+      for (int j = 0; j < ET; j++) {
+        if (j < m) {
+          top_idx[(long)t * m + j] = tii[j];
+          top_val[(long)t * m + j] = tvv[j];
+        }
+        if (j < k) gates[(long)t * k + j] = gk[j];
       }
-      if (j < k) gates[(long)t * k + j] = gk[j];
+#pragma unroll
+      for (int e = 0; e < ET; e++)
+        if (e < E) {
+          clean_o[(long)t * E + e] = cl[e];
+          if (train) sigma_o[(long)t * E + e] = sg[e];
+        }
+      hnorm_o[t] = hn;
+    } else {  // the token is counted once in the importance / load partials
+#pragma unroll
+      for (int e = 0; e < ET; e++) impv[e] = ldv[e] = 0.f;
     }
-#pragma unroll
-    for (int e = 0; e < ET; e++)
-      if (e < E) {
-        clean_o[(long)t * E + e] = cl[e];
-        if (train) sigma_o[(long)t * E + e] = sg[e];
-      }
-    hnorm_o[t] = hn;
   }
   // per-workgroup partials: deterministic wave shuffle tree
 #pragma unroll
@@ -182,7 +194,7 @@ __global__ __launch_bounds__(RT_TOKENS) void moe_router_fwd_kernel(
 //   dcn[t,e] = dclean[t,e] / max(|h_t|, eps)      (so that dSnorm = scale * h^T . dcn is one TN GEMM)
 //   ds_part[workgroup] = sum_t sum_e dclean[t,e] * clean[t,e] / scale   (d scale)
 template <int ET>
-__global__ __launch_bounds__(RT_TOKENS) void moe_router_bwd_kernel(
+__global__ __launch_bounds__(RT_THREADS) void moe_router_bwd_kernel(
     const float* __restrict__ hcat, int ldh, int P, const float* __restrict__ snorm, const float* __restrict__ scale_p,
     const float* __restrict__ noise, int T, int E, int k, int train, const int32_t* __restrict__ top_idx,
     const float* __restrict__ top_val, const float* __restrict__ gates, const float* __restrict__ clean_i,
@@ -191,15 +203,16 @@ __global__ __launch_bounds__(RT_TOKENS) void moe_router_bwd_kernel(
     float* __restrict__ dcn, float* __restrict__ ds_part) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* s_s = sm;
-  float* hs = sm + (long)P * ET;  // [64][P+1]: h on the way in, dh on the way out
-  for (int i = threadIdx.x; i < P * ET; i += RT_TOKENS) {
+  float* hs = sm + (long)P * ET;  // [16][P+1]: h on the way in, dh on the way out
+  for (int i = threadIdx.x; i < P * ET; i += RT_THREADS) {
     const int p = i / ET, e = i - p * ET;
     s_s[i] = e < E ? snorm[p * E + e] : 0.f;
   }
   const int t0 = blockIdx.x * RT_TOKENS;
   load_h_tile(hcat, ldh, P, t0, T, hs);
   __syncthreads();
-  const int t = t0 + threadIdx.x;
+  const int tl = threadIdx.x / LPT, sub = threadIdx.x % LPT;
+  const int t = t0 + tl;
   const bool tv = t < T;
   const int m = min(k + 1, E);
   const float scale = *scale_p;
@@ -289,22 +302,24 @@ __global__ __launch_bounds__(RT_TOKENS) void moe_router_bwd_kernel(
 #pragma unroll
     for (int e = 0; e < ET; e++)
       if (e < E) {
-        dcn[tt * E + e] = dclean[e] * inv;
+        if (sub == 0) dcn[tt * E + e] = dclean[e] * inv;
         dsl += dclean[e] * cl[e];
       }
-    ds_local = dsl / scale;
-    // dh = (dhh - hh <hh, dhh>) * inv,  dhh = scale * snorm . dclean,  hh = h * inv  (row lives in LDS)
-    float* hrow = hs + threadIdx.x * (P + 1);
+    ds_local = sub == 0 ? dsl / scale : 0.f;  // the token is counted once
+    // dh = (dhh - hh <hh, dhh>) * inv,  dhh = scale * snorm . dclean,  hh = h * inv  (row lives in LDS); the four
+    // lanes of the token split p
+    float* hrow = hs + tl * (P + 1);
     float proj = 0.f;
-    for (int p = 0; p < P; p++) {
+    for (int p = sub; p < P; p += LPT) {
       const float* srow = s_s + p * ET;
       float a = 0.f;
 #pragma unroll
       for (int e = 0; e < ET; e++) a += srow[e] * dclean[e];
       proj += a * scale * hrow[p] * inv;
     }
+    proj = group_sum<LPT>(proj);
     if (hn < 1e-12f) proj = 0.f;  // clamp region of F.normalize: d/dh (h/eps) = dhh/eps
-    for (int p = 0; p < P; p++) {
+    for (int p = sub; p < P; p += LPT) {
       const float* srow = s_s + p * ET;
       float a = 0.f;
 #pragma unroll
@@ -316,14 +331,14 @@ __global__ __launch_bounds__(RT_TOKENS) void moe_router_bwd_kernel(
   // coalesced write-out of the dh tile, then the [draw | 0] tail of each row
   {
     const int nq = P >> 2, ldt = P + 1;
-    for (int i = threadIdx.x; i < RT_TOKENS * nq; i += RT_TOKENS) {
+    for (int i = threadIdx.x; i < RT_TOKENS * nq; i += RT_THREADS) {
       const int r = i / nq, q = i - r * nq;
       if (t0 + r < T) {
         const float* d = hs + r * ldt + 4 * q;
         st4(dhcat + (long)(t0 + r) * ldh + 4 * q, f32x4{d[0], d[1], d[2], d[3]});
       }
     }
-    if (tv) {
+    if (tv && sub == 0) {
       float* dh = dhcat + (long)t * ldh;
 #pragma unroll
       for (int e = 0; e < ET; e++)
@@ -351,7 +366,7 @@ int sm3_moe_router_fwd(const float* hcat, int ldh, int P, const float* snorm, co
   const int nblk = sm3_moe_router_partial_rows(T);
   hipStream_t st = (hipStream_t)stream;
 #define CALL(ET)                                                                                                   \
-  moe_router_fwd_kernel<ET><<<nblk, RT_TOKENS, ((size_t)P * ET + (size_t)RT_TOKENS * (P + 1)) * sizeof(float), st>>>( \
+  moe_router_fwd_kernel<ET><<<nblk, RT_THREADS, ((size_t)P * ET + (size_t)RT_TOKENS * (P + 1)) * sizeof(float), st>>>( \
       hcat, ldh, P, snorm, scale, noise, T, E, k, train, top_idx, top_val, gates, clean, sigma, hnorm, partials)
   if (E <= 4) CALL(4);
   else if (E <= 8) CALL(8);
@@ -374,7 +389,7 @@ int sm3_moe_router_bwd(const float* hcat, int ldh, int P, const float* snorm, co
   const int nblk = sm3_moe_router_partial_rows(T);
   hipStream_t st = (hipStream_t)stream;
 #define CALL(ET)                                                                                                   \
-  moe_router_bwd_kernel<ET><<<nblk, RT_TOKENS, ((size_t)P * ET + (size_t)RT_TOKENS * (P + 1)) * sizeof(float), st>>>( \
+  moe_router_bwd_kernel<ET><<<nblk, RT_THREADS, ((size_t)P * ET + (size_t)RT_TOKENS * (P + 1)) * sizeof(float), st>>>( \
       hcat, ldh, P, snorm, scale, noise, T, E, k, train, top_idx, top_val, gates, clean, sigma, hnorm, dgate, dimp,    \
       dload, dhcat, dcn, ds_part)
   if (E <= 4) CALL(4);
