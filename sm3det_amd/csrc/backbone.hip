@@ -181,41 +181,58 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     const int q = lg + i * G;
     wv[i] = (q < nq) ? ld4(w + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  for (long t0 = wave * TPW; t0 < T; t0 += nwaves * TPW) {
-    const long tok = t0 + tg;
-    const bool tv = tok < T;
-    const float mean = tv ? mean_i[tok] : 0.f;
-    const float rstd = tv ? rstd_i[tok] : 0.f;
-    const long ob = tv ? ln_out_offset(tok, C, mode, H, W) : 0;
-    f32x4 xh[NV], g[NV];
-    float s1 = 0.f, s2 = 0.f;
+  // U token groups per iteration: all 2*U*NV 16-byte loads of an iteration are issued before the first reduction, so
+  // a wave keeps U times the bytes in flight (the kernel runs at <= 512 workgroups = 2 waves per SIMD).
+  constexpr int U = NV <= 4 ? 2 : 1;
+  for (long t0 = wave * TPW; t0 < T; t0 += nwaves * TPW * U) {
+    long tok[U];
+    bool tv[U];
+    long ob[U];
+    float mean[U], rstd[U];
+    f32x4 xh[U][NV], g[U][NV];
 #pragma unroll
-    for (int i = 0; i < NV; i++) {
-      const int q = lg + i * G;
-      if (tv && q < nq) {
-        xh[i] = (ld4(x + tok * C + 4 * q) - mean) * rstd;
-        const f32x4 d = ld4(dy + ob + 4 * q);
-        acc[0][i] += d * xh[i];
-        acc[1][i] += d;
-        g[i] = d * wv[i];
-        s1 += hsum4(g[i]);
-        s2 += hsum4(g[i] * xh[i]);
-      } else {
-        xh[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        g[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int u = 0; u < U; u++) {
+      tok[u] = t0 + (long)u * nwaves * TPW + tg;
+      tv[u] = tok[u] < T;
+      ob[u] = tv[u] ? ln_out_offset(tok[u], C, mode, H, W) : 0;
+#pragma unroll
+      for (int i = 0; i < NV; i++) {
+        const int q = lg + i * G;
+        const bool ok = tv[u] && q < nq;
+        xh[u][i] = ok ? ld4(x + tok[u] * C + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+        g[u][i] = ok ? ld4(dy + ob[u] + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
+      mean[u] = tv[u] ? mean_i[tok[u]] : 0.f;
+      rstd[u] = tv[u] ? rstd_i[tok[u]] : 0.f;
     }
-    const float c1 = group_sum<G>(s1) / (float)C;
-    const float c2 = group_sum<G>(s2) / (float)C;
-    if (!tv) continue;
 #pragma unroll
-    for (int i = 0; i < NV; i++) {
-      const int q = lg + i * G;
-      if (q < nq) {
-        f32x4 r = (g[i] - c1 - xh[i] * c2) * rstd;
-        float* o = dx + tok * C + 4 * q;
-        if (accumulate_dx) r += ld4(o);
-        st4(o, r);
+    for (int u = 0; u < U; u++) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < NV; i++) {
+        const int q = lg + i * G;
+        if (tv[u] && q < nq) {
+          xh[u][i] = (xh[u][i] - mean[u]) * rstd[u];
+          const f32x4 d = g[u][i];
+          acc[0][i] += d * xh[u][i];
+          acc[1][i] += d;
+          g[u][i] = d * wv[i];
+          s1 += hsum4(g[u][i]);
+          s2 += hsum4(g[u][i] * xh[u][i]);
+        }
+      }
+      const float c1 = group_sum<G>(s1) / (float)C;
+      const float c2 = group_sum<G>(s2) / (float)C;
+      if (!tv[u]) continue;
+#pragma unroll
+      for (int i = 0; i < NV; i++) {
+        const int q = lg + i * G;
+        if (q < nq) {
+          f32x4 r = (g[u][i] - c1 - xh[u][i] * c2) * rstd[u];
+          float* o = dx + tok[u] * C + 4 * q;
+          if (accumulate_dx) r += ld4(o);
+          st4(o, r);
+        }
       }
     }
   }
