@@ -29,6 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MI355X_FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+MI355X_HBM_PEAK_GBS = 8000.0  # same guide: HBM3E ~8 TB/s
 BACKBONE_CFG = dict(arch='tiny', MoE_Block_inds=[[], [0, 2], [0, 2, 4, 6, 8], [0, 2]], num_experts=8, top_k=2,
                     drop_path_rate=0.1)  # local_configs/main_SM3Det.py:13-21
 BATCH = 2
@@ -324,6 +325,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-ops', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a captured hipGraph')
+    ap.add_argument('--amp', action='store_true', help='BASELINE config #3 arithmetic: fp16 GEMM operands (fp32 '
+                    'accumulation) + dynamic loss scaling; reported as its own dtype, never mixed with the fp32 line')
     ap.add_argument('--cpu-worker', choices=['step', 'ops'], help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_worker:
@@ -361,6 +364,9 @@ def main():
     _lib.lib()  # fail loudly if the HIP extension is missing
 
     net = build_model().cuda().train()
+    if args.amp:
+        from sm3det_amd import amp
+        amp.wrap_fp16_model(net)  # what Fp16OptimizerHook.before_run does (mmcv/mmcv/runner/hooks/optimizer.py:245-249)
     params = [p for p in net.parameters() if p.requires_grad]
     # N>1: the backward is replayed in two segments -- stages 3+2 (93 % of the gradient bytes) first, whose buckets are
     # all-reduced over xGMI while the backward of stages 1+0 still runs (SM3_BENCH_SPLIT=0/1 overrides; N=1 default off)
@@ -376,7 +382,7 @@ def main():
     # parameter (paramwise_cfg / dynamic-lr hook), grad_clip max_norm 35 -- here one fused launch with a per-tensor lr vector
     from sm3det_amd.optim import MultiTensorAdamW
     opt = MultiTensorAdamW([dict(params=[p]) for p in params], lr=1e-4, betas=(0.9, 0.999), weight_decay=0.05,
-                           max_grad_norm=35.0)
+                           max_grad_norm=35.0, loss_scale='dynamic' if args.amp else None)
 
     g = torch.Generator(device='cpu').manual_seed(rank)  # rank r draws its own synthetic shard
     x = torch.randn(BATCH, 3, RES, RES, generator=g).cuda()
@@ -391,7 +397,7 @@ def main():
             proj = [torch.randn(o.shape, generator=gp).cuda().contiguous(memory_format=torch.channels_last)
                     for o in outs]
         loss = loss_fn(outs, gl, proj)
-        loss.backward()
+        opt.scale(loss).backward()  # identity without --amp
         reducer.finalize()
         opt.step()
         return loss
@@ -417,7 +423,7 @@ def main():
             reducer.zero_grad()
             outs, gl = net(x, ['single'])
             l = loss_fn(outs, gl, proj)
-            l.backward()
+            opt.scale(l).backward()
             reducer.pack_all()
             return l
 
@@ -436,14 +442,15 @@ def main():
                     l_early = l_early + t
             # autograd.grad, not backward(inputs=[..., hb]): the latter would EXECUTE hb's producer node (and free its
             # saved tensors) instead of just capturing the gradient that arrives at it
-            grads = torch.autograd.grad(l_late, [hb] + late_params, allow_unused=True)
+            grads = torch.autograd.grad(opt.scale(l_late), [hb] + late_params, allow_unused=True)
             for p, g in zip(late_params, grads[1:]):
                 p.grad = g
             reducer.pack_group(0)
             return l_late, l_early, hb, grads[0]
 
         def seg_early(l_early, hb, ghb):
-            torch.autograd.backward([l_early, hb], grad_tensors=[torch.ones_like(l_early), ghb], inputs=early_params)
+            torch.autograd.backward([opt.scale(l_early), hb], grad_tensors=[torch.ones_like(l_early), ghb],
+                                    inputs=early_params)
             reducer.pack_group(1)
 
         side = torch.cuda.Stream()
@@ -547,7 +554,7 @@ def main():
             k['ms'] += e0.elapsed_time(e1)
             k['flops'] += flops
             k['bytes'] += nbytes
-        gem = [v for n, v in kernels.items() if n.startswith('gemm_f32')]
+        gem = [v for n, v in kernels.items() if n.startswith('gemm_f')]
         g_ms = sum(v['ms'] for v in gem)
         g_fl = sum(v['flops'] for v in gem)
         g_n = sum(v['launches'] for v in gem)
@@ -568,7 +575,13 @@ def main():
                         algorithmic_gflop_per_step=round(g_fl / 1e9, 1),
                         gemm_ms_per_step=round(g_ms, 3),
                         other_kernels_ms_per_step=round(sum(v['ms'] for n, v in kernels.items()
-                                                            if not n.startswith('gemm_f32')), 3))
+                                                            if not n.startswith('gemm_f')), 3))
+        if args.amp:  # fp16 operands: 16x the matrix rate -> the family streams its fp32 operands: HBM-bound
+            gbs = g_by / (g_ms * 1e-3) / 1e9 if g_ms > 0 else 0.0
+            roofline.update(bound='hbm', kernel='gemm_f32_kernel<.., F16> (fp16 operands rounded in the loader, '
+                            'v_mfma_f32_32x32x16_f16, fp32 tensors in HBM)', achieved=round(gbs, 1),
+                            peak=MI355X_HBM_PEAK_GBS, unit='GB/s', frac=round(gbs / MI355X_HBM_PEAK_GBS, 4),
+                            traffic=None, traffic_source=None, mfma_tflops=round(achieved, 1))
 
     result = None
     if rank == 0:
@@ -576,8 +589,10 @@ def main():
             'metric': 'train imgs/sec SM3Det ConvNeXt-T e8t2 @1024^2 bs2/GPU (hot path: MoE backbone train step)',
             'value': round(value, 3), 'unit': 'imgs/sec', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'main_SM3Det.py backbone (ConvNeXt_moe_MultiInput tiny, 8 experts top-2, 9 MoE + 9 '
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16' if args.amp else 'f32', 'data': 'synthetic',
+            'config': {'workload': ('SM3Det_convnext_t.py (AMP: fp16 GEMM operands, fp32 accumulate / master weights / '
+                                    'LayerNorm / router / combine, dynamic loss scale) = ' if args.amp else '') +
+                                   'main_SM3Det.py backbone (ConvNeXt_moe_MultiInput tiny, 8 experts top-2, 9 MoE + 9 '
                                    'dense blocks) fwd+bwd + bucketed grad all-reduce + grad-clip(35)+AdamW (per-parameter lr); synthetic '
                                    f'randn({BATCH},3,{RES},{RES}) per GPU, random-init weights; neck/heads timed separately in ops_us',
                        'global_batch': world * BATCH, 'resolution': RES, 'parallelism': f'dp{world}',

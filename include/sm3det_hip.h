@@ -164,7 +164,10 @@ typedef struct sm3_gemm_desc {
                         fix-up (TN slices are then reduced by a second pass, NT/NN never slice K) */
   int32_t tuning;    /* 0 in production.  Benchmarking override: bits 0-3 tile+1 (0 128x128, 1 128x96, 2 96x128,
                         3 128x192, 4 192x128, 5 64x128), bits 4-7 k-step (1 = 16, 2 = 32), bits 8-15 slices,
-                        bit 16 TN: always reduce by the second pass */
+                        bit 16 TN: slices summed by the in-kernel fix-up instead of the second pass */
+  int32_t compute;   /* 0: fp32 operands (v_mfma_f32_32x32x2_f32, exact).  1: operands rounded to fp16 on the fly, fp32
+                        accumulation (v_mfma_f32_32x32x16_f16) -- the arithmetic autocast gives nn.Linear in the reference's
+                        AMP configs (fp16 = dict(loss_scale='dynamic')); all tensors stay fp32 in memory */
 } sm3_gemm_desc;
 int sm3_gemm_f32_counter_slots(void);
 size_t sm3_gemm_f32_workspace_bytes(const sm3_gemm_desc* desc);
@@ -345,12 +348,18 @@ int sm3_deform_col2im_coord(const float* col, const float* im, const float* offs
  * mmrotate/core/hook/dynamic_lr.py:197-218).  Device tables: *_ptrs[t] = float* of tensor t (param, grad, exp_avg,
  * exp_avg_sq), numel[t]; chunk_tab[c] = (tensor id, chunk index) with sm3_optim_chunk_elems() elements per chunk;
  * lr[t], wd[t] device vectors.  step / clip_coef / grad_norm are device scalars (step is incremented here;
- * max_grad_norm <= 0 disables clipping; partials = n_chunks floats of scratch).  torch.optim.AdamW arithmetic. */
+ * max_grad_norm <= 0 disables clipping; partials = n_chunks floats of scratch).  torch.optim.AdamW arithmetic.
+ * scaler (may be NULL) = device [loss scale, growth tracker, found_inf]: torch.cuda.amp.GradScaler semantics of the
+ * reference's Fp16OptimizerHook (mmcv/mmcv/runner/hooks/optimizer.py:283-300) without a host sync -- gradients are
+ * unscaled inside the update, a non-finite gradient norm skips the step (nothing is written, `step` does not advance)
+ * and multiplies the scale by backoff_factor, growth_interval clean steps multiply it by growth_factor;
+ * growth_interval <= 0 keeps the scale static. */
 int sm3_optim_chunk_elems(void);
 int sm3_adamw_multi(const uint64_t* p_ptrs, const uint64_t* g_ptrs, const uint64_t* m_ptrs, const uint64_t* v_ptrs,
                     const int64_t* numel, const int32_t* chunk_tab, int n_chunks, const float* lr, const float* wd,
                     float beta1, float beta2, float eps, float max_grad_norm, float* step, float* clip_coef,
-                    float* grad_norm, float* partials, sm3_stream_t stream);
+                    float* grad_norm, float* partials, float* scaler, float growth_factor, float backoff_factor,
+                    int growth_interval, sm3_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -21,7 +21,7 @@ class GemmDesc(ctypes.Structure):
         ('stride_b', ctypes.c_int64), ('stride_bias', ctypes.c_int64),
         ('bias', P), ('aux_in', P), ('aux_out', P), ('gamma', P), ('rowscale', P),
         ('rows_per_scale', ctypes.c_int32), ('ld_aux', ctypes.c_int32),
-        ('colsum_out', P), ('counters', P), ('tuning', ctypes.c_int32),
+        ('colsum_out', P), ('counters', P), ('tuning', ctypes.c_int32), ('compute', ctypes.c_int32),
     ]
 
 
@@ -69,7 +69,7 @@ def signatures():
         'sm3_moe_combine_bwd': (I, [P, P, P, P, P, P, I, P, P, P, LL, I, I, P, S, P]),
         'sm3_moe_gather_add': (I, [P, P, P, LL, I, I, I, P]),
         'sm3_optim_chunk_elems': (I, []),
-        'sm3_adamw_multi': (I, [P, P, P, P, P, P, I, P, P, F, F, F, F, P, P, P, P, P]),
+        'sm3_adamw_multi': (I, [P, P, P, P, P, P, I, P, P, F, F, F, F, P, P, P, P, P, F, F, I, P]),
         'sm3_deform_im2col': (I, [P, P, P] + [I] * 13 + [LL, P]),
         'sm3_deform_col2im': (I, [P, P, P] + [I] * 13 + [LL, P]),
         'sm3_deform_col2im_coord': (I, [P, P, P, P] + [I] * 13 + [LL, P]),
@@ -115,6 +115,7 @@ def _p(t):
 
 
 _COUNTERS = {}
+COMPUTE = 0  # 0: fp32 operands; 1: fp16 operands / fp32 accumulation (set by sm3det_amd.amp.autocast)
 TUNING = 0  # benchmarking override forwarded to sm3_gemm_desc.tuning (scripts/gemm_sweep2.py); 0 in production
 
 
@@ -165,12 +166,13 @@ def gemm(mode, A, B, C, M, N, K, *, epilogue=EPI_NONE, bias=None, aux_in=None, a
     d.colsum_out = _p(colsum_out)
     d.counters = _p(gemm_counters(C.device))
     d.tuning = TUNING
+    d.compute = COMPUTE
     ws = None
     nbytes = L.sm3_gemm_f32_workspace_bytes(ctypes.byref(d))
     if nbytes:
         ws = _lib.workspace(nbytes, C.device)
     rows = K if mode == TN else M
-    tag = 'gemm_f32_' + ('nt', 'nn', 'tn')[mode]
+    tag = ('gemm_f16_' if COMPUTE else 'gemm_f32_') + ('nt', 'nn', 'tn')[mode]
     if PROFILE is not None and PROFILE_SHAPES:
         tag += f' {M}x{N}x{K} g{num_groups} e{epilogue} s{splits}'
     # algorithmic bytes: each operand read once, the output (and the epilogue's auxiliary tensor) written once

@@ -23,6 +23,21 @@ from ._lib import SM3Error
 call, gemm, colsum = LB.call, LB.gemm, LB.colsum
 
 
+class _compute:
+    """run the enclosed GEMM launches in the arithmetic the forward of this autograd node used (fp32, or fp16 operands
+    under sm3det_amd.amp.autocast) -- backward may execute outside the autocast block"""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.old, LB.COMPUTE = LB.COMPUTE, self.mode
+
+    def __exit__(self, *exc):
+        LB.COMPUTE = self.old
+        return False
+
+
 def _e(*shape, like, dtype=None):
     return torch.empty(*shape, device=like.device, dtype=dtype or torch.float32)
 
@@ -90,11 +105,17 @@ class _Linear(Function):
         N = w.shape[0]
         y = _e(M, N, like=x)
         gemm(LB.NT, x, w, y, M, N, K, epilogue=LB.EPI_BIAS, bias=b)
+        ctx.compute = LB.COMPUTE
         ctx.save_for_backward(x, w)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, *grads):
+        with _compute(ctx.compute):
+            return _Linear._backward_impl(ctx, *grads)
+
+    @staticmethod
+    def _backward_impl(ctx, dy):
         x, w = ctx.saved_tensors
         dy = dy.contiguous()
         M, K = x.shape
@@ -128,11 +149,17 @@ class _LinearReLU(Function):
         N = w.shape[0]
         y = _e(M, N, like=x)
         gemm(LB.NT, x, w, y, M, N, K, epilogue=LB.EPI_BIAS_RELU, bias=b)
+        ctx.compute = LB.COMPUTE
         ctx.save_for_backward(x, w, y)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, *grads):
+        with _compute(ctx.compute):
+            return _LinearReLU._backward_impl(ctx, *grads)
+
+    @staticmethod
+    def _backward_impl(ctx, dy):
         x, w, y = ctx.saved_tensors
         M, K = x.shape
         N = w.shape[0]
@@ -234,12 +261,18 @@ class _DenseBlock(Function):
         y, out = _e(T, C, like=x), _e(T, C, like=x)
         gemm(LB.NT, act, w2, out, T, C, Hd, epilogue=LB.EPI_BIAS_SCALE_RES, bias=b2, aux_in=x, aux_out=y,
              gamma=gamma, rowscale=rs, rows_per_scale=H * W)
+        ctx.compute = LB.COMPUTE
         ctx.save_for_backward(x, u, mean, rstd, xn, hpre, act, y, w49, lnw, w1, w2, gamma, rs)
         ctx.meta = (B, H, W)
         return out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, *grads):
+        with _compute(ctx.compute):
+            return _DenseBlock._backward_impl(ctx, *grads)
+
+    @staticmethod
+    def _backward_impl(ctx, dout):
         x, u, mean, rstd, xn, hpre, act, y, w49, lnw, w1, w2, gamma, rs = ctx.saved_tensors
         B, H, W = ctx.meta
         T, C = x.shape
@@ -324,6 +357,7 @@ class _MoEBlock(Function):
         gemm(LB.NT, act, w2, yslot, S, C, Hd, epilogue=LB.EPI_BIAS, bias=b2, offsets=offsets, num_groups=E)
         out = _e(T, C, like=x)
         call('moe_combine_fwd', yslot, token_slot, gates, x, gamma, rs, H * W, out, T, C, k)
+        ctx.compute = LB.COMPUTE
         ctx.save_for_backward(x, u, mean, rstd, xn, hcat, top_idx, top_val, gates, clean, sigma, hnorm, offsets,
                               token_slot, xslot, hpre, act, yslot, w49, lnw, wcat, snorm, scale, w1, w2, gamma, rs,
                               noise, sim, temp, tot)
@@ -332,7 +366,12 @@ class _MoEBlock(Function):
         return out, loss.reshape(()), tot, offsets, top_idx
 
     @staticmethod
-    def backward(ctx, dout, dloss, _dtot, _doff, _dtop):
+    def backward(ctx, *grads):
+        with _compute(ctx.compute):
+            return _MoEBlock._backward_impl(ctx, *grads)
+
+    @staticmethod
+    def _backward_impl(ctx, dout, dloss, _dtot, _doff, _dtop):
         from . import _lib
         (x, u, mean, rstd, xn, hcat, top_idx, top_val, gates, clean, sigma, hnorm, offsets, token_slot, xslot, hpre,
          act, yslot, w49, lnw, wcat, snorm, scale, w1, w2, gamma, rs, noise, sim, temp, tot) = ctx.saved_tensors

@@ -332,6 +332,7 @@ class ConvNeXt_moe(nn.Module):
         self.frozen_stages = frozen_stages
         self.gap_before_final_norm = gap_before_final_norm
         self.nchw_outputs = nchw_outputs
+        self.fp16_enabled = False  # set by amp.wrap_fp16_model (mmcv.runner.wrap_fp16_model): GEMMs with fp16 operands
 
         dpr = [x.item() for x in torch.linspace(0, drop_path_rate, sum(self.depths))]
         block_idx = 0
@@ -459,7 +460,15 @@ class ConvNeXt_moe(nn.Module):
         return noise, drop
 
     def forward(self, x):
-        return self._forward_impl(x)
+        return self._run(x)
+
+    def _run(self, x, **kw):
+        """`@auto_fp16`-equivalent entry: fp16-operand GEMMs when wrap_fp16_model flagged the module (or the caller is
+        already inside amp.autocast), fp32 otherwise."""
+        from . import amp
+        from . import _lib_backbone as LB
+        with amp.autocast(bool(self.fp16_enabled) or LB.COMPUTE == 1):
+            return self._forward_impl(x, **kw)
 
     # ---------------------------------------------------------------------------------------------- misc API
     def _freeze_stages(self):
@@ -578,4 +587,4 @@ class ConvNeXt_moe_MultiInput(ConvNeXt_moe):
         if len(datasets) == 1:
             x = [x]
         x = torch.cat(list(x), dim=0)
-        return self._forward_impl(x, noise=noise, drop_scale=drop_scale)
+        return self._run(x, noise=noise, drop_scale=drop_scale)

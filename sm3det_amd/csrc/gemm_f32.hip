@@ -231,6 +231,10 @@ Cfg choose_cfg(const sm3_gemm_desc* d) {
     if (c.tile == 3) c.bk = 16;
     if (t_bk) c.bk = t_bk == 1 ? 16 : 32;
     if (d->K % c.bk) c.bk = 16;
+    if (d->compute == 1) {  // fp16 operands: k-step 32, tiles 128x128 / 128x96 / 64x128
+      c.bk = 32;
+      if (c.tile != 0 && c.tile != 1 && c.tile != 5) c.tile = 0;
+    }
     tile_dims(c.tile, c.bm, c.bn);
     c.ntn = (d->N + c.bn - 1) / c.bn;
     // ragged groups: at most ceil(M/BM) + G row tiles exist; surplus blocks exit
@@ -284,6 +288,10 @@ Cfg choose_cfg(const sm3_gemm_desc* d) {
   c.bk = 16;
   if (t_bk) c.bk = t_bk == 1 ? 16 : 32;
   if (c.tile >= 3) c.bk = 16;
+  if (d->compute == 1) {
+    c.bk = 32;
+    if (c.tile > 2) c.tile = 0;
+  }
   tile_dims(c.tile, c.bm, c.bn);
   c.ntn = (d->N + c.bn - 1) / c.bn;
   c.ntm = (d->M + c.bm - 1) / c.bm;
@@ -327,6 +335,7 @@ int sm3_gemm_f32(const sm3_gemm_desc* d, void* workspace, size_t workspace_bytes
   if (d->mode == MODE_TN && (d->M & 3)) return SM3_ERR_UNSUPPORTED;
   if (d->mode == MODE_TN && d->epilogue != EPI_NONE) return SM3_ERR_INVALID_ARG;
   if (d->mode != MODE_NT && d->mode != MODE_NN && d->mode != MODE_TN) return SM3_ERR_INVALID_ARG;
+  if (d->compute != 0 && d->compute != 1) return SM3_ERR_INVALID_ARG;
   hipStream_t st = (hipStream_t)stream;
   const Cfg c = choose_cfg(d);
   const size_t sb = align_up(slab_bytes(d, c), 256), cb = colpart_bytes(d, c);
@@ -355,7 +364,7 @@ int sm3_gemm_f32(const sm3_gemm_desc* d, void* workspace, size_t workspace_bytes
       p.ldc = d->N;
     }
     dim3 grid(c.ntn * c.ntm, 1, c.groups * c.splits);
-    const int rc = launch_tn(p, c.tile, c.bk, 0, grid, st);
+    const int rc = d->compute == 1 ? launch_tn16(p, c.tile, grid, st) : launch_tn(p, c.tile, c.bk, 0, grid, st);
     if (rc) return rc;
     if (c.splits > 1 && !c.fixup) {
       if (d->ldc != d->N) return SM3_ERR_UNSUPPORTED;
@@ -365,8 +374,12 @@ int sm3_gemm_f32(const sm3_gemm_desc* d, void* workspace, size_t workspace_bytes
   }
   if (d->M == 0) return SM3_OK;
   dim3 grid(c.ntn * c.ntm, 1, c.splits);
-  const int rc = d->mode == MODE_NT ? launch_nt(p, d->epilogue, c.tile, c.bk, 0, grid, st)
-                                    : launch_nn(p, d->epilogue, c.tile, c.bk, 0, grid, st);
+  int rc;
+  if (d->compute == 1)
+    rc = d->mode == MODE_NT ? launch_nt16(p, d->epilogue, c.tile, grid, st) : launch_nn16(p, d->epilogue, c.tile, grid, st);
+  else
+    rc = d->mode == MODE_NT ? launch_nt(p, d->epilogue, c.tile, c.bk, 0, grid, st)
+                            : launch_nn(p, d->epilogue, c.tile, c.bk, 0, grid, st);
   if (rc) return rc;
   if (cb) {
     dim3 rg((d->N + 63) / 64, c.groups);

@@ -35,6 +35,7 @@ namespace sm3gemm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int MODE_NT = 0, MODE_NN = 1, MODE_TN = 2;
 constexpr int NTHREADS = 256;
@@ -140,7 +141,7 @@ constexpr int smem_floats() {
   return 2 * BK * (lda + ldb);
 }
 
-template <int MODE, int EPI, int BK, class TL, int GATHER>
+template <int MODE, int EPI, int BK, class TL, int GATHER, int F16 = 0>
 __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kernel(GemmParams p) {
   constexpr int BM = TL::BM, BN = TL::BN, TI = TL::TI, TJ = TL::TJ, WN = TL::WN, WM = TL::WM;
   // A tile is written transposed (k-contiguous source) in NT/NN, directly (k-major source) in TN; B transposed in NT.
@@ -455,9 +456,50 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
     }
     __syncthreads();
   };
+  // F16 (mixed precision, the reference's `fp16 = dict(loss_scale='dynamic')` configs): same tiles, loaders and LDS
+  // image; the fp32 values are rounded to fp16 while the fragments are assembled (8 k-values per lane and operand) and
+  // multiplied by v_mfma_f32_32x32x16_f16 with fp32 accumulation -- 16x the matrix rate of the fp32 instruction, so the
+  // loop is bound by the operand stream from L2/HBM, not by the matrix pipe.  Every tensor in HBM stays fp32 (master
+  // weights, activations, gradients): no cast kernels, no fp16 copies.  A and B use the same (lane-half, element) -> k
+  // assignment, so the sum over k is complete whatever order the hardware walks it in.
+  auto k_step16 = [&](f32x4 (&ca)[PA], f32x4 (&cb)[PB], f32x4 (&na)[PA], f32x4 (&nb)[PB], int kt) {
+    const int buf = kt & 1;
+    const int kt_load = min(kt + 2, nk - 1);
+    const float* a_s = As + buf * A_STAGE + wm0 + l31;
+    const float* b_s = Bs + buf * B_STAGE + wn0 + l31;
+#pragma unroll
+    for (int q = 0; q < NP; q++) load_piece(na, nb, q, kt_load);
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ks++) {
+      f16x8 a[TI], b[TJ];
+#pragma unroll
+      for (int i = 0; i < TI; i++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) a[i][e] = (_Float16)a_s[(16 * ks + 8 * lh + e) * LDA_S + 32 * i];
+#pragma unroll
+      for (int j = 0; j < TJ; j++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) b[j][e] = (_Float16)b_s[(16 * ks + 8 * lh + e) * LDB_S + 32 * j];
+#pragma unroll
+      for (int i = 0; i < TI; i++)
+#pragma unroll
+        for (int j = 0; j < TJ; j++)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[j], a[i], acc[i][j], 0, 0, 0);
+      if (ks == 0) {
+#pragma unroll
+        for (int q = 0; q < NP; q++) store_piece(ca, cb, q, buf ^ 1);
+      }
+    }
+    __syncthreads();
+  };
   for (int kt = 0; kt < nk; kt += 2) {
-    k_step(sa0, sb0, sa1, sb1, kt);
-    if (kt + 1 < nk) k_step(sa1, sb1, sa0, sb0, kt + 1);
+    if (F16) {
+      k_step16(sa0, sb0, sa1, sb1, kt);
+      if (kt + 1 < nk) k_step16(sa1, sb1, sa0, sb0, kt + 1);
+    } else {
+      k_step(sa0, sb0, sa1, sb1, kt);
+      if (kt + 1 < nk) k_step(sa1, sb1, sa0, sb0, kt + 1);
+    }
   }
 
   // ---- split-K fix-up: publish this slice, the last arriver of the tile sums all slices in order ------------
@@ -623,6 +665,10 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
 int launch_nt(const GemmParams& p, int epi, int tile, int bk, int gather, dim3 grid, hipStream_t st);
 int launch_nn(const GemmParams& p, int epi, int tile, int bk, int gather, dim3 grid, hipStream_t st);
 int launch_tn(const GemmParams& p, int tile, int bk, int gather, dim3 grid, hipStream_t st);
+// fp16-operand variants (gemm_f16.hip): k-step 32, tiles 0 / 1 / 5 (NT, NN), 0 / 1 / 2 (TN)
+int launch_nt16(const GemmParams& p, int epi, int tile, dim3 grid, hipStream_t st);
+int launch_nn16(const GemmParams& p, int epi, int tile, dim3 grid, hipStream_t st);
+int launch_tn16(const GemmParams& p, int tile, dim3 grid, hipStream_t st);
 
 inline void tile_dims(int tile, int& bm, int& bn) {
   static const int d[6][2] = {{128, 128}, {128, 96}, {96, 128}, {128, 192}, {192, 128}, {64, 128}};

@@ -59,9 +59,16 @@ __global__ __launch_bounds__(OPT_THREADS) void grad_sumsq_kernel(TensorTable tt,
 
 // norm = sqrt(sum partial); coef = min(1, max_norm / (norm + 1e-6))  (torch.nn.utils.clip_grad_norm_ semantics);
 // also advances the step counter (one thread).
+// With a loss scaler (scaler = [scale, growth_tracker, found_inf], torch.cuda.amp.GradScaler semantics as used by the
+// reference's Fp16OptimizerHook, mmcv/mmcv/runner/hooks/optimizer.py:283-300): the gradients carry the factor `scale`;
+// a non-finite sum of squares = some gradient overflowed -> found_inf = 1, the AdamW kernel leaves everything untouched,
+// the step counter does not advance, scale *= backoff, tracker = 0.  Otherwise the norm is unscaled, the coefficient
+// folds 1/scale and the clip factor, tracker += 1 and every `growth_interval` clean steps scale *= growth.
+// growth_interval <= 0: static scale (never updated).
 __global__ __launch_bounds__(1024) void clip_coef_kernel(const float* __restrict__ partial, int nparts, float max_norm,
                                                         float* __restrict__ norm_out, float* __restrict__ coef_out,
-                                                        float* __restrict__ step) {
+                                                        float* __restrict__ step, float* __restrict__ scaler,
+                                                        float growth, float backoff, int growth_interval) {
   __shared__ double red[1024 / 64];
   double s = 0.0;
   for (int i = threadIdx.x; i < nparts; i += 1024) s += (double)partial[i];
@@ -72,15 +79,37 @@ __global__ __launch_bounds__(1024) void clip_coef_kernel(const float* __restrict
   if (threadIdx.x == 0) {
     double t = 0.0;
     for (int i = 0; i < 1024 / 64; i++) t += red[i];
-    const float norm = (float)sqrt(t);
+    float inv_scale = 1.f;
+    bool found_inf = false;
+    if (scaler) {
+      inv_scale = 1.f / scaler[0];
+      found_inf = !isfinite(t);
+    }
+    const float norm = (float)sqrt(t) * inv_scale;
     float coef = 1.f;
     if (max_norm > 0.f) {
       coef = max_norm / (norm + 1e-6f);
       coef = coef < 1.f ? coef : 1.f;
     }
+    coef *= inv_scale;
     if (norm_out) *norm_out = norm;
-    *coef_out = coef;
-    if (step) *step += 1.f;
+    if (scaler) {
+      scaler[2] = found_inf ? 1.f : 0.f;
+      if (growth_interval > 0) {
+        if (found_inf) {
+          scaler[0] *= backoff;
+          scaler[1] = 0.f;
+        } else {
+          scaler[1] += 1.f;
+          if (scaler[1] >= (float)growth_interval) {
+            scaler[0] *= growth;
+            scaler[1] = 0.f;
+          }
+        }
+      }
+    }
+    *coef_out = found_inf ? 0.f : coef;
+    if (step && !found_inf) *step += 1.f;
   }
 }
 
@@ -97,7 +126,9 @@ __global__ __launch_bounds__(OPT_THREADS) void adamw_multi_kernel(TensorTable tt
                                                                  const float* __restrict__ wd, float beta1,
                                                                  float beta2, float eps,
                                                                  const float* __restrict__ step_p,
-                                                                 const float* __restrict__ coef_p) {
+                                                                 const float* __restrict__ coef_p,
+                                                                 const float* __restrict__ scaler) {
+  if (scaler && scaler[2] != 0.f) return;  // a gradient overflowed under the loss scale: skip the whole step
   const int tid = chunk_tab[2 * blockIdx.x], ck = chunk_tab[2 * blockIdx.x + 1];
   float* __restrict__ p = reinterpret_cast<float*>(tt.p[tid]);
   const float* __restrict__ g = reinterpret_cast<const float*>(tt.g[tid]);
@@ -160,20 +191,23 @@ int sm3_optim_chunk_elems(void) { return OPT_CHUNK; }
 int sm3_adamw_multi(const uint64_t* p_ptrs, const uint64_t* g_ptrs, const uint64_t* m_ptrs, const uint64_t* v_ptrs,
                     const int64_t* numel, const int32_t* chunk_tab, int n_chunks, const float* lr, const float* wd,
                     float beta1, float beta2, float eps, float max_grad_norm, float* step, float* clip_coef,
-                    float* grad_norm, float* partials, sm3_stream_t stream) {
+                    float* grad_norm, float* partials, float* scaler, float growth_factor, float backoff_factor,
+                    int growth_interval, sm3_stream_t stream) {
   if (!p_ptrs || !g_ptrs || !m_ptrs || !v_ptrs || !numel || !chunk_tab || !lr || !wd || !step || !clip_coef)
     return SM3_ERR_INVALID_ARG;
   if (n_chunks <= 0) return SM3_OK;
   hipStream_t st = (hipStream_t)stream;
   TensorTable tt{p_ptrs, g_ptrs, m_ptrs, v_ptrs, numel};
-  if (max_grad_norm > 0.f) {
+  if (max_grad_norm > 0.f || scaler) {  // the overflow check of the loss scaler needs the same pass as the clip norm
     if (!partials) return SM3_ERR_WORKSPACE;
     grad_sumsq_kernel<<<n_chunks, OPT_THREADS, 0, st>>>(tt, chunk_tab, partials);
-    clip_coef_kernel<<<1, 1024, 0, st>>>(partials, n_chunks, max_grad_norm, grad_norm, clip_coef, step);
+    clip_coef_kernel<<<1, 1024, 0, st>>>(partials, n_chunks, max_grad_norm, grad_norm, clip_coef, step, scaler,
+                                         growth_factor, backoff_factor, growth_interval);
   } else {
     step_inc_kernel<<<1, 1, 0, st>>>(step, clip_coef);
   }
-  adamw_multi_kernel<<<n_chunks, OPT_THREADS, 0, st>>>(tt, chunk_tab, lr, wd, beta1, beta2, eps, step, clip_coef);
+  adamw_multi_kernel<<<n_chunks, OPT_THREADS, 0, st>>>(tt, chunk_tab, lr, wd, beta1, beta2, eps, step, clip_coef,
+                                                       scaler);
   return launch_status();
 }
 

@@ -21,12 +21,66 @@ from . import _lib_backbone as LB
 
 
 class MultiTensorAdamW(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm=None):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm=None,
+                 loss_scale=None):
+        """loss_scale: None (fp32 training) | 'dynamic' | float (static) | dict of torch GradScaler arguments
+        (init_scale, growth_factor, backoff_factor, growth_interval) -- the `loss_scale` argument of the reference's
+        Fp16OptimizerHook (mmcv/mmcv/runner/hooks/optimizer.py:198-243).  With a scale, train with
+        ``opt.scale(loss).backward(); opt.step()``: unscaling, the overflow check, the skipped step and the scale update
+        all happen on the device inside ``step()``."""
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
         self.max_grad_norm = float(max_grad_norm) if max_grad_norm else 0.0
         self._built = False
         self._last_hyper = None
+        self._scaler = None
+        self._scaler_cfg = None
+        if loss_scale is not None:
+            cfg = dict(init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000)  # GradScaler()
+            if isinstance(loss_scale, dict):
+                cfg.update(loss_scale)
+            elif isinstance(loss_scale, (int, float)):
+                cfg.update(init_scale=float(loss_scale), growth_interval=0)  # static (hook re-sets it every iteration)
+            elif loss_scale != 'dynamic':
+                raise ValueError('loss_scale must be of type float, dict, or "dynamic", got ' + repr(loss_scale))
+            self._scaler_cfg = cfg
+
+    # ------------------------------------------------------------------------------------------- loss scaling
+    def _ensure_scaler(self, device):
+        if self._scaler is None and self._scaler_cfg is not None:
+            self._scaler = torch.tensor([self._scaler_cfg['init_scale'], 0.0, 0.0], dtype=torch.float32, device=device)
+        return self._scaler
+
+    def scale(self, loss):
+        """GradScaler.scale: loss * current scale (a device scalar; no sync)."""
+        if self._scaler_cfg is None:
+            return loss
+        return loss * self._ensure_scaler(loss.device)[0]
+
+    @property
+    def loss_scale(self):
+        """current scale as a python float (synchronises; logging / checkpoints only)"""
+        return None if self._scaler is None else float(self._scaler[0])
+
+    @property
+    def found_inf(self):
+        """1.0 if the last step() was skipped because a gradient overflowed (device tensor view)"""
+        return None if self._scaler is None else self._scaler[2]
+
+    def scaler_state_dict(self):
+        if self._scaler is None:
+            return dict(self._scaler_cfg or {})
+        sc, tr, _ = self._scaler.tolist()
+        return dict(self._scaler_cfg, scale=sc, _growth_tracker=int(tr))
+
+    def load_scaler_state_dict(self, sd):
+        if self._scaler_cfg is None:
+            raise _lib.SM3Error('this optimizer was built without loss_scale')
+        self._scaler_cfg.update({k: sd[k] for k in ('growth_factor', 'backoff_factor', 'growth_interval') if k in sd})
+        if self._scaler is not None and 'scale' in sd:
+            self._scaler.copy_(torch.tensor([sd['scale'], float(sd.get('_growth_tracker', 0)), 0.0]))
+        elif 'scale' in sd:
+            self._scaler_cfg['init_scale'] = sd['scale']
 
     # ------------------------------------------------------------------------------------------- tables
     def _build(self):
@@ -108,9 +162,12 @@ class MultiTensorAdamW(torch.optim.Optimizer):
             self.update_hyperparams()
         g0 = self.param_groups[0]
         b1, b2 = g0['betas']
+        sc = self._ensure_scaler(self._step.device)
+        cfg = self._scaler_cfg or dict(growth_factor=2.0, backoff_factor=0.5, growth_interval=0)
         LB.call('adamw_multi', self._p_ptrs, self._g_ptrs, self._m_ptrs, self._v_ptrs, self._numel, self._chunks,
                 self._n_chunks, self._lr, self._wd, float(b1), float(b2), float(g0['eps']), float(self.max_grad_norm),
-                self._step, self._coef, self.grad_norm, self._partials)
+                self._step, self._coef, self.grad_norm, self._partials, sc, float(cfg['growth_factor']),
+                float(cfg['backoff_factor']), int(cfg['growth_interval']))
         return loss
 
 

