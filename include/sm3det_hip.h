@@ -201,6 +201,21 @@ int sm3_sumpool2x_add(const float* dfine, const float* base, float* dcoarse, int
                       sm3_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * GroupNorm (+ ReLU) on NHWC tokens: the normalisation of the GFL head's conv towers (local_configs/main_SM3Det.py:29-48
+ * `type='GFLHead', stacked_convs=4`: ConvModule(conv3x3, GN(32), ReLU); the class is mmdet 2.x code the reference does
+ * not vendor -- torch.nn.GroupNorm semantics).  x, y, dy, dx: (B, P, C) with P = H*W; stats (B, G, 2) = (mean, rstd);
+ * C <= 1024, (C/G) % 4 == 0.  bwd leaves (B * sm3_groupnorm_blocks(P,C)) x 2C partial rows [d gamma | d beta] for
+ * sm3_row_partials_reduce.  relu != 0: y = max(0, gn(x)), the backward masks dy with y > 0. */
+int sm3_groupnorm_blocks(long P, int C);
+size_t sm3_groupnorm_workspace_bytes(int B, long P, int C, int G);
+int sm3_groupnorm_fwd(const float* x, const float* gamma, const float* beta, float eps, int relu, float* y,
+                      float* stats, int B, long P, int C, int G, void* workspace, size_t workspace_bytes,
+                      sm3_stream_t stream);
+int sm3_groupnorm_bwd(const float* dy, const float* x, const float* y, const float* gamma, const float* stats,
+                      int relu, float* dx, float* dgamma_dbeta_part, int B, long P, int C, int G, void* workspace,
+                      size_t workspace_bytes, sm3_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * Oriented-RPN proposal glue.
  * relu_bwd: dx = y > 0 ? dy : 0 (n multiple of 4).  sigmoid: y = 1/(1+exp(-x)) (oriented_rpn_head.py:236-238).
  * rpn_decode_le90: for i < n, src = order ? order[i] : i (order = descending-score permutation: the top-k gather of

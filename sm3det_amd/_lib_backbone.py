@@ -51,6 +51,10 @@ def signatures():
         'sm3_conv3x3_nhwc_bwd_input': (I, [P, P, P, I, I, I, I, I, I, P, S, P]),
         'sm3_conv3x3_nhwc_bwd_weight_workspace_bytes': (S, [I, I, I, I, I, I]),
         'sm3_conv3x3_nhwc_bwd_weight': (I, [P, P, P, I, I, I, I, I, I, P, S, P]),
+        'sm3_groupnorm_blocks': (I, [LL, I]),
+        'sm3_groupnorm_workspace_bytes': (S, [I, LL, I, I]),
+        'sm3_groupnorm_fwd': (I, [P, P, P, F, I, P, P, I, LL, I, I, P, S, P]),
+        'sm3_groupnorm_bwd': (I, [P, P, P, P, P, I, P, P, I, LL, I, I, P, S, P]),
         'sm3_upsample2x_add': (I, [P, P, P, I, I, I, I, P]),
         'sm3_sumpool2x_add': (I, [P, P, P, I, I, I, I, P]),
         'sm3_row_partial_blocks': (I, [LL, I]),

@@ -41,7 +41,8 @@ class _Conv3x3(Function):
     @staticmethod
     def forward(ctx, x, w, b, stride, relu=False):
         _lib.require_gpu(x, w, b)
-        x, w, b = x.contiguous(), w.contiguous(), b.contiguous()
+        x, w = x.contiguous(), w.contiguous()
+        b = b.contiguous() if b is not None else None  # bias-free: ConvModule in front of a norm layer
         B, H, W, Cin = x.shape
         Cout = w.shape[0]
         Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
@@ -51,7 +52,7 @@ class _Conv3x3(Function):
         call('conv3x3_nhwc_fwd', x, w, b, y, B, H, W, Cin, Cout, stride, int(relu), ws, nb,
              flops=2.0 * B * Ho * Wo * Cout * 9 * Cin)
         ctx.save_for_backward(x, w, y if relu else None)
-        ctx.stride, ctx.relu = stride, relu
+        ctx.stride, ctx.relu, ctx.has_bias = stride, relu, b is not None
         return y
 
     @staticmethod
@@ -77,8 +78,10 @@ class _Conv3x3(Function):
         nb = _lib.lib().sm3_conv3x3_nhwc_bwd_weight_workspace_bytes(B, H, W, Cin, Cout, s)
         ws = _lib.workspace(nb, x.device)
         call('conv3x3_nhwc_bwd_weight', x, dy, dw, B, H, W, Cin, Cout, s, ws, nb, flops=fl)
-        db = _e(Cout, like=x)
-        colsum(dy.view(-1, Cout), B * Ho * Wo, Cout, db)
+        db = None
+        if ctx.has_bias:
+            db = _e(Cout, like=x)
+            colsum(dy.view(-1, Cout), B * Ho * Wo, Cout, db)
         return dx, dw, db, None, None
 
 
