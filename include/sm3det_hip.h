@@ -201,6 +201,20 @@ int sm3_sumpool2x_add(const float* dfine, const float* base, float* dcoarse, int
                       sm3_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * MaxIoU target assignment: mmdet MaxIoUAssigner.assign_wrt_overlaps as configured by
+ * local_configs/main_SM3Det.py:165-196 (rpn: BboxOverlaps2D on (x1,y1,x2,y2) anchors; rcnn: RBboxOverlaps2D =
+ * rbbox_overlaps, mmrotate/core/bbox/iou_calculators/rotate_iou2d_calculator.py:52-87), called from
+ * oriented_rpn_head.py:76-78 / oriented_standard_roi_head.py:68-70.  No (k x n) overlap matrix is materialised.
+ * gt_inds[j] = -1 ignore / 0 background / i+1 matched gt; max_overlaps[j]; labels[j] = gt_labels[i] or -1 (labels and
+ * gt_labels may be NULL).  gt_max_assign_all semantics (every box tying a gt's best IoU >= min_pos_iou is assigned to
+ * it; later gts override earlier ones).  rotated: boxes (cx,cy,w,h,a) else (x1,y1,x2,y2); strides in floats. */
+size_t sm3_max_iou_assign_workspace_bytes(int n, int k);
+int sm3_max_iou_assign(const float* boxes, int box_stride, int n, const float* gts, int gt_stride, int k, int rotated,
+                       float pos_iou_thr, float neg_iou_thr, float min_pos_iou, int match_low_quality,
+                       const int64_t* gt_labels, int64_t* gt_inds, float* max_overlaps, int64_t* labels,
+                       void* workspace, size_t workspace_bytes, sm3_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * GroupNorm (+ ReLU) on NHWC tokens: the normalisation of the GFL head's conv towers (local_configs/main_SM3Det.py:29-48
  * `type='GFLHead', stacked_convs=4`: ConvModule(conv3x3, GN(32), ReLU); the class is mmdet 2.x code the reference does
  * not vendor -- torch.nn.GroupNorm semantics).  x, y, dy, dx: (B, P, C) with P = H*W; stats (B, G, 2) = (mean, rstd);

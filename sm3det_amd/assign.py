@@ -1,0 +1,162 @@
+"""Target assignment and sampling for the two-stage branch on the MI355X -- SURVEY.md 8(f) row 3.
+
+What it stands in for (all by ``type`` string in ``local_configs/main_SM3Det.py:165-196``):
+
+* ``MaxIoUAssigner`` (mmdet 2.x ``core/bbox/assigners/max_iou_assigner.py`` -- NOT vendored by the reference: semantics
+  restated, **parity unpinned**) with ``BboxOverlaps2D`` (rpn: horizontal anchors vs ``obb2xyxy(gt)``,
+  ``oriented_rpn_head.py:72-78``) or ``RBboxOverlaps2D`` (rcnn: rotated proposals vs rotated gts,
+  ``mmrotate/core/bbox/iou_calculators/rotate_iou2d_calculator.py:8-87``, ``oriented_standard_roi_head.py:66-70``);
+* ``RandomSampler`` / ``RRandomSampler`` (``mmrotate/core/bbox/samplers/rotate_random_sampler.py:10-80`` on mmdet's
+  ``BaseSampler.sample``).
+
+MI355X design: the assignment is ONE fused pass pair over the boxes (``sm3_max_iou_assign``: each thread walks the k
+ground-truth boxes; the k x n overlap matrix -- 261 888 anchors x k per image for the RPN -- never exists), and the
+sampler's core ``sample_fixed`` returns fixed-size index buffers + device counts, so nothing on the training path waits
+for the host (the reference does ``nonzero`` / ``randperm`` / ``unique`` with implicit syncs per image).  ``sample()``
+keeps mmdet's variable-length ``SamplingResult`` API on top of it (that API itself forces a sync).
+"""
+import torch
+
+from . import _lib
+from ._lib import SM3Error, check, lib, ptr, require_gpu, stream_ptr, workspace
+from .registry import Registry
+
+BBOX_ASSIGNERS = Registry('bbox_assigner')
+BBOX_SAMPLERS = Registry('bbox_sampler')
+
+
+class AssignResult:
+    """mmdet AssignResult: num_gts, gt_inds (n,) [-1 ignore, 0 negative, i+1 gt], max_overlaps (n,), labels (n,)|None"""
+
+    def __init__(self, num_gts, gt_inds, max_overlaps, labels=None):
+        self.num_gts, self.gt_inds, self.max_overlaps, self.labels = num_gts, gt_inds, max_overlaps, labels
+
+    @property
+    def num_preds(self):
+        return len(self.gt_inds)
+
+    def add_gt_(self, gt_labels):
+        """mmdet AssignResult.add_gt_: prepend the gts as self-matched proposals"""
+        k = self.num_gts
+        self_inds = torch.arange(1, k + 1, dtype=torch.long, device=self.gt_inds.device)
+        self.gt_inds = torch.cat([self_inds, self.gt_inds])
+        self.max_overlaps = torch.cat([self.max_overlaps.new_ones(k), self.max_overlaps])
+        if self.labels is not None:
+            self.labels = torch.cat([gt_labels, self.labels])
+
+
+@BBOX_ASSIGNERS.register_module()
+class MaxIoUAssigner:
+    def __init__(self, pos_iou_thr, neg_iou_thr, min_pos_iou=0.0, gt_max_assign_all=True, ignore_iof_thr=-1,
+                 ignore_wrt_candidates=True, match_low_quality=True, gpu_assign_thr=-1,
+                 iou_calculator=dict(type='BboxOverlaps2D')):
+        if isinstance(neg_iou_thr, (tuple, list)):
+            raise NotImplementedError('neg_iou_thr as an interval is not used by any SM3Det config')
+        if not gt_max_assign_all:
+            raise NotImplementedError('gt_max_assign_all=False is not used by any SM3Det config')
+        if ignore_iof_thr > 0:
+            raise NotImplementedError('ignore_iof_thr > 0 (crowd regions) is not used by any SM3Det config')
+        kind = iou_calculator.get('type', 'BboxOverlaps2D')
+        if kind not in ('BboxOverlaps2D', 'RBboxOverlaps2D'):
+            raise NotImplementedError(f'iou_calculator {kind}')
+        self.rotated = kind == 'RBboxOverlaps2D'
+        self.pos_iou_thr, self.neg_iou_thr, self.min_pos_iou = float(pos_iou_thr), float(neg_iou_thr), float(min_pos_iou)
+        self.match_low_quality = bool(match_low_quality)
+
+    def assign(self, bboxes, gt_bboxes, gt_bboxes_ignore=None, gt_labels=None):
+        """bboxes (n, 4|5[+score]), gt_bboxes (k, 4|5) on the GPU -> AssignResult (device tensors, no sync)."""
+        require_gpu(bboxes, gt_bboxes)
+        w = 5 if self.rotated else 4
+        if bboxes.dim() != 2 or bboxes.size(1) < w or (gt_bboxes.numel() and gt_bboxes.size(1) < w):
+            raise SM3Error(f'MaxIoUAssigner: boxes must be (n, >={w})')
+        b = bboxes.detach().float().contiguous()
+        g = gt_bboxes.detach().float().contiguous()
+        n, k = b.size(0), g.size(0)
+        gt_inds = torch.empty(n, dtype=torch.long, device=b.device)
+        max_ov = torch.empty(n, dtype=torch.float32, device=b.device)
+        labels = torch.empty(n, dtype=torch.long, device=b.device) if gt_labels is not None else None
+        gl = gt_labels.long().contiguous() if gt_labels is not None else None
+        if n:
+            with torch.cuda.device(b.device):
+                nb = lib().sm3_max_iou_assign_workspace_bytes(n, k)
+                ws = workspace(nb, b.device)
+                check(lib().sm3_max_iou_assign(ptr(b), b.size(1), n, ptr(g), g.size(1) if k else w, k, int(self.rotated),
+                                               self.pos_iou_thr, self.neg_iou_thr, self.min_pos_iou,
+                                               int(self.match_low_quality), ptr(gl), ptr(gt_inds), ptr(max_ov),
+                                               ptr(labels), ptr(ws), nb, stream_ptr()), 'max_iou_assign')
+        return AssignResult(k, gt_inds, max_ov, labels)
+
+
+class SamplingResult:
+    """mmdet SamplingResult (the fields the heads read)"""
+
+    def __init__(self, pos_inds, neg_inds, bboxes, gt_bboxes, assign_result, gt_flags):
+        self.pos_inds, self.neg_inds = pos_inds, neg_inds
+        self.pos_bboxes, self.neg_bboxes = bboxes[pos_inds], bboxes[neg_inds]
+        self.pos_is_gt = gt_flags[pos_inds]
+        self.num_gts = gt_bboxes.shape[0]
+        self.pos_assigned_gt_inds = assign_result.gt_inds[pos_inds] - 1
+        if gt_bboxes.numel() == 0:
+            self.pos_gt_bboxes = torch.empty_like(gt_bboxes).view(-1, gt_bboxes.size(-1) if gt_bboxes.dim() == 2 else 4)
+        else:
+            self.pos_gt_bboxes = gt_bboxes[self.pos_assigned_gt_inds.long(), :]
+        self.pos_gt_labels = assign_result.labels[pos_inds] if assign_result.labels is not None else None
+
+    @property
+    def bboxes(self):
+        return torch.cat([self.pos_bboxes, self.neg_bboxes])
+
+
+@BBOX_SAMPLERS.register_module()
+class RandomSampler:
+    def __init__(self, num, pos_fraction, neg_pos_ub=-1, add_gt_as_proposals=True, **kwargs):
+        self.num, self.pos_fraction, self.neg_pos_ub = int(num), float(pos_fraction), neg_pos_ub
+        self.add_gt_as_proposals = bool(add_gt_as_proposals)
+
+    def sample_fixed(self, gt_inds, generator=None):
+        """Sync-free core.  gt_inds (n,) as produced by the assigner (after add_gt_ when applicable).  Returns
+        (idx (num,) long, is_pos (num,) bool, valid (num,) bool, n_pos, n_neg device scalars): up to
+        int(num*pos_fraction) uniformly chosen positives first, then uniformly chosen negatives filling ``num``
+        (capped at neg_pos_ub * max(n_pos, 1) when neg_pos_ub >= 0); unused slots have valid = False."""
+        n = gt_inds.numel()
+        dev = gt_inds.device
+        num = self.num
+        exp_pos = int(num * self.pos_fraction)
+        key = torch.rand(n, device=dev, generator=generator)
+        pos, neg = gt_inds > 0, gt_inds == 0
+        big = torch.full_like(key, 2.0)
+        pos_order = torch.argsort(torch.where(pos, key, big))  # positives first, in random order
+        neg_order = torch.argsort(torch.where(neg, key, big))
+        n_pos_all, n_neg_all = pos.sum(), neg.sum()
+        n_pos = torch.clamp(n_pos_all, max=exp_pos)
+        n_neg = torch.minimum(n_neg_all, num - n_pos)
+        if self.neg_pos_ub >= 0:
+            n_neg = torch.minimum(n_neg, (self.neg_pos_ub * torch.clamp(n_pos, min=1)).long())
+        slot = torch.arange(num, device=dev)
+        take_pos = slot < n_pos
+        from_neg = (slot - n_pos).clamp(min=0)
+        pidx = pos_order[slot.clamp(max=max(n - 1, 0))] if n else slot * 0
+        nidx = neg_order[from_neg.clamp(max=max(n - 1, 0))] if n else slot * 0
+        idx = torch.where(take_pos, pidx, nidx)
+        valid = take_pos | ((slot >= n_pos) & (slot < n_pos + n_neg))
+        return idx, take_pos, valid, n_pos, n_neg
+
+    def sample(self, assign_result, bboxes, gt_bboxes, gt_labels=None, generator=None, **kwargs):
+        """mmdet BaseSampler.sample: variable-length SamplingResult (compaction = one host sync, inherent to the API)."""
+        w = gt_bboxes.size(-1) if gt_bboxes.dim() == 2 and gt_bboxes.numel() else bboxes.size(-1)
+        bboxes = bboxes[:, :w]
+        gt_flags = bboxes.new_zeros((bboxes.shape[0],), dtype=torch.uint8)
+        if self.add_gt_as_proposals and len(gt_bboxes) > 0:
+            if gt_labels is None:
+                raise ValueError('gt_labels must be given when add_gt_as_proposals is True')
+            bboxes = torch.cat([gt_bboxes, bboxes], dim=0)
+            assign_result.add_gt_(gt_labels)
+            gt_flags = torch.cat([bboxes.new_ones(gt_bboxes.shape[0], dtype=torch.uint8), gt_flags])
+        idx, is_pos, valid, _, _ = self.sample_fixed(assign_result.gt_inds, generator)
+        pos_inds, neg_inds = idx[is_pos & valid], idx[(~is_pos) & valid]
+        return SamplingResult(pos_inds, neg_inds, bboxes, gt_bboxes, assign_result, gt_flags)
+
+
+@BBOX_SAMPLERS.register_module()
+class RRandomSampler(RandomSampler):
+    """mmrotate/core/bbox/samplers/rotate_random_sampler.py:10 -- same rule on rotated boxes"""

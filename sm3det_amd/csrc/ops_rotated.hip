@@ -740,10 +740,115 @@ __global__ __launch_bounds__(ROI_THREADS) void roi_align_rotated_bwd_kernel(
   }
 }
 
+
+// ---------------------------------------------------------------- MaxIoU assignment
+// mmdet MaxIoUAssigner.assign_wrt_overlaps (the assigner of `rpn` and `rcnn` in local_configs/main_SM3Det.py:165-196,
+// called from oriented_rpn_head.py:76-78 and oriented_standard_roi_head.py:68-70) without the (k x n) overlap matrix:
+// one thread per box walks the k ground-truth boxes.  rotated = 1: boxes (cx,cy,w,h,a), IoU of RBboxOverlaps2D =
+// rbbox_overlaps (rotate_iou2d_calculator.py:52-87: w,h clamped to >= 1e-3, then box_iou_rotated); rotated = 0: boxes
+// (x1,y1,x2,y2), mmdet bbox_overlaps 'iou' (eps 1e-6).
+__device__ __forceinline__ float assign_iou(const float* __restrict__ g, const float* __restrict__ b, int rotated) {
+  if (rotated) {
+    float gg[5] = {g[0], g[1], fmaxf(g[2], 1e-3f), fmaxf(g[3], 1e-3f), g[4]};
+    float bb[5] = {b[0], b[1], fmaxf(b[2], 1e-3f), fmaxf(b[3], 1e-3f), b[4]};
+    return single_box_iou_rotated(gg, bb, 0);
+  }
+  const float a1 = (g[2] - g[0]) * (g[3] - g[1]);
+  const float a2 = (b[2] - b[0]) * (b[3] - b[1]);
+  const float w = fmaxf(fminf(g[2], b[2]) - fmaxf(g[0], b[0]), 0.f);
+  const float h = fmaxf(fminf(g[3], b[3]) - fmaxf(g[1], b[1]), 0.f);
+  const float ov = w * h;
+  const float uni = fmaxf(a1 + a2 - ov, 1e-6f);
+  return ov / uni;
+}
+
+// pass 1: max_ov[j] = max_i iou(gt_i, box_j), argmax[j] = first i reaching it; gt_max_bits[i] = max_j (as ordered
+// bits: IoUs are >= 0, so the unsigned order of the bit patterns is the float order).  gt_max_bits zeroed by the caller.
+__global__ __launch_bounds__(256) void max_iou_pass1_kernel(const float* __restrict__ boxes, int box_stride, int n,
+                                                           const float* __restrict__ gts, int gt_stride, int k,
+                                                           int rotated, float* __restrict__ max_ov,
+                                                           int32_t* __restrict__ argmax,
+                                                           unsigned* __restrict__ gt_max_bits) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const float* b = boxes + (long)j * box_stride;
+  float best = -1.f;
+  int bi = 0;
+  for (int i = 0; i < k; i++) {
+    const float ov = assign_iou(gts + (long)i * gt_stride, b, rotated);
+    if (ov > best) {
+      best = ov;
+      bi = i;
+    }
+    atomicMax(gt_max_bits + i, __float_as_uint(ov));
+  }
+  max_ov[j] = k > 0 ? best : 0.f;
+  argmax[j] = bi;
+}
+
+// pass 2: the assignment rule (negatives, positives, low-quality matches in gt order -- a later gt overrides an
+// earlier one, as the reference's python loop does), labels of the positives
+__global__ __launch_bounds__(256) void max_iou_pass2_kernel(const float* __restrict__ boxes, int box_stride, int n,
+                                                           const float* __restrict__ gts, int gt_stride, int k,
+                                                           int rotated, const float* __restrict__ max_ov,
+                                                           const int32_t* __restrict__ argmax,
+                                                           const unsigned* __restrict__ gt_max_bits, float pos_thr,
+                                                           float neg_thr, float min_pos, int match_low_quality,
+                                                           const int64_t* __restrict__ gt_labels,
+                                                           int64_t* __restrict__ gt_inds,
+                                                           int64_t* __restrict__ labels) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  int a = -1;
+  if (k == 0) {
+    a = 0;  // no ground truth: everything is background (max_iou_assigner.py: assigned_gt_inds[:] = 0)
+  } else {
+    const float mo = max_ov[j];
+    if (mo >= 0.f && mo < neg_thr) a = 0;
+    if (mo >= pos_thr) a = argmax[j] + 1;
+    if (match_low_quality) {
+      const float* b = boxes + (long)j * box_stride;
+      for (int i = 0; i < k; i++) {
+        const float gmax = __uint_as_float(gt_max_bits[i]);
+        if (gmax >= min_pos && assign_iou(gts + (long)i * gt_stride, b, rotated) == gmax) a = i + 1;
+      }
+    }
+  }
+  gt_inds[j] = a;
+  if (labels) labels[j] = (a > 0 && gt_labels) ? gt_labels[a - 1] : -1;
+}
+
 }  // namespace
 
 // =================================================================================================== C ABI
 extern "C" {
+
+size_t sm3_max_iou_assign_workspace_bytes(int n, int k) {
+  return align_up((size_t)(n > 0 ? n : 1) * sizeof(int32_t), 256) + (size_t)(k > 0 ? k : 1) * sizeof(unsigned);
+}
+
+int sm3_max_iou_assign(const float* boxes, int box_stride, int n, const float* gts, int gt_stride, int k, int rotated,
+                       float pos_iou_thr, float neg_iou_thr, float min_pos_iou, int match_low_quality,
+                       const int64_t* gt_labels, int64_t* gt_inds, float* max_overlaps, int64_t* labels,
+                       void* workspace, size_t workspace_bytes, sm3_stream_t stream) {
+  if (n < 0 || k < 0 || (rotated ? (box_stride < 5 || gt_stride < 5) : (box_stride < 4 || gt_stride < 4)))
+    return SM3_ERR_INVALID_ARG;
+  if (n == 0) return SM3_OK;
+  if (!boxes || !gt_inds || !max_overlaps || (k > 0 && !gts)) return SM3_ERR_INVALID_ARG;
+  const size_t need = sm3_max_iou_assign_workspace_bytes(n, k);
+  if (!workspace || workspace_bytes < need) return SM3_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  int32_t* argmax = (int32_t*)workspace;
+  unsigned* gmax = (unsigned*)((char*)workspace + align_up((size_t)n * sizeof(int32_t), 256));
+  (void)hipMemsetAsync(gmax, 0, sizeof(unsigned) * (size_t)(k > 0 ? k : 1), st);
+  const int blocks = (n + 255) / 256;
+  max_iou_pass1_kernel<<<blocks, 256, 0, st>>>(boxes, box_stride, n, gts, gt_stride, k, rotated, max_overlaps, argmax,
+                                               gmax);
+  max_iou_pass2_kernel<<<blocks, 256, 0, st>>>(boxes, box_stride, n, gts, gt_stride, k, rotated, max_overlaps, argmax,
+                                               gmax, pos_iou_thr, neg_iou_thr, min_pos_iou, match_low_quality,
+                                               gt_labels, gt_inds, labels);
+  return launch_status();
+}
 
 int sm3_box_iou_rotated(const float* boxes1, const float* boxes2, float* ious, int n1, int n2, int mode_flag,
                         int aligned, sm3_stream_t stream) {
