@@ -210,16 +210,6 @@ def ops_microbench():
     out['roi_align_rotated_bwd_nhwc'] = timeit(lambda: torch.autograd.grad(yl, xl, go, retain_graph=True))
     d10, s10 = dev(synth.rotated_boxes(10000, 7)), dev(synth.unique_scores(10000, 8))
     out['nms_rotated_10000'] = timeit(lambda: ops.nms_rotated(d10, s10, 0.1), n=3)
-    # DeformConv2d at the SURVEY 8(d) shape: x (2,256,128,128), 3x3, 256 -> 256, offsets randn*2
-    from sm3det_amd.mmcv_deform_conv import deform_conv2d
-    xd = torch.randn(2, 256, 128, 128, device='cuda', requires_grad=True)
-    od = (torch.randn(2, 18, 128, 128, device='cuda') * 2).requires_grad_(True)
-    wd = (torch.randn(256, 256, 3, 3, device='cuda') * 0.02).requires_grad_(True)
-    out['deform_conv2d_fwd_2x256x128x128'] = timeit(lambda: deform_conv2d(xd, od, wd, 1, 1, 1, 1, 1, False, 2), n=5)
-    yd = deform_conv2d(xd, od, wd, 1, 1, 1, 1, 1, False, 2)
-    gd = torch.randn_like(yd)
-    out['deform_conv2d_bwd_2x256x128x128'] = timeit(
-        lambda: torch.autograd.grad(yd, (xd, od, wd), gd, retain_graph=True), n=5)
     # the neck of main_SM3Det.py on backbone-shaped NHWC inputs (bs 2 @ 1024^2, start_level 0)
     from sm3det_amd.fpn import MultitaskFPN
     fpn = MultitaskFPN(in_channels=[96, 192, 384, 768], out_channels=256, extra_level=1, add_extra_convs='on_output',
@@ -293,12 +283,56 @@ def ops_microbench():
         a, b = head(xf)
         ((a * a).mean() + (b * b).mean()).backward()
     out['shared2fc_head_fwd_bwd_1024rois'] = timeit(head_step, n=5)
-    # the pieces chained as the detector chains them for the 2-stage branch (no losses / targets: those are mmdet):
-    # backbone -> neck -> RPN tower -> proposals (no grad) -> RoI extractor -> Shared2FC, forward + backward, bs 2
-    from sm3det_amd.rpn_head import rbbox2roi
+    # DeformConv2d at the SURVEY 8(d) shape: x (2,256,128,128), 3x3, 256 -> 256, offsets randn*2
+    from sm3det_amd.mmcv_deform_conv import deform_conv2d
+    xd = torch.randn(2, 256, 128, 128, device='cuda', requires_grad=True)
+    od = (torch.randn(2, 18, 128, 128, device='cuda') * 2).requires_grad_(True)
+    wd = (torch.randn(256, 256, 3, 3, device='cuda') * 0.02).requires_grad_(True)
+    out['deform_conv2d_fwd_2x256x128x128'] = timeit(lambda: deform_conv2d(xd, od, wd, 1, 1, 1, 1, 1, False, 2), n=5)
+    yd = deform_conv2d(xd, od, wd, 1, 1, 1, 1, 1, False, 2)
+    gd = torch.randn_like(yd)
+    out['deform_conv2d_bwd_2x256x128x128'] = timeit(
+        lambda: torch.autograd.grad(yd, (xd, od, wd), gd, retain_graph=True), n=5)
+    del xd, od, wd, yd, gd
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()  # the column buffers of DeformConv2d (GBs) otherwise distort the allocator for what follows
+    # GFL head towers (SAR branch) on the 5 levels it sees at 1024^2 (strides 8..128), one image, forward + backward
+    from sm3det_amd.gfl_head import GFLHead
+    gfl = GFLHead(num_classes=26, in_channels=256, stacked_convs=4, feat_channels=256, reg_max=16).cuda()
+    gl_feats = [torch.randn(1, 256, 128 >> i, 128 >> i, device='cuda').contiguous(memory_format=torch.channels_last)
+                .requires_grad_(True) for i in range(5)]
+
+    def gfl_step():
+        for q in gfl.parameters():
+            q.grad = None
+        cs, rg = gfl(gl_feats)
+        (sum((c * c).mean() for c in cs) + sum((r * r).mean() for r in rg)).backward()
+    out['gfl_head_fwd_bwd_bs1_5levels'] = timeit(gfl_step, n=5)
+    # target assignment on the real shapes: rpn = 261 888 anchors x 8 gts (horizontal), rcnn = 2000 proposals x 8 gts
+    from sm3det_amd.assign import MaxIoUAssigner, RandomSampler
+    from sm3det_amd.rpn_head import grid_anchors as _ga
+    anc = torch.cat(_ga([(256 >> i, 256 >> i) for i in range(5)], [4, 8, 16, 32, 64], [8], [0.5, 1.0, 2.0], device='cuda'))
+    ghb = dev(synth.hboxes(8, 31, extent=1024.0))
+    rpn_asg = MaxIoUAssigner(pos_iou_thr=0.7, neg_iou_thr=0.3, min_pos_iou=0.3, match_low_quality=True)
+    out['max_iou_assign_rpn_261888x8'] = timeit(lambda: rpn_asg.assign(anc, ghb))
+    grb = dev(synth.rotated_boxes(8, 32))
+    prb = dev(synth.rotated_boxes(2000, 33, cluster=True))
+    rcnn_asg = MaxIoUAssigner(pos_iou_thr=0.5, neg_iou_thr=0.5, min_pos_iou=0.5, match_low_quality=False,
+                              iou_calculator=dict(type='RBboxOverlaps2D'))
+    out['max_iou_assign_rcnn_2000x8_rotated'] = timeit(lambda: rcnn_asg.assign(prb, grb))
+    # ---- second named workload (never part of `value`): the two-stage branch chained as the detector chains it --
+    # backbone -> neck -> Oriented-RPN tower -> proposals (fixed-size, sync-free) -> MaxIoU assignment + random sampling
+    # (512 RoIs / image) -> fused multi-level RoI extractor -> Shared2FC head, forward + backward, bs 2 @ 1024^2, replayed
+    # from ONE hipGraph.  Losses are surrogates (the real ones are mmdet code); no optimizer step.
     bb = build_model().cuda().train()
     img = torch.randn(BATCH, 3, RES, RES, device='cuda')
     mods = (bb, fpn, rpn, head)
+    sampler = RandomSampler(num=512, pos_fraction=0.25, neg_pos_ub=-1, add_gt_as_proposals=False)
+    gts = [dev(synth.rotated_boxes(8, 40 + i)) for i in range(BATCH)]
+    lvl_sizes = [(RES // s, RES // s) for s in (4, 8, 16, 32, 64)]
+    anchors = _ga(lvl_sizes, [4, 8, 16, 32, 64], [8], [0.5, 1.0, 2.0], device='cuda')
+    prop_cfg = dict(nms_pre=2000, max_per_img=2000, nms=dict(type='nms', iou_threshold=0.8), min_bbox_size=0)
+    bidx = torch.arange(BATCH, device='cuda', dtype=torch.float32).view(BATCH, 1, 1).expand(BATCH, 512, 1)
 
     def slice_step():
         for m in mods:
@@ -307,13 +341,36 @@ def ops_microbench():
         feats_, gl_ = bb(img, ['single'])
         pyr = fpn(feats_)
         cls_, reg_ = rpn(pyr)
-        props = rpn.get_bboxes(cls_, reg_, cfg=dict(nms_pre=2000, max_per_img=512,
-                                                    nms=dict(type='nms', iou_threshold=0.8), min_bbox_size=0))
-        rois_ = rbbox2roi(props)
+        with torch.no_grad():
+            props, _cnt = rpn.get_bboxes_fixed(cls_, reg_, (RES, RES, 3), prop_cfg, mlvl_anchors=anchors)
+            sel = []
+            for i in range(BATCH):
+                ar = rcnn_asg.assign(props[i, :, :5].contiguous(), gts[i])
+                idx, _is_pos, _valid, _, _ = sampler.sample_fixed(ar.gt_inds)
+                sel.append(props[i, :, :5][idx])
+            rois_ = torch.cat([bidx, torch.stack(sel)], -1).view(-1, 6)
         a, b = head(ext(pyr[:4], rois_))
-        (gl_ + (a * a).mean() + (b * b).mean() + sum((c * c).mean() for c in cls_)
-         + sum((r * r).mean() for r in reg_)).backward()
-    out['detector_slice_fwd_bwd_bs2_1024'] = timeit(slice_step, n=3)
+        loss = (gl_ + (a * a).mean() + (b * b).mean() + sum((c * c).mean() for c in cls_)
+                + sum((r * r).mean() for r in reg_))
+        loss.backward()
+        return loss
+
+    # everything about the slice runs on a NON-default stream: autograd caches each parameter's AccumulateGrad node with
+    # the stream of its first use, and a node bound to the legacy default stream drags that stream into a later capture
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        out['detector_slice_eager_fwd_bwd_bs2_1024'] = timeit(slice_step, n=3)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    try:
+        gslice = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gslice):
+            slice_step()
+        out['detector_slice_fwd_bwd_bs2_1024'] = timeit(gslice.replay, n=5)
+    except Exception as e:  # noqa: BLE001
+        print(f'[bench] detector slice: hipGraph capture failed ({type(e).__name__}: {e})', file=sys.stderr)
+        out['detector_slice_fwd_bwd_bs2_1024'] = out['detector_slice_eager_fwd_bwd_bs2_1024']
     return {k: round(v, 1) for k, v in out.items()}
 
 

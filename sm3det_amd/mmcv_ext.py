@@ -78,6 +78,26 @@ def nms(boxes, scores, iou_threshold, offset):
         return _finish_keep(keep, num)
 
 
+def nms_fixed(boxes, scores, iou_threshold, offset):
+    """Sync-free form of ``nms``: returns (keep (N,) int64 -- the first ``num`` entries are the kept indices in
+    descending-score order, the rest undefined -- and num (1,) int32 ON THE DEVICE).  The mmcv entry point above has
+    to read ``num`` on the host to size its result; a training step that only needs the first max_per_img proposals
+    does not (sm3det_amd.rpn_head.OrientedRPNHead.get_bboxes_fixed)."""
+    require_gpu(boxes, scores)
+    n = boxes.size(0)
+    _f32c(boxes, 'boxes'); _f32c(scores, 'scores')
+    if n == 0 or boxes.size(1) != 4 or scores.numel() != n:
+        raise SM3Error('nms_fixed expects non-empty boxes (N,4) and scores (N,)')
+    with torch.cuda.device(boxes.device):
+        keep = torch.empty(n, dtype=torch.long, device=boxes.device)
+        num = torch.empty(1, dtype=torch.int32, device=boxes.device)
+        nbytes = lib().sm3_nms_workspace_bytes(n)
+        ws = workspace(nbytes, boxes.device)
+        check(lib().sm3_nms(ptr(boxes), ptr(scores), None, n, float(iou_threshold), int(offset), ptr(keep),
+                            ptr(num), ptr(ws), nbytes, stream_ptr()), 'nms')
+    return keep, num
+
+
 def nms_rotated(dets, scores, order, dets_sorted, iou_threshold, multi_label):
     """pybind.cpp:311-313,749-751.  Follows the CPU path (pytorch/nms_rotated.cpp:31 ->
     cpu/nms_rotated.cpp:7-57): ``order``/``dets_sorted``/``multi_label`` are ignored, labels in a 6th column too;

@@ -253,6 +253,62 @@ class OrientedRPNHead(nn.Module):
         dets = torch.cat([proposals, scores[:, None]], dim=1)[keep]
         return dets[:max_per_img]
 
+    def get_bboxes_fixed(self, cls_scores, bbox_preds, img_shape=None, cfg=None, mlvl_anchors=None):
+        """Sync-free proposal generation for the training step: the same pipeline as ``_get_bboxes_single`` (per level
+        sigmoid -> top nms_pre -> MidpointOffsetCoder.decode -> obb2xyxy, then level-aware NMS on the horizontal
+        boxes), but the result is a FIXED-size block per image, (B, max_per_img, 6) proposals (cx,cy,w,h,a,score) +
+        (B,) valid counts on the device; slots past the count are zero boxes.  Requires min_bbox_size == 0 and every
+        level to have >= nms_pre candidates or all of them used (true for the SM3Det configs), so no shape depends on
+        data and the whole thing can sit inside a hipGraph."""
+        from . import mmcv_ext
+        cfg = dict(self.test_cfg if cfg is None else cfg)
+        nms_pre, max_per_img = int(cfg.get('nms_pre', -1)), int(cfg['max_per_img'])
+        if float(cfg.get('min_bbox_size', 0)) > 0:
+            raise NotImplementedError('get_bboxes_fixed: min_bbox_size > 0 makes the proposal count data dependent')
+        thr = float(cfg['nms'].get('iou_threshold', cfg['nms'].get('iou_thr', 0.7)))
+        B = cls_scores[0].shape[0]
+        if mlvl_anchors is None:
+            sizes = [tuple(c.shape[-2:]) for c in cls_scores]
+            mlvl_anchors = grid_anchors(sizes, self.anchor_cfg['strides'], self.anchor_cfg.get('scales', [8]),
+                                        self.anchor_cfg.get('ratios', [1.0]), device=cls_scores[0].device)
+        L = _lib.lib()
+        out = cls_scores[0].new_zeros(B, max_per_img, 6)
+        counts = torch.zeros(B, dtype=torch.int32, device=out.device)
+        slot = torch.arange(max_per_img, device=out.device)
+        for i in range(B):
+            props, hboxes, scores, ids = [], [], [], []
+            for idx in range(len(cls_scores)):
+                logits = cls_scores[idx][i].detach().permute(1, 2, 0).reshape(-1).float().contiguous()
+                deltas = bbox_preds[idx][i].detach().permute(1, 2, 0).reshape(-1, 6)
+                n = logits.numel()
+                sc = torch.empty_like(logits)
+                call('sigmoid_f32', logits, sc, n)
+                order = None
+                if nms_pre > 0 and n > nms_pre:
+                    nb = L.sm3_argsort_desc_workspace_bytes(n)
+                    ws = _lib.workspace(nb, sc.device)
+                    full = torch.empty(n, dtype=torch.int64, device=sc.device)
+                    call('argsort_desc_f32', sc, n, full, ws, nb)
+                    order = full[:nms_pre]
+                p, hb, s = self.bbox_coder.decode(mlvl_anchors[idx], deltas, max_shape=img_shape, order=order, scores=sc)
+                props.append(p)
+                hboxes.append(hb)
+                scores.append(s)
+                ids.append(torch.full((s.numel(),), idx, dtype=torch.float32, device=s.device))
+            proposals, hprop = torch.cat(props), torch.cat(hboxes)
+            scores, ids = torch.cat(scores), torch.cat(ids)
+            # batched_nms offset trick (mmcv/ops/nms.py:300-304), then ONE NMS whose keep count stays on the device
+            off = ids * (hprop.max() + 1.0)
+            keep, num = mmcv_ext.nms_fixed((hprop + off[:, None]).contiguous(), scores.contiguous(), thr, 0)
+            m = min(max_per_img, keep.numel())
+            cnt = torch.clamp(num[0], max=m)
+            valid = slot[:m] < cnt
+            kidx = torch.where(valid, keep[:m], torch.zeros_like(keep[:m]))
+            dets = torch.cat([proposals, scores[:, None]], 1)[kidx] * valid[:, None].to(proposals.dtype)
+            out[i, :m] = dets
+            counts[i] = cnt
+        return out, counts
+
     def get_bboxes(self, cls_scores, bbox_preds, img_metas=None, cfg=None, rescale=False, mlvl_anchors=None):
         """per-image proposals (list of (n,6) tensors) from the multi-level head outputs"""
         num_imgs = cls_scores[0].shape[0]

@@ -179,3 +179,47 @@ def test_coder_round_trips_on_the_device():
                                   edge_swap=es, proj_xy=pj)
         back = xc.decode(rois.cuda(), xc.encode(rois.cuda(), gt.cuda()))
         assert_boxes_close(back.cpu(), gt, 5e-3, 1e-4)
+
+
+def test_get_bboxes_fixed_equals_the_variable_length_path_and_is_graph_capturable():
+    """sync-free fixed-size proposals == the first `count` rows of `_get_bboxes_single`, zeros after; and the call can
+    be captured in a hipGraph (no host synchronisation inside)."""
+    from sm3det_amd.rpn_head import OrientedRPNHead, grid_anchors
+    torch.manual_seed(0)
+    rpn = OrientedRPNHead(in_channels=256, feat_channels=256, version='le90',
+                          bbox_coder=dict(type='MidpointOffsetCoder', angle_range='le90', target_means=[0.0] * 6,
+                                          target_stds=[1.0, 1.0, 1.0, 1.0, 0.5, 0.5])).cuda()
+    rpn.init_weights()
+    g = torch.Generator().manual_seed(3)
+    sizes = [(64, 64), (32, 32), (16, 16), (8, 8), (4, 4)]
+    cls = [torch.randn(2, 3, h, w, generator=g).cuda() for h, w in sizes]
+    reg = [torch.randn(2, 18, h, w, generator=g).cuda() * 0.5 for h, w in sizes]
+    anchors = grid_anchors(sizes, [4, 8, 16, 32, 64], device='cuda')
+    cfg = dict(nms_pre=1000, max_per_img=300, nms=dict(type='nms', iou_threshold=0.8), min_bbox_size=0)
+    props, counts = rpn.get_bboxes_fixed(cls, reg, (256, 256, 3), cfg, mlvl_anchors=anchors)
+    assert props.shape == (2, 300, 6) and counts.dtype == torch.int32
+    for i in range(2):
+        ref = rpn._get_bboxes_single([c[i] for c in cls], [r[i] for r in reg], anchors, (256, 256, 3), None, cfg)
+        n = int(counts[i])
+        assert n == ref.shape[0] == 300
+        assert torch.equal(props[i, :n], ref)
+    # few candidates: count < max_per_img, the tail is zero
+    cfg2 = dict(cfg, nms=dict(type='nms', iou_threshold=0.05), max_per_img=2000)
+    props, counts = rpn.get_bboxes_fixed(cls, reg, (256, 256, 3), cfg2, mlvl_anchors=anchors)
+    for i in range(2):
+        ref = rpn._get_bboxes_single([c[i] for c in cls], [r[i] for r in reg], anchors, (256, 256, 3), None, cfg2)
+        n = int(counts[i])
+        assert n == ref.shape[0] < 2000 and torch.equal(props[i, :n], ref) and float(props[i, n:].abs().sum()) == 0.0
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        rpn.get_bboxes_fixed(cls, reg, (256, 256, 3), cfg, mlvl_anchors=anchors)
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        p2, c2 = rpn.get_bboxes_fixed(cls, reg, (256, 256, 3), cfg, mlvl_anchors=anchors)
+    gr.replay()
+    torch.cuda.synchronize()
+    ref = rpn._get_bboxes_single([c[0] for c in cls], [r[0] for r in reg], anchors, (256, 256, 3), None, cfg)
+    assert torch.equal(p2[0], ref)
