@@ -660,6 +660,10 @@ def main():
             'loss': float(loss.detach()),
             'roofline': roofline,
             'kernels_ms_per_step': {n: round(v['ms'], 3) for n, v in sorted(kernels.items(), key=lambda kv: -kv[1]['ms'])},
+            # achieved GB/s of the HBM-bound kernels: ALGORITHMIC bytes (each operand once) / time
+            'kernels_algorithmic_gbs': {n: round(v['bytes'] / (v['ms'] * 1e-3) / 1e9, 1) for n, v in
+                                        sorted(kernels.items(), key=lambda kv: -kv[1]['ms'])
+                                        if v['bytes'] > 0 and v['ms'] > 0 and not n.startswith('gemm_f')},
         }
         if world == 1 and not args.no_ops:
             result['ops_us'] = ops_microbench()

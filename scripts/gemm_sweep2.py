@@ -63,7 +63,7 @@ def candidates(mode, M, N, K, quick):
             for bk in ((16, 32) if t < 3 else (16,)):
                 for s in (1, 2, 3, 4, 6, 8):
                     out.append(dict(tile=t, bk=bk, splits=s))
-                for s in (2, 3, 4, 6, 8, 12, 16, 32, 64, 128, 341):
+                for s in (2, 3, 4, 5, 6, 8, 10, 12, 16, 21, 24, 32, 48, 64, 96, 128, 192, 256, 341):
                     out.append(dict(tile=t, bk=bk, splits=s, separate=True))
     else:
         for t in (0, 1, 3, 5):
@@ -79,6 +79,8 @@ def main():
     quick = '--quick' in sys.argv
     dev = torch.device('cuda')
     for mode, M, N, K, G, epi, cnt in SHAPES:
+        if '--tn-only' in sys.argv and mode != 'tn':
+            continue
         rows = K if mode == 'tn' else M
         offs = None
         if G > 1:  # mildly ragged expert loads

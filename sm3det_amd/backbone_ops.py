@@ -199,7 +199,7 @@ class _LayerNorm(Function):
         T, C = x.shape
         y = _e(T // 4, 4 * C, like=x) if mode == 1 else _e(T, C, like=x)
         mean, rstd = _e(T, like=x), _e(T, like=x)
-        call('layernorm_fwd', x, w, b, float(eps), y, mean, rstd, T, C, mode, H, W)
+        call('layernorm_fwd', x, w, b, float(eps), y, mean, rstd, T, C, mode, H, W, nbytes=8.0 * T * C)
         ctx.save_for_backward(x, w, mean, rstd)
         ctx.meta = (mode, H, W)
         return y
@@ -212,7 +212,8 @@ class _LayerNorm(Function):
         dx = _e(T, C, like=x)
         dwdb = _e(2, C, like=x)
         ws, nb = LB.row_ws(C, x)
-        call('layernorm_bwd', dy.contiguous(), x, w, mean, rstd, dx, dwdb, T, C, mode, H, W, 0, ws, nb)
+        call('layernorm_bwd', dy.contiguous(), x, w, mean, rstd, dx, dwdb, T, C, mode, H, W, 0, ws, nb,
+             nbytes=12.0 * T * C)
         return dx, dwdb[0], dwdb[1], None, None, None, None
 
 
@@ -224,10 +225,10 @@ def layer_norm(x, w, b, eps, patch_major=False, H=0, W=0):
 def _dw_ln_forward(x, w49, bdw, lnw, lnb, eps, B, H, W, C):
     T = B * H * W
     u = _e(T, C, like=x)
-    call('dwconv7_fwd', x, w49, bdw, None, u, B, H, W, C, 0)
+    call('dwconv7_fwd', x, w49, bdw, None, u, B, H, W, C, 0, nbytes=8.0 * T * C)
     xn = _e(T, C, like=x)
     mean, rstd = _e(T, like=x), _e(T, like=x)
-    call('layernorm_fwd', u, lnw, lnb, float(eps), xn, mean, rstd, T, C, 0, H, W)
+    call('layernorm_fwd', u, lnw, lnb, float(eps), xn, mean, rstd, T, C, 0, H, W, nbytes=8.0 * T * C)
     return u, xn, mean, rstd
 
 
@@ -238,13 +239,14 @@ def _dw_ln_backward(dxn, dout, x, u, w49, lnw, mean, rstd, B, H, W, C):
     du = _e(T, C, like=x)
     dwdb = _e(2, C, like=x)
     ws, nb = LB.row_ws(C, x)
-    call('layernorm_bwd', dxn, u, lnw, mean, rstd, du, None, T, C, 0, H, W, 0, ws, nb)
+    call('layernorm_bwd', dxn, u, lnw, mean, rstd, du, None, T, C, 0, H, W, 0, ws, nb, nbytes=12.0 * T * C)
     _deferred_reduce(ws, T, C, 2 * C, dwdb)  # d(ln weight) | d(ln bias); joined by the caller
     dwb = _e(50, C, like=x)  # [dw49 (49,C); dbias (C)] in one buffer: one fill inside the kernel wrapper
     dw49, dbdw = dwb[:49], dwb[49]
-    _on_side(x.device, lambda: call('dwconv7_bwd_weight', x, du, dw49, dbdw, B, H, W, C))  # joined by the caller
+    _on_side(x.device, lambda: call('dwconv7_bwd_weight', x, du, dw49, dbdw, B, H, W, C,
+                                    nbytes=8.0 * T * C))  # joined by the caller
     dx = _e(T, C, like=x)
-    call('dwconv7_fwd', du, w49, None, dout, dx, B, H, W, C, 1)  # flip=1: correlation with the reversed taps
+    call('dwconv7_fwd', du, w49, None, dout, dx, B, H, W, C, 1, nbytes=12.0 * T * C)  # flip=1: reversed taps
     return dx, dw49, dbdw, dwdb[0], dwdb[1]
 
 
@@ -281,7 +283,7 @@ class _DenseBlock(Function):
         dy, dgdb = _e(T, C, like=x), _e(2, C, like=x)
         ws, nb = LB.row_ws(C, x)
         dev = x.device
-        call('scale_bwd_prep', dout, y, gamma, rs, H * W, dy, None, T, C, ws, nb)
+        call('scale_bwd_prep', dout, y, gamma, rs, H * W, dy, None, T, C, ws, nb, nbytes=12.0 * T * C)
         _deferred_reduce(ws, T, C, 2 * C, dgdb)
         dgamma, db2 = dgdb[0], dgdb[1]
         dw2 = _on_side(dev, lambda: _tn(dy, act, C, Hd, T))
@@ -337,7 +339,7 @@ class _MoEBlock(Function):
         nblk = _lib.lib().sm3_moe_router_partial_rows(T)
         partials = _e(nblk, 2 * E, like=x)
         call('moe_router_fwd', hcat, PC, P, snorm, scale, noise, T, E, k, int(train), top_idx, top_val, gates,
-             clean, sigma, hnorm, partials)
+             clean, sigma, hnorm, partials, nbytes=4.0 * T * (PC + 4 * E))
         tot, loss = _e(2 * E, like=x), _e(1, like=x)
         call('moe_aux_loss_fwd', partials, nblk, E, float(loss_coef), tot, loss)
         # dispatch tables (no host sync)
@@ -348,7 +350,7 @@ class _MoEBlock(Function):
         ws = _lib.workspace(nb, x.device)
         call('moe_plan', top_idx, m, T, E, k, offsets, slot_token, token_slot, ws, nb)
         xslot = _e(S, C, like=x)
-        call('moe_dispatch', xn, slot_token, xslot, S, C)
+        call('moe_dispatch', xn, slot_token, xslot, S, C, nbytes=8.0 * S * C)
         # experts: grouped GEMM pair over the expert-major slots
         hpre, act = _e(S, Hd, like=x), _e(S, Hd, like=x)
         gemm(LB.NT, xslot, w1, act, S, Hd, C, epilogue=LB.EPI_BIAS_GELU, bias=b1, aux_out=hpre, offsets=offsets,
@@ -356,7 +358,8 @@ class _MoEBlock(Function):
         yslot = _e(S, C, like=x)
         gemm(LB.NT, act, w2, yslot, S, C, Hd, epilogue=LB.EPI_BIAS, bias=b2, offsets=offsets, num_groups=E)
         out = _e(T, C, like=x)
-        call('moe_combine_fwd', yslot, token_slot, gates, x, gamma, rs, H * W, out, T, C, k)
+        call('moe_combine_fwd', yslot, token_slot, gates, x, gamma, rs, H * W, out, T, C, k,
+             nbytes=4.0 * (k + 2) * T * C)
         ctx.compute = LB.COMPUTE
         ctx.save_for_backward(x, u, mean, rstd, xn, hcat, top_idx, top_val, gates, clean, sigma, hnorm, offsets,
                               token_slot, xslot, hpre, act, yslot, w49, lnw, wcat, snorm, scale, w1, w2, gamma, rs,
@@ -390,7 +393,8 @@ class _MoEBlock(Function):
         # combine backward
         dyslot, dgate, dgamma = _e(S, C, like=x), _e(T, k, like=x), _e(C, like=x)
         ws, nb = LB.row_ws(C, x)
-        call('moe_combine_bwd', dout, yslot, token_slot, gates, gamma, rs, H * W, dyslot, dgate, None, T, C, k, ws, nb)
+        call('moe_combine_bwd', dout, yslot, token_slot, gates, gamma, rs, H * W, dyslot, dgate, None, T, C, k, ws, nb,
+             nbytes=4.0 * (2 * k + 1) * T * C)
         _deferred_reduce(ws, T, C, C, dgamma)
         # experts backward (every expert gets a -- possibly zero -- gradient: DDP-safe); weight gradients on the side
         # stream, the dx chain on this one
@@ -411,7 +415,7 @@ class _MoEBlock(Function):
         nblk = _lib.lib().sm3_moe_router_partial_rows(T)
         dhcat, dcn, ds_part = _e(T, PC, like=x), _e(T, E, like=x), _e(nblk, like=x)
         call('moe_router_bwd', hcat, PC, P, snorm, scale, noise, T, E, k, int(train), top_idx, top_val, gates, clean,
-             sigma, hnorm, dgate, dimp_load, dimp_load[E:], dhcat, dcn, ds_part)
+             sigma, hnorm, dgate, dimp_load, dimp_load[E:], dhcat, dcn, ds_part, nbytes=4.0 * T * (2 * PC + 6 * E))
         # gate parameters ([Wp; Wn^T] rows, normalize and exp(clamp) backward in one launch) -- side stream
         dwp, dbp, dwn = _e(P, C, like=x), _e(P, like=x), _e(C, E, like=x)
         dsim, dtemp = _e(P, E, like=x), _e(1, like=x)
@@ -430,7 +434,7 @@ class _MoEBlock(Function):
         _on_side(dev, gate_wgrad)
         dxn = _e(T, C, like=x)
         gemm(LB.NN, dhcat, wcat, dxn, T, C, PC)
-        call('moe_gather_add', dxslot, token_slot, dxn, T, C, k, 1)
+        call('moe_gather_add', dxslot, token_slot, dxn, T, C, k, 1, nbytes=4.0 * (k + 2) * T * C)
         dx, dw49, dbdw, dlnw, dlnb = _dw_ln_backward(dxn, dout, x, u, w49, lnw, mean, rstd, B, H, W, C)
         _join_side(dev)
         return (dx, dw49, dbdw, dlnw, dlnb, dwp, dbp, dwn, dsim, dtemp.reshape(temp.shape), dw1, db1, dw2, db2, dgamma,

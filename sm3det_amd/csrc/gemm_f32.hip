@@ -201,7 +201,8 @@ inline double quant_cost(long blocks) {
 //  * TN: candidates 128x128, 128x96, 96x128 x slices 1..512 reduced by the second pass (never the in-kernel fix-up:
 //    on 64 KB slabs it measured slower); cost adds the slab round trip, 100*G/K of the GEMM's own time per slice.
 // d->tuning (benchmarking aid, 0 in production): bits 0-3 tile+1, 4-7 k-step (1 = 16, 2 = 32), 8-15 slices,
-// bit 16: TN slices summed by the in-kernel fix-up instead of the second pass
+// bit 16: TN slices summed by the in-kernel fix-up instead of the second pass (so a literal 256 in the slices field
+// reads as `automatic + fix-up`: scripts/gemm_sweep2.py)
 Cfg choose_cfg(const sm3_gemm_desc* d) {
   Cfg c;
   memset(&c, 0, sizeof(c));
@@ -227,7 +228,7 @@ Cfg choose_cfg(const sm3_gemm_desc* d) {
       if (c.tile < 0 || cost < best - 1e-9) { best = cost; c.tile = cand[i]; best_tiles = tiles; }
     }
     if (t_tile >= 0) c.tile = t_tile;
-    c.bk = (d->K >= 1024 || (c.tile == 1 && d->K >= 384)) ? 32 : 16;
+    c.bk = (d->K >= 1024 || (c.tile == 1 && d->K >= 768)) ? 32 : 16;
     if (c.tile == 3) c.bk = 16;
     if (t_bk) c.bk = t_bk == 1 ? 16 : 32;
     if (d->K % c.bk) c.bk = 16;
@@ -277,9 +278,12 @@ Cfg choose_cfg(const sm3_gemm_desc* d) {
     for (int s = 1; s <= 512; s++) {
       if (s > 1 && rows / s < 64) break;
       if (d->splits > 0 && s != d->splits) continue;
+      if (d->splits <= 0 && s > 192) break;  // beyond ~200 slices the second pass and the short k-loops cost more than
+                                             // the extra workgroups bring (stage-0 weight gradients: 128-192 best)
       const long blocks = tiles * s;
       const double pc = (double)blocks / kNumCU;
-      const double occ = 1.0 + 0.15 * (pc < 3.0 ? 3.0 - pc : 0.0);
+      double occ = 1.0 + 0.15 * (pc < 3.0 ? 3.0 - pc : 0.0);
+      if (d->group_offsets && pc < 4.5) occ += 0.05 * (4.5 - pc);  // ragged expert segments: more, smaller work items
       const double cost = quant_cost(blocks) * occ * handicap[i] * waste + pen * (s > 1 ? s : 0);
       if (c.tile < 0 || cost < best - 1e-9) { best = cost; c.tile = cand[i]; best_s = s; }
     }

@@ -114,6 +114,7 @@ class MultiTensorAdamW(torch.optim.Optimizer):
         self._numel = torch.tensor([p.numel() for _, p in ps], dtype=torch.int64, device=dev)
         self._chunks = torch.tensor(tab, dtype=torch.int32, device=dev).contiguous()
         self._n_chunks = len(tab)
+        self._total_numel = sum(p.numel() for _, p in ps)
         self._lr = torch.empty(len(ps), dtype=torch.float32, device=dev)
         self._wd = torch.empty(len(ps), dtype=torch.float32, device=dev)
         self._step = torch.zeros(1, dtype=torch.float32, device=dev)
@@ -167,7 +168,8 @@ class MultiTensorAdamW(torch.optim.Optimizer):
         LB.call('adamw_multi', self._p_ptrs, self._g_ptrs, self._m_ptrs, self._v_ptrs, self._numel, self._chunks,
                 self._n_chunks, self._lr, self._wd, float(b1), float(b2), float(g0['eps']), float(self.max_grad_norm),
                 self._step, self._coef, self.grad_norm, self._partials, sc, float(cfg['growth_factor']),
-                float(cfg['backoff_factor']), int(cfg['growth_interval']))
+                float(cfg['backoff_factor']), int(cfg['growth_interval']),
+                nbytes=(28.0 + (4.0 if (self.max_grad_norm > 0 or sc is not None) else 0.0)) * self._total_numel)
         return loss
 
 
