@@ -619,14 +619,16 @@ def main():
         g_by = sum(v['bytes'] for v in gem)
         traffic = None  # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside bench.py)
         try:
-            with open(os.path.join(ROOT, 'profiles', 'r01', 'pmc_traffic.json')) as f:
-                traffic = round(json.load(f)['hbm_bytes_per_launch'])
+            with open(os.path.join(ROOT, 'profiles', 'r02', 'pmc_traffic.json')) as f:
+                traffic = round(json.load(f)['gemm_family']['hbm_bytes_per_launch'])
         except Exception:
             pass
         roofline = dict(bound='mfma', kernel='gemm_f32_kernel (NT/NN/TN, fp32 v_mfma_f32_32x32x2_f32)',
                         achieved=round(achieved, 2), peak=MI355X_FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
                         frac=round(achieved / MI355X_FP32_MFMA_PEAK_TFLOPS, 4), traffic=traffic,
-                        traffic_source='profiles/r01/pmc_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, per launch)',
+                        traffic_source='profiles/r02/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, '
+                                       'FETCH x2 + WRITE, per launch incl. the slice-reduce pass of the TN launches; '
+                                       'scripts/collect_artifacts.sh)',
                         algorithmic_bytes_per_launch=round(g_by / max(g_n, 1)),
                         launches_per_step=g_n, avg_launch_us=round(g_ms / max(g_n, 1) * 1e3, 2),
                         algorithmic_gflop_per_step=round(g_fl / 1e9, 1),
@@ -660,6 +662,8 @@ def main():
             'loss': float(loss.detach()),
             'roofline': roofline,
             'kernels_ms_per_step': {n: round(v['ms'], 3) for n, v in sorted(kernels.items(), key=lambda kv: -kv[1]['ms'])},
+            'kernels_launches_per_step': {n: v['launches'] for n, v in kernels.items()},
+            'kernels_algorithmic_mb_per_step': {n: round(v['bytes'] / 1e6, 1) for n, v in kernels.items() if v['bytes'] > 0},
             # achieved GB/s of the HBM-bound kernels: ALGORITHMIC bytes (each operand once) / time
             'kernels_algorithmic_gbs': {n: round(v['bytes'] / (v['ms'] * 1e-3) / 1e9, 1) for n, v in
                                         sorted(kernels.items(), key=lambda kv: -kv[1]['ms'])

@@ -14,7 +14,7 @@ import sys
 
 
 def kernel_key(name):
-    n = name.replace('void ', '').replace('(anonymous namespace)::', '')
+    n = name.replace('void ', '').replace('(anonymous namespace)::', '').replace('sm3gemm::', '')
     n = re.sub(r'<.*', '', n.split('(')[0]).strip()
     return n[:60] or name[:60]
 

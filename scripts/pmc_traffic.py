@@ -7,8 +7,13 @@ utilisation of the GEMM family from the SQ pass.
 import json
 import sys
 
-fetch, write, bench = (json.load(open(a)) for a in sys.argv[1:4])
-mfma = json.load(open(sys.argv[4])) if len(sys.argv) > 4 else None
+def _load(path):
+    d = json.load(open(path))
+    return {k.replace('sm3gemm::', ''): v for k, v in d.items()} if isinstance(d, dict) and 'metric' not in d else d
+
+
+fetch, write, bench = (_load(a) for a in sys.argv[1:4])
+mfma = _load(sys.argv[4]) if len(sys.argv) > 4 else None
 # rocprof kernel name -> name of the C-ABI call in bench.py's kernels_ms_per_step
 ALIAS = {'gemm_f32_kernel': 'gemm_f32', 'dwconv7_lds_fwd_kernel': 'dwconv7_fwd',
          'dwconv7_lds_bwd_weight_kernel': 'dwconv7_bwd_weight', 'layernorm_fwd_kernel': 'layernorm_fwd',
@@ -42,6 +47,20 @@ if mfma and 'gemm_f32_kernel' in mfma:
     busy, wave = m.get('SQ_VALU_MFMA_BUSY_CYCLES'), m.get('SQ_BUSY_CYCLES')
     ga = m.get('GRBM_GUI_ACTIVE')
     if busy and ga:
-        # MFMA-busy cycles are summed over the 1024 SIMDs; GRBM_GUI_ACTIVE is wall cycles of the kernel
-        out['gemm_family_mfma_busy_frac'] = round(busy['total'] / (ga['total'] * 1024.0), 4)
+        # same formula as profiles/r01/pmc_mfma.json: MFMA-busy cycles are summed over the 1024 SIMDs, GRBM_GUI_ACTIVE
+        # over the 8 XCDs (calibration: 64.0 busy cycles per v_mfma_f32_32x32x2_f32 on an isolated GEMM)
+        out['gemm_family_mfma_util'] = round(busy['total'] / ((ga['total'] / 8.0) * 1024.0), 4)
+        wc = m.get('SQ_WAVE_CYCLES')
+        if wc:
+            out['gemm_family_wait_inst_any_over_wave_cycles'] = round(m['SQ_WAIT_INST_ANY']['total'] / wc['total'], 3)
+            out['gemm_family_wait_any_over_wave_cycles'] = round(m['SQ_WAIT_ANY']['total'] / wc['total'], 3)
+# per-kernel: counted HBM bytes vs the algorithmic bytes the bench line states for the same C-ABI call
+alg, nl = bench.get('kernels_algorithmic_mb_per_step', {}), bench.get('kernels_launches_per_step', {})
+out['vs_algorithmic'] = {}
+for rk, bk in ALIAS.items():
+    k = out['kernels'].get(rk)
+    if k and bk in alg and nl.get(bk):
+        a = alg[bk] * 1e6 / nl[bk]
+        out['vs_algorithmic'][bk] = dict(hbm_bytes_per_launch=k['hbm_bytes_per_launch'],
+                                         algorithmic_bytes_per_launch=round(a), ratio=round(k['hbm_bytes_per_launch'] / a, 3))
 print(json.dumps(out, indent=1))

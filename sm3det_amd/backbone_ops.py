@@ -319,16 +319,28 @@ class _MoEBlock(Function):
         x = _chk(x, 'x')
         T, C = x.shape
         E, Hd = w1.shape[0], w1.shape[1]
-        P = wp.shape[0]
-        PC = _pad_rows(P + E)
+        linear = sim is None  # gating='linear' (reference :195-196): wp is w_gate (C, E), no bias / sim_matrix / temperature
+        if linear:
+            # clean logits = x @ w_gate come straight out of the fused projection: wcat = [w_gate^T (E rows, padded to a
+            # multiple of 4); w_noise^T; 0].  The (<= 2E x C) operand is assembled with three tiny torch copies -- no
+            # SM3Det config uses this gate, so it has no prep kernel of its own.
+            P = (E + 3) // 4 * 4
+            PC = _pad_rows(P + E)
+            wcat, bcat = x.new_zeros(PC, C), x.new_zeros(PC)
+            wcat[:E].copy_(wp.t())
+            wcat[P:P + E].copy_(wn.t())
+            snorm = scale = None
+        else:
+            P = wp.shape[0]
+            PC = _pad_rows(P + E)
+            # gate operands: wcat = [Wp; Wn^T; 0], bcat = [bp; 0], snorm = normalize(sim, dim=0), scale = exp(clamp(t))
+            wcat, bcat = _e(PC, C, like=x), _e(PC, like=x)
+            snorm, scale = _e(P, E, like=x), _e(1, like=x)
+            call('moe_gate_prep_fwd', wp.contiguous(), bp.contiguous(), wn.contiguous(), sim.contiguous(), temp,
+                 float(clamp_max), P, C, E, PC, wcat, bcat, snorm, scale)
         m = min(k + 1, E)
         S = T * k
         u, xn, mean, rstd = _dw_ln_forward(x, w49, bdw, lnw, lnb, eps, B, H, W, C)
-        # gate operands: wcat = [Wp; Wn^T; 0], bcat = [bp; 0], snorm = normalize(sim, dim=0), scale = exp(clamp(t))
-        wcat, bcat = _e(PC, C, like=x), _e(PC, like=x)
-        snorm, scale = _e(P, E, like=x), _e(1, like=x)
-        call('moe_gate_prep_fwd', wp.contiguous(), bp.contiguous(), wn.contiguous(), sim.contiguous(), temp,
-             float(clamp_max), P, C, E, PC, wcat, bcat, snorm, scale)
         # gate projection (+ noise projection) in one GEMM: hcat = [h | raw | 0]
         hcat = _e(T, PC, like=x)
         gemm(LB.NT, xn, wcat, hcat, T, PC, C, epilogue=LB.EPI_BIAS, bias=bcat)
@@ -417,16 +429,27 @@ class _MoEBlock(Function):
         call('moe_router_bwd', hcat, PC, P, snorm, scale, noise, T, E, k, int(train), top_idx, top_val, gates, clean,
              sigma, hnorm, dgate, dimp_load, dimp_load[E:], dhcat, dcn, ds_part, nbytes=4.0 * T * (2 * PC + 6 * E))
         # gate parameters ([Wp; Wn^T] rows, normalize and exp(clamp) backward in one launch) -- side stream
-        dwp, dbp, dwn = _e(P, C, like=x), _e(P, like=x), _e(C, E, like=x)
-        dsim, dtemp = _e(P, E, like=x), _e(1, like=x)
+        if sim is None:  # linear gate: wp is w_gate (C, E)
+            dwp, dwn = _e(C, E, like=x), _e(C, E, like=x)
+            dbp = dsim = dtemp = None
+        else:
+            dwp, dbp, dwn = _e(P, C, like=x), _e(P, like=x), _e(C, E, like=x)
+            dsim, dtemp = _e(P, E, like=x), _e(1, like=x)
+
+        linear = sim is None
 
         def gate_wgrad():
-            if E % 4 == 0:
-                dsn = _e(P, E, like=x)
-                gemm(LB.TN, hcat, dcn, dsn, P, E, T, lda=PC, ldb=E)
-            else:  # tiny (P x E) product; E not a multiple of the 16-byte vector width
-                dsn = (hcat[:, :P].t() @ dcn).contiguous()
             dwcat = _tn(dhcat, xn, PC, C, T)
+            if linear:  # d w_gate = (d hcat[:, :E])^T x,  d w_noise = (d hcat[:, P:P+E])^T x -- rows of dwcat
+                dwp.copy_(dwcat[:E].t())
+                dwn.copy_(dwcat[P:P + E].t())
+                return
+            # d snorm-product = h^T . dcn (P x E, reduction over tokens); E is padded to the 16-byte vector width
+            E4 = (E + 3) // 4 * 4
+            dcn4 = dcn if E4 == E else torch.nn.functional.pad(dcn, (0, E4 - E))
+            dsn4 = _e(P, E4, like=x)
+            gemm(LB.TN, hcat, dcn4, dsn4, P, E4, T, lda=PC, ldb=E4)
+            dsn = dsn4 if E4 == E else dsn4[:, :E].contiguous()
             dbcat = _e(PC, like=x)
             colsum(dhcat, T, PC, dbcat)
             call('moe_gate_prep_bwd', dwcat, dbcat, dsn, ds_part, nblk, sim.contiguous(), temp, clamp_max, P, C, E,
@@ -437,7 +460,8 @@ class _MoEBlock(Function):
         call('moe_gather_add', dxslot, token_slot, dxn, T, C, k, 1, nbytes=4.0 * (k + 2) * T * C)
         dx, dw49, dbdw, dlnw, dlnb = _dw_ln_backward(dxn, dout, x, u, w49, lnw, mean, rstd, B, H, W, C)
         _join_side(dev)
-        return (dx, dw49, dbdw, dlnw, dlnb, dwp, dbp, dwn, dsim, dtemp.reshape(temp.shape), dw1, db1, dw2, db2, dgamma,
+        return (dx, dw49, dbdw, dlnw, dlnb, dwp, dbp, dwn, dsim, None if dtemp is None else dtemp.reshape(temp.shape),
+                dw1, db1, dw2, db2, dgamma,
                 None, None, None, None, None, None, None, None, None, None)
 
 

@@ -9,8 +9,8 @@ Differences by design (documented in DESIGN.md):
   * expert weights are stored fused, ``(E, 4C, C)`` etc., and translated to/from the reference's per-expert
     ``ffn.experts.{e}.pointwise_conv{1,2}.{weight,bias}`` keys in ``state_dict()`` / ``load_state_dict()``;
   * the dispatch never synchronises with the host (reference: ``.cpu()`` per MoE block, :259);
-  * only ``gate='cosine'``, ``linear_pw_conv=True``, ``use_grn=False`` (what every SM3Det config uses) run on the
-    kernels; other values raise ``NotImplementedError`` at construction.
+  * both gates of the reference (``gate='cosine'`` -- every SM3Det config -- and ``gate='linear'``) run on the
+    kernels; ``linear_pw_conv=False`` and ``use_grn=True`` raise ``NotImplementedError`` at construction.
 There is no CPU path: calling the module with CPU tensors raises.
 """
 import math
@@ -109,8 +109,8 @@ class MoE_layer(nn.Module):
         self.input_size = moe_cfg['in_channels']
         self.k = moe_cfg['top_k']
         self.gating = moe_cfg['gating']
-        if self.gating != 'cosine':
-            raise NotImplementedError("only gate='cosine' (every SM3Det config) runs on the MI355X kernels")
+        if self.gating not in ('cosine', 'linear'):
+            raise NotImplementedError(f"gate={self.gating!r}: the reference knows 'cosine' and 'linear' (:127-130)")
         if moe_cfg.get('use_grn', False):
             raise NotImplementedError('use_grn=True is outside the SM3Det hot path')
         assert self.k <= self.num_experts
@@ -127,7 +127,10 @@ class MoE_layer(nn.Module):
         self.b1 = nn.Parameter(torch.stack(b1))
         self.w2 = nn.Parameter(torch.stack(w2))
         self.b2 = nn.Parameter(torch.stack(b2))
-        self.w_gate = CosineTopKGate(C, E)
+        if self.gating == 'linear':  # reference :127-128: clean_logits = x @ w_gate
+            self.w_gate = nn.Parameter(torch.zeros(C, E), requires_grad=True)
+        else:
+            self.w_gate = CosineTopKGate(C, E)
         self.w_noise = nn.Parameter(torch.zeros(C, E), requires_grad=True)
         self.register_buffer('mean', torch.tensor([0.0]))
         self.register_buffer('std', torch.tensor([1.0]))
@@ -264,10 +267,14 @@ class ConvNeXtBlock(nn.Module):
         train = bool(moe.training and moe.noisy_gating)
         if train and noise is None:
             noise = torch.randn(x.shape[0], moe.num_experts, device=x.device)  # torch.randn_like(clean) :203
+        if moe.gating == 'linear':
+            gate_args, clamp_max = (g, None, moe.w_noise, None, None), 0.0
+        else:
+            gate_args = (g.cosine_projector.weight, g.cosine_projector.bias, moe.w_noise, g.sim_matrix, g.temperature)
+            clamp_max = g.clamp_max
         out, loss, tot, offsets, top_idx = ops.moe_block(
-            x, w49, self.depthwise_conv.bias, self.norm.weight, self.norm.bias, g.cosine_projector.weight,
-            g.cosine_projector.bias, moe.w_noise, g.sim_matrix, g.temperature, moe.w1, moe.b1, moe.w2, moe.b2,
-            self.gamma, rs, noise if train else None, self.norm.eps, B, H, W, moe.k, train, g.clamp_max,
+            x, w49, self.depthwise_conv.bias, self.norm.weight, self.norm.bias, *gate_args, moe.w1, moe.b1, moe.w2,
+            moe.b2, self.gamma, rs, noise if train else None, self.norm.eps, B, H, W, moe.k, train, clamp_max,
             moe.loss_coef)  # aux loss (:234-238) comes out of the block: coef * (cv^2(importance) + cv^2(load))
         moe.last_expert_offsets = offsets
         moe.last_importance_load = tot
@@ -549,6 +556,14 @@ class ConvNeXt_moe(nn.Module):
                 elif isinstance(m, nn.LayerNorm):
                     nn.init.constant_(m.weight, 1.0)
                     nn.init.constant_(m.bias, 0.)
+                elif isinstance(m, MoE_layer):
+                    # the reference applies the same rule to every expert's pointwise_conv{1,2} Linear (they are
+                    # nn.Linear modules there); here they are fused parameters
+                    for e in range(m.num_experts):
+                        nn.init.trunc_normal_(m.w1.data[e], std=.02)
+                        nn.init.trunc_normal_(m.w2.data[e], std=.02)
+                    nn.init.constant_(m.b1, 0.)
+                    nn.init.constant_(m.b2, 0.)
             return
         cfg = self.init_cfg
         assert 'checkpoint' in cfg, f'Only support specify `Pretrained` in `init_cfg` in {self.__class__.__name__}'

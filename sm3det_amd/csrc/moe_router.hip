@@ -46,6 +46,8 @@ __device__ __forceinline__ void load_h_tile(const float* __restrict__ hcat, int 
 }
 
 // hcat row layout: [h (P) | raw (E) | pad]; snorm = column-normalised sim_matrix (P,E); scale = exp(min(tau, ln 100)).
+// snorm == NULL selects the LINEAR gate (gating='linear', convnext_moe.py:195-196: clean_logits = x @ w_gate): the first E
+// of the P columns of hcat already ARE the clean logits.
 // Outputs per token: top_idx/top_val (m = min(k+1,E), descending), gates (k, softmax of the top k), clean (E),
 // sigma (E, train only), hnorm; per-workgroup partial sums [importance (E) | load (E)] to `partials`.
 template <int ET>
@@ -57,10 +59,12 @@ __global__ __launch_bounds__(RT_THREADS) void moe_router_fwd_kernel(
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* s_s = sm;                         // snorm, row stride ET (zero padded), 16-byte aligned rows
   float* hs = sm + (long)P * ET;           // [16][P+1]
-  for (int i = threadIdx.x; i < P * ET; i += RT_THREADS) {
-    const int p = i / ET, e = i - p * ET;
-    s_s[i] = e < E ? snorm[p * E + e] : 0.f;
-  }
+  const bool linear = snorm == nullptr;
+  if (!linear)
+    for (int i = threadIdx.x; i < P * ET; i += RT_THREADS) {
+      const int p = i / ET, e = i - p * ET;
+      s_s[i] = e < E ? snorm[p * E + e] : 0.f;
+    }
   const int t0 = blockIdx.x * RT_TOKENS;
   load_h_tile(hcat, ldh, P, t0, T, hs);
   __syncthreads();
@@ -68,7 +72,7 @@ __global__ __launch_bounds__(RT_THREADS) void moe_router_fwd_kernel(
   const int t = t0 + tl;
   const bool tv = t < T;
   const int m = min(k + 1, E);
-  const float scale = *scale_p;
+  const float scale = linear ? 1.f : *scale_p;
   const bool smooth = train && (k < E);
   float impv[ET], ldv[ET];
 #pragma unroll
@@ -79,17 +83,22 @@ __global__ __launch_bounds__(RT_THREADS) void moe_router_fwd_kernel(
 #pragma unroll
     for (int e = 0; e < ET; e++) dot[e] = 0.f;
     float nn = 0.f;
-    for (int p = sub; p < P; p += LPT) {
-      const float hv = hrow[p];
-      nn += hv * hv;
-      const float* srow = s_s + p * ET;
+    if (!linear) {
+      for (int p = sub; p < P; p += LPT) {
+        const float hv = hrow[p];
+        nn += hv * hv;
+        const float* srow = s_s + p * ET;
 #pragma unroll
-      for (int e = 0; e < ET; e++) dot[e] += hv * srow[e];
+        for (int e = 0; e < ET; e++) dot[e] += hv * srow[e];
+      }
+      nn = group_sum<LPT>(nn);  // the 4 lanes of a token are adjacent: xor 1, 2 (all lanes of the group are in `tv`)
+#pragma unroll
+      for (int e = 0; e < ET; e++) dot[e] = group_sum<LPT>(dot[e]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < ET; e++) dot[e] = e < E ? hrow[e] : 0.f;
     }
-    nn = group_sum<LPT>(nn);  // the 4 lanes of a token are adjacent: xor 1, 2 (all lanes of the group are in `tv`)
-#pragma unroll
-    for (int e = 0; e < ET; e++) dot[e] = group_sum<LPT>(dot[e]);
-    const float hn = sqrtf(nn);
+    const float hn = linear ? 1.f : sqrtf(nn);
     const float inv = 1.0f / fmaxf(hn, 1e-12f);  // F.normalize eps
     const float* h = hcat + (long)t * ldh;
     float logit[ET], cl[ET], sg[ET];
@@ -204,10 +213,12 @@ __global__ __launch_bounds__(RT_THREADS) void moe_router_bwd_kernel(
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* s_s = sm;
   float* hs = sm + (long)P * ET;  // [16][P+1]: h on the way in, dh on the way out
-  for (int i = threadIdx.x; i < P * ET; i += RT_THREADS) {
-    const int p = i / ET, e = i - p * ET;
-    s_s[i] = e < E ? snorm[p * E + e] : 0.f;
-  }
+  const bool linear = snorm == nullptr;
+  if (!linear)
+    for (int i = threadIdx.x; i < P * ET; i += RT_THREADS) {
+      const int p = i / ET, e = i - p * ET;
+      s_s[i] = e < E ? snorm[p * E + e] : 0.f;
+    }
   const int t0 = blockIdx.x * RT_TOKENS;
   load_h_tile(hcat, ldh, P, t0, T, hs);
   __syncthreads();
@@ -215,7 +226,7 @@ __global__ __launch_bounds__(RT_THREADS) void moe_router_bwd_kernel(
   const int t = t0 + tl;
   const bool tv = t < T;
   const int m = min(k + 1, E);
-  const float scale = *scale_p;
+  const float scale = linear ? 1.f : *scale_p;
   const bool smooth = train && (k < E);
   float ds_local = 0.f;
   float draw[ET];
@@ -296,7 +307,7 @@ __global__ __launch_bounds__(RT_THREADS) void moe_router_bwd_kernel(
           draw[e] = dsig[e] / (1.0f + __expf(-h[P + e]));  // d softplus = sigmoid
         }
       }
-    const float hn = hnorm_i[tt];
+    const float hn = linear ? 1.f : hnorm_i[tt];
     const float inv = 1.0f / fmaxf(hn, 1e-12f);
     float dsl = 0.f;
 #pragma unroll
@@ -310,6 +321,15 @@ __global__ __launch_bounds__(RT_THREADS) void moe_router_bwd_kernel(
     // lanes of the token split p
     float* hrow = hs + tl * (P + 1);
     float proj = 0.f;
+    if (linear) {  // d clean IS d h on the first E columns
+      for (int p = sub; p < P; p += LPT) {
+        float a = 0.f;
+#pragma unroll
+        for (int e = 0; e < ET; e++)
+          if (e == p) a = dclean[e];
+        hrow[p] = a;
+      }
+    } else {
     for (int p = sub; p < P; p += LPT) {
       const float* srow = s_s + p * ET;
       float a = 0.f;
@@ -325,6 +345,7 @@ __global__ __launch_bounds__(RT_THREADS) void moe_router_bwd_kernel(
 #pragma unroll
       for (int e = 0; e < ET; e++) a += srow[e] * dclean[e];
       hrow[p] = (a * scale - hrow[p] * inv * proj) * inv;
+    }
     }
   }
   __syncthreads();
@@ -359,8 +380,9 @@ int sm3_moe_router_partial_rows(int T) { return (T + RT_TOKENS - 1) / RT_TOKENS;
 int sm3_moe_router_fwd(const float* hcat, int ldh, int P, const float* snorm, const float* scale, const float* noise,
                        int T, int E, int k, int train, int32_t* top_idx, float* top_val, float* gates, float* clean,
                        float* sigma, float* hnorm, float* partials, sm3_stream_t stream) {
-  if (!hcat || !snorm || !scale || !top_idx || !top_val || !gates || !clean || !hnorm || !partials)
+  if (!hcat || (snorm && !scale) || !top_idx || !top_val || !gates || !clean || !hnorm || !partials)
     return SM3_ERR_INVALID_ARG;
+  if (!snorm && P < E) return SM3_ERR_INVALID_ARG;  // linear gate: the logits are the first E of the P columns
   if (T <= 0 || E < 1 || E > 32 || k < 1 || k > E || (P & 3) || P + E > ldh || (ldh & 3)) return SM3_ERR_INVALID_ARG;
   if (train && (!noise || !sigma)) return SM3_ERR_INVALID_ARG;
   const int nblk = sm3_moe_router_partial_rows(T);
@@ -381,9 +403,10 @@ int sm3_moe_router_bwd(const float* hcat, int ldh, int P, const float* snorm, co
                        const float* gates, const float* clean, const float* sigma, const float* hnorm,
                        const float* dgate, const float* dimp, const float* dload, float* dhcat, float* dcn,
                        float* ds_part, sm3_stream_t stream) {
-  if (!hcat || !snorm || !scale || !top_idx || !top_val || !gates || !clean || !hnorm || !dgate || !dimp || !dload ||
+  if (!hcat || (snorm && !scale) || !top_idx || !top_val || !gates || !clean || !hnorm || !dgate || !dimp || !dload ||
       !dhcat || !dcn || !ds_part)
     return SM3_ERR_INVALID_ARG;
+  if (!snorm && P < E) return SM3_ERR_INVALID_ARG;
   if (T <= 0 || E < 1 || E > 32 || k < 1 || k > E || (P & 3) || P + E > ldh || (ldh & 3)) return SM3_ERR_INVALID_ARG;
   if (train && (!noise || !sigma)) return SM3_ERR_INVALID_ARG;
   const int nblk = sm3_moe_router_partial_rows(T);

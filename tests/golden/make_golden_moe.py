@@ -26,6 +26,9 @@ CASES = {
     'moe_e4k2': dict(arch=dict(depths=[1, 1, 2, 1], channels=[32, 32, 64, 64]),
                      MoE_Block_inds=[[], [0], [0], [0]], num_experts=4, top_k=2, drop_path_rate=0.3,
                      input=(2, 3, 64, 64)),
+    'moe_lin_e4k2': dict(arch=dict(depths=[1, 1, 2, 1], channels=[32, 32, 64, 64]), gate='linear',
+                         MoE_Block_inds=[[], [0], [1], [0]], num_experts=4, top_k=2, drop_path_rate=0.2,
+                         input=(2, 3, 64, 64)),
     'moe_e8k3': dict(arch=dict(depths=[1, 2, 1, 1], channels=[32, 32, 32, 64]),
                      MoE_Block_inds=[[], [1], [0], []], num_experts=8, top_k=3, drop_path_rate=0.2,
                      input=(1, 3, 96, 64)),
@@ -47,6 +50,8 @@ def randomise(net, g):
             if n.endswith('gamma'):
                 p.copy_(torch.empty_like(p).uniform_(0.5, 1.5, generator=g))
             elif 'w_noise' in n:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.5)
+            elif n.endswith('w_gate'):  # gate='linear': (C, E) parameter, zeros by default
                 p.copy_(torch.randn(p.shape, generator=g) * 0.5)
             elif 'sim_matrix' in n:
                 p.copy_(torch.randn(p.shape, generator=g))
@@ -128,4 +133,6 @@ def make(name, cfg):
 if __name__ == '__main__':
     assert ref_moe.available(), 'needs /root/reference'
     for n, c in CASES.items():
+        if len(sys.argv) > 1 and n not in sys.argv[1:]:
+            continue
         make(n, c)

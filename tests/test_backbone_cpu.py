@@ -60,9 +60,13 @@ def test_pretrained_key_remap_clones_dense_ffn_into_experts():
 def test_unsupported_options_raise():
     from sm3det_amd.convnext_moe import ConvNeXt_moe
     with pytest.raises(NotImplementedError):
-        ConvNeXt_moe(arch='tiny', gate='linear', MoE_Block_inds=[[], [0], [], []])
+        ConvNeXt_moe(arch='tiny', gate='softmax', MoE_Block_inds=[[], [0], [], []])  # the reference knows cosine | linear
     with pytest.raises(NotImplementedError):
         ConvNeXt_moe(arch='tiny', use_grn=True)
+    # gate='linear' constructs with the reference's parameter: w_gate (C, E) zeros instead of the CosineTopKGate module
+    net = ConvNeXt_moe(arch='tiny', gate='linear', MoE_Block_inds=[[], [0], [], []], num_experts=4)
+    sd = net.state_dict()
+    assert sd['stages.1.0.ffn.w_gate'].shape == (192, 4) and 'stages.1.0.ffn.w_gate.temperature' not in sd
 
 
 def test_collect_by_source_matches_reference_gather_logic():

@@ -44,7 +44,7 @@ def _ref_key_grads(net):
     return out
 
 
-@pytest.mark.parametrize('name', ['moe_e4k2', 'moe_e8k3'])
+@pytest.mark.parametrize('name', ['moe_e4k2', 'moe_e8k3', 'moe_lin_e4k2'])
 def test_eval_forward_matches_reference_fixture(name):
     fx = load_fixture(name)
     net = _build(fx['cfg'], fx['state_dict']).eval()
@@ -57,7 +57,7 @@ def test_eval_forward_matches_reference_fixture(name):
     assert rel_err(gl, fx['eval']['gate_loss']) < FWD_TOL
 
 
-@pytest.mark.parametrize('name', ['moe_e4k2', 'moe_e8k3'])
+@pytest.mark.parametrize('name', ['moe_e4k2', 'moe_e8k3', 'moe_lin_e4k2'])
 def test_train_forward_backward_matches_reference_fixture(name):
     fx = load_fixture(name)
     net = _build(fx['cfg'], fx['state_dict']).train()

@@ -10,7 +10,7 @@ from oracle import ref_moe
 from tests.moe_common import load_fixture, loss_of, oracle_kwargs, rel_err
 
 
-@pytest.mark.parametrize('name', ['moe_e4k2', 'moe_e8k3'])
+@pytest.mark.parametrize('name', ['moe_e4k2', 'moe_e8k3', 'moe_lin_e4k2'])
 def test_oracle_eval_matches_reference_fixture(name):
     fx = load_fixture(name)
     with torch.no_grad():
@@ -20,7 +20,7 @@ def test_oracle_eval_matches_reference_fixture(name):
     assert rel_err(gl, fx['eval']['gate_loss']) < 1e-5
 
 
-@pytest.mark.parametrize('name', ['moe_e4k2', 'moe_e8k3'])
+@pytest.mark.parametrize('name', ['moe_e4k2', 'moe_e8k3', 'moe_lin_e4k2'])
 def test_oracle_train_fwd_bwd_matches_reference_fixture(name):
     fx = load_fixture(name)
     p = {k: v.clone().requires_grad_(v.is_floating_point() and not k.endswith(('.mean', '.std')))
