@@ -16,43 +16,49 @@ class PinnedUploader:
             raise RuntimeError('PinnedUploader needs the GPU runtime (pinned host memory); there is no CPU fallback')
         self.device = torch.device(device)
         self.stream = torch.cuda.Stream(device=self.device)
-        self._staging = {}   # (tag, shape, dtype) -> [pinned tensor, event of its last upload]
+        self._staging = {}   # (tag, dtype) -> [flat pinned buffer (grow-only), event of its last upload]
 
     def _stage(self, tag, shape, dtype):
-        key = (tag, tuple(shape), dtype)
+        """A pinned view of `shape` out of ONE grow-only flat buffer per (tag, dtype): variable-length entries
+        (``ignore_tensor=True``: per-sample gt boxes / labels of any count) reuse it instead of page-locking a fresh
+        buffer for every distinct shape."""
+        key = (tag, dtype)
+        numel = 1
+        for d in shape:
+            numel *= int(d)
         slot = self._staging.get(key)
-        if slot is None:
-            slot = [torch.empty(shape, dtype=dtype, pin_memory=True), None]
-            self._staging[key] = slot
-        elif slot[1] is not None:
+        if slot is not None and slot[1] is not None:
             slot[1].synchronize()  # the previous upload out of this buffer must have left the host memory
-        return slot
+        if slot is None or slot[0].numel() < numel:
+            slot = [torch.empty(max(numel, 1), dtype=dtype, pin_memory=True), None]
+            self._staging[key] = slot
+        return [slot[0][:numel].view(tuple(shape)), slot]
 
     def upload(self, tensors, tag='', stack=True):
         """list of equally-shaped CPU tensors -> one stacked GPU tensor (stack=True) or a list of GPU tensors."""
+        if any(t.is_cuda for t in tensors):  # already on the device (the reference's .cuda() accepts both): pass through
+            ts = [t.to(self.device) for t in tensors]
+            return torch.stack(ts) if stack else ts
         if stack:
             first = tensors[0]
-            slot = self._stage(tag, (len(tensors),) + tuple(first.shape), first.dtype)
-            torch.stack(list(tensors), out=slot[0])
-            with torch.cuda.stream(self.stream):
-                dev = slot[0].to(self.device, non_blocking=True)
-                slot[1] = torch.cuda.Event()
-                slot[1].record(self.stream)
-            torch.cuda.current_stream(self.device).wait_event(slot[1])
-            dev.record_stream(torch.cuda.current_stream(self.device))
-            return dev
+            view, slot = self._stage(tag, (len(tensors),) + tuple(first.shape), first.dtype)
+            torch.stack(list(tensors), out=view)
+            return self._send(view, slot)
         out = []
         for i, t in enumerate(tensors):
-            slot = self._stage(f'{tag}/{i}', tuple(t.shape), t.dtype)
-            slot[0].copy_(t)
-            with torch.cuda.stream(self.stream):
-                dev = slot[0].to(self.device, non_blocking=True)
-                slot[1] = torch.cuda.Event()
-                slot[1].record(self.stream)
-            torch.cuda.current_stream(self.device).wait_event(slot[1])
-            dev.record_stream(torch.cuda.current_stream(self.device))
-            out.append(dev)
+            view, slot = self._stage(f'{tag}/{i}', tuple(t.shape), t.dtype)
+            view.copy_(t)
+            out.append(self._send(view, slot))
         return out
+
+    def _send(self, view, slot):
+        with torch.cuda.stream(self.stream):
+            dev = view.to(self.device, non_blocking=True)
+            slot[1] = torch.cuda.Event()
+            slot[1].record(self.stream)
+        torch.cuda.current_stream(self.device).wait_event(slot[1])
+        dev.record_stream(torch.cuda.current_stream(self.device))
+        return dev
 
 
 def collect_by_source(data, train_datasets):

@@ -101,8 +101,10 @@ def nms_fixed(boxes, scores, iou_threshold, offset):
 def nms_rotated(dets, scores, order, dets_sorted, iou_threshold, multi_label):
     """pybind.cpp:311-313,749-751.  Follows the CPU path (pytorch/nms_rotated.cpp:31 ->
     cpu/nms_rotated.cpp:7-57): ``order``/``dets_sorted``/``multi_label`` are ignored, labels in a 6th column too;
-    suppression uses ``>=``.  ``order`` IS used as the precomputed permutation when it is a valid int64 tensor
-    (it equals what the CPU path recomputes on tie-free scores)."""
+    suppression uses ``>=`` -- NOTE: the reference's *CUDA* path (nms_rotated_cuda) uses ``>`` and the caller's ``order``;
+    keep sets therefore differ from a CUDA run of the reference for boxes at exactly the threshold (e.g. duplicates at
+    thr = 1.0) and for tied scores.  The CPU path is the oracle this tier is measured against (north_star: "outputs
+    matching the reference CPU path"), see tests/test_ops_gpu.py::test_nms_rotated_threshold_equality_follows_cpu_path."""
     require_gpu(dets, scores)
     n = dets.size(0)
     if n == 0:

@@ -8,6 +8,10 @@ mmcv/mmcv/runner/hooks/optimizer.py:55-73).  All tensors are updated by ONE kern
 every step cost nothing; step counter, gradient norm and clip coefficient stay on the device (no host sync, hipGraph
 capturable).
 
+Differences from ``clip_grad_norm_`` + ``AdamW`` worth knowing: the clip coefficient is applied INSIDE the update, so
+``p.grad`` keeps the unclipped (and, under a loss scale, still scaled) values after ``step()``; parameters without a
+gradient are skipped like torch does (the tables are rebuilt when that set changes, outside captures only).
+
 ``DynamicLrPolicy`` -- the scalar arithmetic of ``DynamicLrUpdaterHook.get_dynamic_lr``
 (mmrotate/core/hook/dynamic_lr.py:107-175; default ``head_policy='normal'``, ``backbone_policy`` min/avg/max) as a
 plain object: feed it the step's loss scalars, get one lr multiplier per parameter name.
@@ -83,6 +87,9 @@ class MultiTensorAdamW(torch.optim.Optimizer):
             self._scaler_cfg['init_scale'] = sd['scale']
 
     # ------------------------------------------------------------------------------------------- tables
+    def _grad_set(self):
+        return frozenset(id(p) for g in self.param_groups for p in g['params'] if p.grad is not None)
+
     def _build(self):
         ps = []
         for gi, g in enumerate(self.param_groups):
@@ -117,11 +124,15 @@ class MultiTensorAdamW(torch.optim.Optimizer):
         self._total_numel = sum(p.numel() for _, p in ps)
         self._lr = torch.empty(len(ps), dtype=torch.float32, device=dev)
         self._wd = torch.empty(len(ps), dtype=torch.float32, device=dev)
-        self._step = torch.zeros(1, dtype=torch.float32, device=dev)
+        if not hasattr(self, '_step'):  # a rebuild keeps the step counter
+            self._step = torch.zeros(1, dtype=torch.float32, device=dev)
         self._coef = torch.ones(1, dtype=torch.float32, device=dev)
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
         self._partials = torch.empty(self._n_chunks, dtype=torch.float32, device=dev)
         self._built = True
+        self._built_set = self._grad_set()
+        self._hyper_pin = torch.empty(2, len(ps), dtype=torch.float32, pin_memory=True)  # persistent staging: a
+        # non_blocking H2D copy out of a temporary pageable tensor may read freed memory
         self.update_hyperparams(force=True)
 
     def refresh_grad_pointers(self):
@@ -130,9 +141,13 @@ class MultiTensorAdamW(torch.optim.Optimizer):
         a graph that contains ``step()`` so the graph reads the gradients where the captured backward writes them."""
         if not self._built:
             return
-        if any(p.grad is None for _, p in self._params):
-            raise _lib.SM3Error('MultiTensorAdamW: a parameter that had a gradient when the tables were built has '
-                                'none now')
+        if self._grad_set() != self._built_set:
+            # torch.optim.AdamW skips parameters without a gradient and picks them up when one appears: rebuild the
+            # tables for the current set (optimizer state is kept per parameter; never inside a capture)
+            if torch.cuda.is_current_stream_capturing():
+                raise _lib.SM3Error('MultiTensorAdamW: the set of parameters with gradients changed inside a capture')
+            self._build()
+            return
         addr = [p.grad.data_ptr() for _, p in self._params]
         if addr != self._g_addr:
             self._g_ptrs.copy_(torch.tensor(addr, dtype=torch.int64))
@@ -146,8 +161,11 @@ class MultiTensorAdamW(torch.optim.Optimizer):
         lr = [self.param_groups[gi]['lr'] for gi, _ in self._params]
         wd = [self.param_groups[gi]['weight_decay'] for gi, _ in self._params]
         if force or (lr, wd) != self._last_hyper:
-            self._lr.copy_(torch.tensor(lr, dtype=torch.float32), non_blocking=True)
-            self._wd.copy_(torch.tensor(wd, dtype=torch.float32), non_blocking=True)
+            torch.cuda.current_stream().synchronize() if self._last_hyper is not None else None  # staging reuse
+            self._hyper_pin[0].copy_(torch.tensor(lr, dtype=torch.float32))
+            self._hyper_pin[1].copy_(torch.tensor(wd, dtype=torch.float32))
+            self._lr.copy_(self._hyper_pin[0], non_blocking=True)
+            self._wd.copy_(self._hyper_pin[1], non_blocking=True)
             self._last_hyper = (lr, wd)
 
     @torch.no_grad()

@@ -308,3 +308,21 @@ def test_box_iou_rotated_bench_shape_2000x64():
     got = ops.box_iou_rotated(dev(b1), dev(b2)).cpu().numpy()
     exp = O.box_iou_rotated(b1, b2, 0)
     assert np.abs(got - exp).max() <= 1e-6 and np.array_equal(got > 0, exp > 0)
+
+
+def test_nms_rotated_threshold_equality_follows_cpu_path():
+    """exact duplicates at iou_threshold = 1.0: the reference CPU op suppresses with `>=` (cpu/nms_rotated.cpp), its CUDA
+    op with `>`; this implementation follows the CPU path (documented in sm3det_amd/mmcv_ext.py)."""
+    ops, O = _ops(), _oracle()
+    d = np.array([[50, 50, 20, 10, 0.3], [50, 50, 20, 10, 0.3], [200, 200, 30, 30, 0.0], [200, 200, 30, 30, 0.0],
+                  [400, 100, 8, 40, -0.7]], np.float32)
+    s = np.array([0.9, 0.8, 0.7, 0.6, 0.5], np.float32)
+    _, keep = ops.nms_rotated(dev(d), dev(s), 1.0)
+    exp = O.nms_rotated(d, s, 1.0)
+    assert np.array_equal(keep.cpu().numpy(), exp)
+    # the axis-aligned duplicate has IoU exactly 1.0 and is suppressed by `>=` (a `>` rule would keep it); the rotated
+    # duplicate's IoU rounds just below 1.0 in fp32 and survives under either rule
+    assert keep.cpu().tolist() == [0, 1, 2, 4]
+    ref = _ref_or_none()
+    if ref is not None:
+        assert ref.nms_rotated_cpu(torch.from_numpy(d), torch.from_numpy(s), 1.0).tolist() == [0, 1, 2, 4]
