@@ -200,6 +200,11 @@ int sm3_upsample2x_add(const float* fine, const float* coarse, float* out, int B
 int sm3_sumpool2x_add(const float* dfine, const float* base, float* dcoarse, int B, int Hc, int Wc, int C,
                       sm3_stream_t stream);
 
+/* dst[b][c][r] = src[b][r][c] (batched 2-D transpose; NHWC <-> NCHW of a feature map with rows = H*W, cols = C).  Used
+ * where the mmcv._ext boundary hands NCHW tensors to a kernel whose scatter pattern wants NHWC (RoIAlignRotated
+ * backward: 4.1 ms on NCHW vs 0.41 ms on NHWC for 512 RoIs on a 256x256x256 level). */
+int sm3_transpose_f32(const float* src, float* dst, int batch, int rows, int cols, sm3_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * MaxIoU target assignment: mmdet MaxIoUAssigner.assign_wrt_overlaps as configured by
  * local_configs/main_SM3Det.py:165-196 (rpn: BboxOverlaps2D on (x1,y1,x2,y2) anchors; rcnn: RBboxOverlaps2D =

@@ -120,7 +120,7 @@ def _p(t):
 
 _COUNTERS = {}
 COMPUTE = 0  # 0: fp32 operands; 1: fp16 operands / fp32 accumulation (set by sm3det_amd.amp.autocast)
-TUNING = 0  # benchmarking override forwarded to sm3_gemm_desc.tuning (scripts/gemm_sweep2.py); 0 in production
+TUNING = int(__import__('os').environ.get('SM3_GEMM_TUNING', '0'))  # benchmarking override forwarded to sm3_gemm_desc.tuning (scripts/gemm_sweep2.py); 0 in production
 
 
 def gemm_counters(device):

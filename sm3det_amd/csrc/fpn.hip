@@ -58,6 +58,28 @@ int grid_for(long total) {
   return nb < 1 ? 1 : (int)nb;
 }
 
+
+// Batched 2-D transpose dst[b][c][r] = src[b][r][c] through a 32x33 LDS tile (NHWC <-> NCHW of a feature map:
+// rows = H*W, cols = C or the other way round).  Both sides move full 128-byte row segments.
+__global__ __launch_bounds__(256) void transpose_f32_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                           int rows, int cols) {
+  __shared__ float tile[32][33];
+  const long base = (long)blockIdx.z * rows * cols;
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int r = r0 + ty + 8 * i, c = c0 + tx;
+    if (r < rows && c < cols) tile[ty + 8 * i][tx] = src[base + (long)r * cols + c];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int c = c0 + ty + 8 * i, r = r0 + tx;
+    if (r < rows && c < cols) dst[base + (long)c * rows + r] = tile[tx][ty + 8 * i];
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -79,6 +101,14 @@ int sm3_sumpool2x_add(const float* dfine, const float* base, float* dcoarse, int
   const long npix = (long)B * Hc * Wc;
   sumpool2x_add_kernel<<<grid_for(npix * (C / 4)), 256, 0, (hipStream_t)stream>>>(dfine, base, dcoarse, npix, Hc, Wc,
                                                                                    C / 4);
+  return launch_status();
+}
+
+int sm3_transpose_f32(const float* src, float* dst, int batch, int rows, int cols, sm3_stream_t stream) {
+  if (!src || !dst || batch <= 0 || rows <= 0 || cols <= 0 || batch > 65535) return SM3_ERR_INVALID_ARG;
+  dim3 grid((cols + 31) / 32, (rows + 31) / 32, batch);
+  if (grid.y > 65535) return SM3_ERR_UNSUPPORTED;
+  transpose_f32_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(src, dst, rows, cols);
   return launch_status();
 }
 

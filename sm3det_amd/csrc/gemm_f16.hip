@@ -7,42 +7,43 @@
 namespace sm3gemm {
 
 template <int MODE, int EPI, class TL>
-static void go16(const GemmParams& p, dim3 grid, hipStream_t st) {
-  gemm_f32_kernel<MODE, EPI, 32, TL, 0, 1><<<grid, NTHREADS, 0, st>>>(p);
+static void go16(const GemmParams& p, int bk, dim3 grid, hipStream_t st) {
+  if (bk == 16) gemm_f32_kernel<MODE, EPI, 16, TL, 0, 1><<<grid, NTHREADS, 0, st>>>(p);
+  else gemm_f32_kernel<MODE, EPI, 32, TL, 0, 1><<<grid, NTHREADS, 0, st>>>(p);
 }
 
 template <int MODE, int EPI>
-static int by_tile16(const GemmParams& p, int tile, dim3 grid, hipStream_t st) {
+static int by_tile16(const GemmParams& p, int tile, int bk, dim3 grid, hipStream_t st) {
   switch (tile) {
-    case 0: go16<MODE, EPI, T128x128>(p, grid, st); return SM3_OK;
-    case 1: go16<MODE, EPI, T128x96>(p, grid, st); return SM3_OK;
-    case 5: go16<MODE, EPI, T64x128>(p, grid, st); return SM3_OK;
+    case 0: go16<MODE, EPI, T128x128>(p, bk, grid, st); return SM3_OK;
+    case 1: go16<MODE, EPI, T128x96>(p, bk, grid, st); return SM3_OK;
+    case 5: go16<MODE, EPI, T64x128>(p, bk, grid, st); return SM3_OK;
   }
   return SM3_ERR_INVALID_ARG;
 }
 
-int launch_nt16(const GemmParams& p, int epi, int tile, dim3 grid, hipStream_t st) {
+int launch_nt16(const GemmParams& p, int epi, int tile, int bk, dim3 grid, hipStream_t st) {
   switch (epi) {
-    case EPI_NONE: return by_tile16<MODE_NT, EPI_NONE>(p, tile, grid, st);
-    case EPI_BIAS: return by_tile16<MODE_NT, EPI_BIAS>(p, tile, grid, st);
-    case EPI_BIAS_GELU: return by_tile16<MODE_NT, EPI_BIAS_GELU>(p, tile, grid, st);
-    case EPI_BIAS_SCALE_RES: return by_tile16<MODE_NT, EPI_BIAS_SCALE_RES>(p, tile, grid, st);
-    case EPI_BIAS_RELU: return by_tile16<MODE_NT, EPI_BIAS_RELU>(p, tile, grid, st);
+    case EPI_NONE: return by_tile16<MODE_NT, EPI_NONE>(p, tile, bk, grid, st);
+    case EPI_BIAS: return by_tile16<MODE_NT, EPI_BIAS>(p, tile, bk, grid, st);
+    case EPI_BIAS_GELU: return by_tile16<MODE_NT, EPI_BIAS_GELU>(p, tile, bk, grid, st);
+    case EPI_BIAS_SCALE_RES: return by_tile16<MODE_NT, EPI_BIAS_SCALE_RES>(p, tile, bk, grid, st);
+    case EPI_BIAS_RELU: return by_tile16<MODE_NT, EPI_BIAS_RELU>(p, tile, bk, grid, st);
   }
   return SM3_ERR_INVALID_ARG;
 }
 
-int launch_nn16(const GemmParams& p, int epi, int tile, dim3 grid, hipStream_t st) {
-  if (epi == EPI_NONE) return by_tile16<MODE_NN, EPI_NONE>(p, tile, grid, st);
-  if (epi == EPI_GELU_BWD) return by_tile16<MODE_NN, EPI_GELU_BWD>(p, tile, grid, st);
+int launch_nn16(const GemmParams& p, int epi, int tile, int bk, dim3 grid, hipStream_t st) {
+  if (epi == EPI_NONE) return by_tile16<MODE_NN, EPI_NONE>(p, tile, bk, grid, st);
+  if (epi == EPI_GELU_BWD) return by_tile16<MODE_NN, EPI_GELU_BWD>(p, tile, bk, grid, st);
   return SM3_ERR_INVALID_ARG;
 }
 
-int launch_tn16(const GemmParams& p, int tile, dim3 grid, hipStream_t st) {
+int launch_tn16(const GemmParams& p, int tile, int bk, dim3 grid, hipStream_t st) {
   switch (tile) {
-    case 0: go16<MODE_TN, EPI_NONE, T128x128>(p, grid, st); return SM3_OK;
-    case 1: go16<MODE_TN, EPI_NONE, T128x96>(p, grid, st); return SM3_OK;
-    case 2: go16<MODE_TN, EPI_NONE, T96x128>(p, grid, st); return SM3_OK;
+    case 0: go16<MODE_TN, EPI_NONE, T128x128>(p, bk, grid, st); return SM3_OK;
+    case 1: go16<MODE_TN, EPI_NONE, T128x96>(p, bk, grid, st); return SM3_OK;
+    case 2: go16<MODE_TN, EPI_NONE, T96x128>(p, bk, grid, st); return SM3_OK;
   }
   return SM3_ERR_INVALID_ARG;
 }

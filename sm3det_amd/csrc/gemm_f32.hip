@@ -232,8 +232,8 @@ Cfg choose_cfg(const sm3_gemm_desc* d) {
     if (c.tile == 3) c.bk = 16;
     if (t_bk) c.bk = t_bk == 1 ? 16 : 32;
     if (d->K % c.bk) c.bk = 16;
-    if (d->compute == 1) {  // fp16 operands: k-step 32, tiles 128x128 / 128x96 / 64x128
-      c.bk = 32;
+    if (d->compute == 1) {  // fp16 operands: tiles 128x128 / 128x96 / 64x128
+      c.bk = t_bk == 1 ? 16 : 32;
       if (c.tile != 0 && c.tile != 1 && c.tile != 5) c.tile = 0;
     }
     tile_dims(c.tile, c.bm, c.bn);
@@ -293,7 +293,7 @@ Cfg choose_cfg(const sm3_gemm_desc* d) {
   if (t_bk) c.bk = t_bk == 1 ? 16 : 32;
   if (c.tile >= 3) c.bk = 16;
   if (d->compute == 1) {
-    c.bk = 32;
+    c.bk = t_bk == 1 ? 16 : 32;
     if (c.tile > 2) c.tile = 0;
   }
   tile_dims(c.tile, c.bm, c.bn);
@@ -368,7 +368,7 @@ int sm3_gemm_f32(const sm3_gemm_desc* d, void* workspace, size_t workspace_bytes
       p.ldc = d->N;
     }
     dim3 grid(c.ntn * c.ntm, 1, c.groups * c.splits);
-    const int rc = d->compute == 1 ? launch_tn16(p, c.tile, grid, st) : launch_tn(p, c.tile, c.bk, 0, grid, st);
+    const int rc = d->compute == 1 ? launch_tn16(p, c.tile, c.bk, grid, st) : launch_tn(p, c.tile, c.bk, 0, grid, st);
     if (rc) return rc;
     if (c.splits > 1 && !c.fixup) {
       if (d->ldc != d->N) return SM3_ERR_UNSUPPORTED;
@@ -380,7 +380,8 @@ int sm3_gemm_f32(const sm3_gemm_desc* d, void* workspace, size_t workspace_bytes
   dim3 grid(c.ntn * c.ntm, 1, c.splits);
   int rc;
   if (d->compute == 1)
-    rc = d->mode == MODE_NT ? launch_nt16(p, d->epilogue, c.tile, grid, st) : launch_nn16(p, d->epilogue, c.tile, grid, st);
+    rc = d->mode == MODE_NT ? launch_nt16(p, d->epilogue, c.tile, c.bk, grid, st)
+                            : launch_nn16(p, d->epilogue, c.tile, c.bk, grid, st);
   else
     rc = d->mode == MODE_NT ? launch_nt(p, d->epilogue, c.tile, c.bk, 0, grid, st)
                             : launch_nn(p, d->epilogue, c.tile, c.bk, 0, grid, st);

