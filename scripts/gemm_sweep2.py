@@ -15,9 +15,9 @@ from sm3det_amd import _lib_backbone as LB  # noqa: E402
 E = 8
 
 
-def tune(tile=None, bk=None, splits=0, separate=False, staged=False):  # staged: historical A/B, now always on
+def tune(tile=None, bk=None, splits=0, separate=False, staged=False):  # staged: historical A/B (always on now)
     # bit 16 = TN in-kernel fix-up; `separate` (the default path) is the absence of it
-    return ((tile + 1) if tile is not None else 0) | ({None: 0, 16: 1, 32: 2}[bk] << 4) | (splits << 8) | (int(not separate) << 16) | (int(staged) << 17)
+    return ((tile + 1) if tile is not None else 0) | ({None: 0, 16: 1, 32: 2}[bk] << 4) | (splits << 8) | (int(not separate) << 16)
 
 
 # (mode, M, N, K, groups, epilogue, count per step)
@@ -50,6 +50,8 @@ SHAPES = [
 
 def candidates(mode, M, N, K, quick):
     out = [dict()]
+    if '--default-only' in sys.argv:
+        return out
     if '--staged' in sys.argv:  # A/B of the LDS-staged epilogue on the default configuration and its neighbours
         if mode == 'tn':
             return [dict(separate=True), dict(separate=True, staged=True)]
@@ -81,6 +83,8 @@ def main():
     for mode, M, N, K, G, epi, cnt in SHAPES:
         if '--tn-only' in sys.argv and mode != 'tn':
             continue
+        if '--aux-only' in sys.argv and epi not in (LB.EPI_BIAS_SCALE_RES, LB.EPI_GELU_BWD):
+            continue
         rows = K if mode == 'tn' else M
         offs = None
         if G > 1:  # mildly ragged expert loads
@@ -110,6 +114,8 @@ def main():
             kw.update(epilogue=epi, bias=bias)
         md = dict(nt=LB.NT, nn=LB.NN, tn=LB.TN)[mode]
         cands = candidates(mode, M, N, K, quick)
+        if not cands:
+            continue
         best_t = [float('inf')] * len(cands)
         errs = {}
         for rnd in range(2):  # two interleaved rounds, keep the minimum: clock / cache drift hits all candidates alike

@@ -378,6 +378,7 @@ class _MoEBlock(Function):
                               noise, sim, temp, tot)
         ctx.meta = (B, H, W, P, k, train, float(clamp_max), float(loss_coef))
         ctx.mark_non_differentiable(tot, offsets, top_idx)
+        ctx.set_materialize_grads(False)  # else autograd fills a zero tensor per non-differentiable output per block
         return out, loss.reshape(()), tot, offsets, top_idx
 
     @staticmethod
@@ -395,7 +396,7 @@ class _MoEBlock(Function):
         E, Hd = w1.shape[0], w1.shape[1]
         PC = wcat.shape[0]
         S = T * k
-        dout = dout.contiguous()
+        dout = x.new_zeros(T, C) if dout is None else dout.contiguous()
         # aux loss backward -> dimp | dload
         dimp_load = _e(2 * E, like=x)
         if dloss is None:

@@ -74,26 +74,42 @@ __device__ __forceinline__ void block_colsum_store(f32x4 (&acc)[NSETS][NV], floa
     partials[(long)blockIdx.x * NSETS * C + i] = t;
   }
 }
-// out[c] = sum_b partials[b][c]; block = 64 columns x 4 row lanes, rows strided by 4 with 4 independent loads in flight
-__global__ __launch_bounds__(256) void partials_reduce_kernel(const float* __restrict__ partials, int nblocks,
-                                                             int ncols, float* __restrict__ out) {
-  __shared__ float red[4][64];
-  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+// out[c] = sum_b partials[b][c]; block = 16 column quads (64 columns, 16 B per lane) x 64 row lanes, 8 independent
+// loads in flight per thread: <= 512 partial rows are ONE round trip.  The partials were just written by another kernel
+// (cold in this XCD's L2, ~2 us per dependent trip inside the step): one lane per column walking them four at a time
+// cost 11-15 us per call, 44 calls per training step.
+constexpr int PR_THREADS = 1024;
+__global__ __launch_bounds__(PR_THREADS) void partials_reduce_kernel(const float* __restrict__ partials, int nblocks,
+                                                                    int ncols, float* __restrict__ out) {
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  __shared__ v4 red[64][17];
+  const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 64 + 4 * cq;  // ncols is a multiple of 4 (C is)
+  v4 s[8];
+#pragma unroll
+  for (int u = 0; u < 8; u++) s[u] = v4{0.f, 0.f, 0.f, 0.f};
   if (c < ncols) {
-    int b = rl;
-    for (; b + 12 < nblocks; b += 16) {
-      s0 += partials[(long)b * ncols + c];
-      s1 += partials[(long)(b + 4) * ncols + c];
-      s2 += partials[(long)(b + 8) * ncols + c];
-      s3 += partials[(long)(b + 12) * ncols + c];
+    for (int b = rl; b < nblocks; b += 512) {
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int r = b + 64 * u;
+        const v4 v = *reinterpret_cast<const v4*>(partials + (long)min(r, nblocks - 1) * ncols + c);
+        if (r < nblocks) s[u] += v;  // clamped address + select: the batch of loads stays in flight
+      }
     }
-    for (; b < nblocks; b += 4) s0 += partials[(long)b * ncols + c];
   }
-  red[rl][cl] = (s0 + s1) + (s2 + s3);
+  red[rl][cq] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
   __syncthreads();
-  if (rl == 0 && c < ncols) out[c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+  if (threadIdx.x < 256) {  // 4 partial sums of 16 row lanes per column, then 4 -> 1 through a shuffle
+    const int col = threadIdx.x >> 2, part = threadIdx.x & 3;
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; i++) t += red[16 * part + i][col >> 2][col & 3];
+    t += __shfl_xor(t, 1, 64);
+    t += __shfl_xor(t, 2, 64);
+    const int oc = blockIdx.x * 64 + col;
+    if (part == 0 && oc < ncols) out[oc] = t;
+  }
 }
 
 // ============================================================================================== LayerNorm rows
@@ -420,15 +436,26 @@ __global__ __launch_bounds__(PLAN_TB) void moe_hist_kernel(const int32_t* __rest
   __syncthreads();
   for (int i = threadIdx.x; i < E; i += blockDim.x) counts[(long)blockIdx.x * E + i] = s_cnt[i];
 }
-// counts (nblk,E) -> base (nblk,E) exclusive over blocks + expert offsets; offsets (E+1)
-__global__ void moe_scan_kernel(const int32_t* __restrict__ counts, int nblk, int E, int32_t* __restrict__ base,
-                                int32_t* __restrict__ offsets) {
+// counts (nblk,E) -> base (nblk,E) exclusive over blocks + expert offsets; offsets (E+1).  One wave per expert (waves
+// stride over the experts): every lane owns a contiguous chunk of the histogram rows, the chunks meet in a wave scan
+// (one lane per expert walking all rows twice was ~10 us of dependent loads per MoE block).
+__device__ __forceinline__ int scan_chunk_sum(const int32_t* __restrict__ counts, int E, int e, int b0, int b1) {
+  int s = 0;
+  for (int b = b0; b < b1; b++) s += counts[(long)b * E + e];
+  return s;
+}
+__global__ __launch_bounds__(1024) void moe_scan_kernel(const int32_t* __restrict__ counts, int nblk, int E,
+                                                       int32_t* __restrict__ base, int32_t* __restrict__ offsets) {
   extern __shared__ int s_tot[];  // E+1
-  const int e = threadIdx.x;
-  int tot = 0;
-  if (e < E)
-    for (int b = 0; b < nblk; b++) tot += counts[(long)b * E + e];
-  if (e < E) s_tot[e] = tot;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int per = (nblk + 63) / 64;
+  const int b0 = min(nblk, lane * per), b1 = min(nblk, b0 + per);
+  for (int e = wave; e < E; e += nw) {
+    int t = scan_chunk_sum(counts, E, e, b0, b1);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+    if (lane == 0) s_tot[e] = t;
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
     int run = 0;
@@ -441,9 +468,16 @@ __global__ void moe_scan_kernel(const int32_t* __restrict__ counts, int nblk, in
     offsets[E] = run;
   }
   __syncthreads();
-  if (e < E) {
-    int run = s_tot[e];
-    for (int b = 0; b < nblk; b++) {
+  for (int e = wave; e < E; e += nw) {
+    const int mine = scan_chunk_sum(counts, E, e, b0, b1);
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += v;
+    }
+    int run = s_tot[e] + incl - mine;
+    for (int b = b0; b < b1; b++) {
       base[(long)b * E + e] = run;
       run += counts[(long)b * E + e];
     }
@@ -654,8 +688,8 @@ int sm3_row_partial_blocks(long T, int C) {
 }
 
 int sm3_row_partials_reduce(const float* partials, int nblocks, int ncols, float* out, sm3_stream_t stream) {
-  if (!partials || !out || nblocks <= 0 || ncols <= 0) return SM3_ERR_INVALID_ARG;
-  partials_reduce_kernel<<<(ncols + 63) / 64, 256, 0, (hipStream_t)stream>>>(partials, nblocks, ncols, out);
+  if (!partials || !out || nblocks <= 0 || ncols <= 0 || (ncols & 3)) return SM3_ERR_INVALID_ARG;  // 16-byte column quads
+  partials_reduce_kernel<<<(ncols + 63) / 64, PR_THREADS, 0, (hipStream_t)stream>>>(partials, nblocks, ncols, out);
   return launch_status();
 }
 
@@ -676,7 +710,7 @@ int sm3_layernorm_bwd(const float* dy, const float* x, const float* w, const flo
   layernorm_bwd_kernel<G, NV><<<nb, 256, lds, st>>>(dy, x, w, mean, rstd, dx, part, T, C, out_mode, H, W, accumulate_dx)
   SM3_ROW_DISPATCH(C, CALL);
 #undef CALL
-  if (dwdb) partials_reduce_kernel<<<(2 * C + 63) / 64, 256, 0, st>>>(part, nb, 2 * C, dwdb);
+  if (dwdb) partials_reduce_kernel<<<(2 * C + 63) / 64, PR_THREADS, 0, st>>>(part, nb, 2 * C, dwdb);
   return launch_status();
 }
 
@@ -736,7 +770,7 @@ int sm3_scale_bwd_prep(const float* dout, const float* y, const float* gamma, co
   scale_bwd_prep_kernel<G, NV><<<nb, 256, lds, st>>>(dout, y, gamma, rowscale, rows_per_scale, dy, part, T, C)
   SM3_ROW_DISPATCH(C, CALL);
 #undef CALL
-  if (dgamma_db) partials_reduce_kernel<<<(2 * C + 63) / 64, 256, 0, st>>>(part, nb, 2 * C, dgamma_db);
+  if (dgamma_db) partials_reduce_kernel<<<(2 * C + 63) / 64, PR_THREADS, 0, st>>>(part, nb, 2 * C, dgamma_db);
   return launch_status();
 }
 
@@ -755,7 +789,7 @@ int sm3_moe_plan(const int32_t* top_idx, int m, int T, int E, int k, int32_t* of
   int32_t* base = counts + (size_t)nblk * E;
   hipStream_t st = (hipStream_t)stream;
   moe_hist_kernel<<<nblk, PLAN_TB, E * sizeof(int), st>>>(top_idx, m, T, E, k, counts);
-  const int sthreads = ((E + 63) / 64) * 64;
+  const int sthreads = 64 * (E < 16 ? E : 16);
   moe_scan_kernel<<<1, sthreads, (E + 1) * sizeof(int), st>>>(counts, nblk, E, base, offsets);
   moe_rank_kernel<<<nblk, PLAN_TB, 0, st>>>(top_idx, m, T, E, k, base, slot_token, token_slot);
   return launch_status();
@@ -798,7 +832,7 @@ int sm3_moe_combine_bwd(const float* dout, const float* yslot, const int32_t* to
                                                       dyslot, dgate, part, T, C, k)
   SM3_ROW_DISPATCH(C, CALL);
 #undef CALL
-  if (dgamma) partials_reduce_kernel<<<(C + 63) / 64, 256, 0, st>>>(part, nb, C, dgamma);
+  if (dgamma) partials_reduce_kernel<<<(C + 63) / 64, PR_THREADS, 0, st>>>(part, nb, C, dgamma);
   return launch_status();
 }
 

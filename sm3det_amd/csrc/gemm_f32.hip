@@ -53,14 +53,16 @@ int launch_nt(const GemmParams& p, int epi, int tile, int bk, int gather, dim3 g
 namespace {
 
 // colpart [row tiles][N] -> out[g][n]: sum the row tiles that belong to group g (same tile->group map as the GEMM, whose
-// row tile height is `bm`).  block = 64 columns x 4 tile lanes
-__global__ __launch_bounds__(256) void tile_colsum_reduce_kernel(const float* __restrict__ colpart, int N, int M, int bm,
-                                                                const int32_t* __restrict__ offsets,
-                                                                int num_groups, float* __restrict__ out) {
-  __shared__ float red[4][64];
+// row tile height is `bm`).  block = 16 column quads (64 columns) x 64 tile lanes, 8 independent 16-byte loads in flight
+// per thread: 512 row tiles per round trip (1024 exist at stage 0; four lanes walking them two at a time took 128 trips)
+constexpr int TCR_THREADS = 1024;
+__global__ __launch_bounds__(TCR_THREADS) void tile_colsum_reduce_kernel(const float* __restrict__ colpart, int N, int M,
+                                                                        int bm, const int32_t* __restrict__ offsets,
+                                                                        int num_groups, float* __restrict__ out) {
+  __shared__ f32x4 red[64][17];
   const int g = blockIdx.y;
-  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int n = blockIdx.x * 64 + cl;
+  const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int n = blockIdx.x * 64 + 4 * cq;  // N is a multiple of 4
   int t0 = 0, t1 = (M + bm - 1) / bm;
   if (offsets) {
     int base = 0;
@@ -68,18 +70,31 @@ __global__ __launch_bounds__(256) void tile_colsum_reduce_kernel(const float* __
     t0 = base;
     t1 = base + (offsets[g + 1] - offsets[g] + bm - 1) / bm;
   }
-  float s0 = 0.f, s1 = 0.f;
-  if (n < N) {
-    int t = t0 + rl;
-    for (; t + 4 < t1; t += 8) {
-      s0 += colpart[(long)t * N + n];
-      s1 += colpart[(long)(t + 4) * N + n];
+  f32x4 s[8];
+#pragma unroll
+  for (int u = 0; u < 8; u++) s[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (n < N && t1 > t0) {
+    for (int t = t0 + rl; t < t1; t += 512) {
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int r = t + 64 * u;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(colpart + (long)min(r, t1 - 1) * N + n);
+        if (r < t1) s[u] += v;
+      }
     }
-    for (; t < t1; t += 4) s0 += colpart[(long)t * N + n];
   }
-  red[rl][cl] = s0 + s1;
+  red[rl][cq] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
   __syncthreads();
-  if (rl == 0 && n < N) out[(long)g * N + n] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+  if (threadIdx.x < 256) {
+    const int col = threadIdx.x >> 2, part = threadIdx.x & 3;
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; i++) t += red[16 * part + i][col >> 2][col & 3];
+    t += __shfl_xor(t, 1, 64);
+    t += __shfl_xor(t, 2, 64);
+    const int oc = blockIdx.x * 64 + col;
+    if (part == 0 && oc < N) out[(long)g * N + oc] = t;
+  }
 }
 
 // Sum the raw split-K slices of a GEMM: out[g][i] = sum_s ws[(g*splits+s)][i] (+ bias, relu).  A workgroup is
@@ -159,8 +174,18 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
   const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int c = blockIdx.x * 64 + 4 * cq;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
-  if (c < N)
-    for (int r = r0 + rl; r < r1; r += 16) s += *reinterpret_cast<const f32x4*>(X + (long)r * ld + c);
+  if (c < N) {
+    f32x4 s1 = s, s2 = s, s3 = s;  // four independent loads in flight per thread
+    int r = r0 + rl;
+    for (; r + 48 < r1; r += 64) {
+      s += *reinterpret_cast<const f32x4*>(X + (long)r * ld + c);
+      s1 += *reinterpret_cast<const f32x4*>(X + (long)(r + 16) * ld + c);
+      s2 += *reinterpret_cast<const f32x4*>(X + (long)(r + 32) * ld + c);
+      s3 += *reinterpret_cast<const f32x4*>(X + (long)(r + 48) * ld + c);
+    }
+    for (; r < r1; r += 16) s += *reinterpret_cast<const f32x4*>(X + (long)r * ld + c);
+    s = (s + s1) + (s2 + s3);
+  }
   __shared__ f32x4 red[16][16];
   red[rl][cq] = s;
   __syncthreads();
@@ -388,7 +413,7 @@ int sm3_gemm_f32(const sm3_gemm_desc* d, void* workspace, size_t workspace_bytes
   if (rc) return rc;
   if (cb) {
     dim3 rg((d->N + 63) / 64, c.groups);
-    tile_colsum_reduce_kernel<<<rg, 256, 0, st>>>(p.colpart, d->N, d->M, c.bm, d->group_offsets, c.groups,
+    tile_colsum_reduce_kernel<<<rg, TCR_THREADS, 0, st>>>(p.colpart, d->N, d->M, c.bm, d->group_offsets, c.groups,
                                                  d->colsum_out);
   }
   return launch_status();

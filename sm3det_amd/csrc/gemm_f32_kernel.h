@@ -582,6 +582,29 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
 #pragma unroll
     for (int j = 0; j < TJ; j++) cs[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
+  // The auxiliary input (gelu' / residual) runs two 32x32 tiles ahead of the tile being staged and stored (three rotating
+  // register buffers; the request for tile t + 2 goes out once tile t's accumulators have been written to LDS and their
+  // registers are free): otherwise every tile exposes one full HBM round trip -- the compiler cannot hoist the loads
+  // over the LDS hand-over.
+  constexpr bool AUX_IN = (EPI == EPI_GELU_BWD || EPI == EPI_BIAS_SCALE_RES);
+  constexpr int NT_ = TI * TJ;
+  constexpr int AUX_DEPTH = 1;  // tiles of look-ahead (2 spills at 128 VGPRs: measured slower)
+  f32x4 pre[AUX_DEPTH + 1][4];
+  auto aux_fetch = [&](int t, f32x4 (&dst)[4]) {
+    const int j = t / TI, i = t - j * TI;
+    const int col = n0 + wn0 + 32 * j + sc;
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+      const int row = m0 + wm0 + 32 * i + sr + 8 * it;
+      const bool ok = row < m_lim && col < p.N;
+      const long ai = ok ? (long)row * p.ld_aux + col : 0;
+      dst[it] = *reinterpret_cast<const f32x4*>(p.aux_in + ai);
+    }
+  };
+  if (AUX_IN) {
+    aux_fetch(0, pre[0]);
+    if (AUX_DEPTH > 1 && NT_ > 1) aux_fetch(1, pre[1]);
+  }
 #pragma unroll
   for (int j = 0; j < TJ; j++) {
     const int col = n0 + wn0 + 32 * j + sc;
@@ -591,11 +614,13 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
     if (EPI == EPI_BIAS_SCALE_RES && col_ok) gv = *reinterpret_cast<const f32x4*>(p.gamma + col);
 #pragma unroll
     for (int i = 0; i < TI; i++) {
+      const int t = j * TI + i;
 #pragma unroll
       for (int q = 0; q < 4; q++)
         *reinterpret_cast<f32x4*>(stg + l31 * 36 + 8 * q + 4 * lh) =
             f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
       asm volatile("" ::: "memory");
+      if (AUX_IN && t + AUX_DEPTH < NT_) aux_fetch(t + AUX_DEPTH, pre[(t + AUX_DEPTH) % (AUX_DEPTH + 1)]);
       f32x4 v[4];
 #pragma unroll
       for (int it = 0; it < 4; it++) v[it] = *reinterpret_cast<const f32x4*>(stg + (sr + 8 * it) * 36 + sc);
@@ -631,9 +656,9 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
           const f32x4 y = v[it] + bv;
           *reinterpret_cast<f32x4*>(p.aux_out + ai) = y;
           const float rsc = p.rowscale ? p.rowscale[row / p.rows_per_scale] : 1.f;
-          *reinterpret_cast<f32x4*>(cp) = *reinterpret_cast<const f32x4*>(p.aux_in + ai) + (gv * rsc) * y;
+          *reinterpret_cast<f32x4*>(cp) = pre[t % (AUX_DEPTH + 1)][it] + (gv * rsc) * y;
         } else if (EPI == EPI_GELU_BWD) {
-          const f32x4 o = v[it] * *reinterpret_cast<const f32x4*>(p.aux_in + ai);
+          const f32x4 o = v[it] * pre[t % (AUX_DEPTH + 1)][it];
           *reinterpret_cast<f32x4*>(cp) = o;
           cs[j] += o;
         }

@@ -152,9 +152,17 @@ __global__ __launch_bounds__(GP_THREADS) void aux_loss_fwd_kernel(const float* _
   const int ncol = 2 * E;
   const int col = threadIdx.x % ncol, grp = threadIdx.x / ncol, ngrp = GP_THREADS / ncol;
   float s = 0.f;
-  if (grp < ngrp)
-    for (int r = grp; r < nblk; r += ngrp) s += partials[(long)r * ncol + col];
-  if (grp < ngrp) sm[grp * ncol + col] = s;
+  if (grp < ngrp) {
+    float u[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // 8 independent loads in flight (one workgroup walks
+    int r = grp;                                             // up to 2048 partial rows: latency-bound otherwise)
+    for (; r + 7 * ngrp < nblk; r += 8 * ngrp) {
+#pragma unroll
+      for (int q = 0; q < 8; q++) u[q] += partials[(long)(r + q * ngrp) * ncol + col];
+    }
+    for (; r < nblk; r += ngrp) u[0] += partials[(long)r * ncol + col];
+    s = ((u[0] + u[1]) + (u[2] + u[3])) + ((u[4] + u[5]) + (u[6] + u[7]));
+    sm[grp * ncol + col] = s;
+  }
   __syncthreads();
   if (threadIdx.x < ncol) {
     float t = 0.f;
