@@ -11,7 +11,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libsm3det_hip.so')
+# SM3DET_HIP_LIB: A/B aid for kernel work (another build of the same ABI); never a fallback -- it must exist and resolve
+LIB_PATH = os.environ.get('SM3DET_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libsm3det_hip.so')
 
 c_void_p, c_int, c_float, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
 

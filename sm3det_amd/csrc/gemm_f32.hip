@@ -365,6 +365,13 @@ int sm3_gemm_f32(const sm3_gemm_desc* d, void* workspace, size_t workspace_bytes
   if (d->mode == MODE_TN && d->epilogue != EPI_NONE) return SM3_ERR_INVALID_ARG;
   if (d->mode != MODE_NT && d->mode != MODE_NN && d->mode != MODE_TN) return SM3_ERR_INVALID_ARG;
   if (d->compute != 0 && d->compute != 1) return SM3_ERR_INVALID_ARG;
+  {  // the kernel addresses each operand as block base + 32-bit byte offset (buffer loads): keep the spans below 2^31
+    const long lim = (1l << 31) - 65536;
+    const long ld = d->lda > d->ldb ? d->lda : d->ldb;
+    const long span = d->mode == MODE_TN ? (long)d->K * ld * 4
+                                         : ((long)256 * ld + d->K) * 4 + (d->mode == MODE_NN ? (long)d->K * d->ldb * 4 : 0);
+    if (span >= lim) return SM3_ERR_UNSUPPORTED;
+  }
   hipStream_t st = (hipStream_t)stream;
   const Cfg c = choose_cfg(d);
   const size_t sb = align_up(slab_bytes(d, c), 256), cb = colpart_bytes(d, c);

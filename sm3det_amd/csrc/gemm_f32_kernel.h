@@ -94,7 +94,9 @@ using T64x128 = Tile<2, 2, 1, 2>;
 // resident workgroups per CU the launch bounds ask for (VGPR budget 512 / waves-per-SIMD)
 template <class TL, int BK>
 constexpr int occupancy() {
-  return (TL::TI * TL::TJ >= 6 || BK == 32) ? 2 : 4;
+  // 128x128 at k-step 16 needs ~150 VGPRs to keep its LDS read bases out of the loop: 3 waves per SIMD without spills
+  // instead of 4 with scratch reloads and address arithmetic between the MFMAs
+  return (TL::TI * TL::TJ >= 6 || BK == 32) ? 2 : (TL::TI * TL::TJ == 4 ? 3 : 4);
 }
 
 // exact n / d for n * d < 2^32 with m = floor(2^32 / d) + 1 (d >= 2); d == 1 passes through
@@ -238,6 +240,15 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
     }
   }
 
+  // block-uniform by construction; readfirstlane makes it provable, so loop counters and k-offsets live in SGPRs (the
+  // TN kernel kept its trip count in a spilled VGPR and drained vmcnt(0) every iteration to reload it)
+  nk = __builtin_amdgcn_readfirstlane(nk);
+  kbase = __builtin_amdgcn_readfirstlane(kbase);
+  row0 = __builtin_amdgcn_readfirstlane(row0);
+  row_end = __builtin_amdgcn_readfirstlane(row_end);
+  m0 = __builtin_amdgcn_readfirstlane(m0);
+  g = __builtin_amdgcn_readfirstlane(g);
+
   // ---- loaders ----------------------------------------------------------------------------------------------
   // transposed loader (source rows k-contiguous): thread -> (row t_r + T_ROWS i, k quad t_kq)
   constexpr int KQ = BK / 4;
@@ -246,6 +257,9 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
   // direct loader (source k-major) of an operand with R columns: quad index tid + 256 i -> (k row, column quad)
   constexpr int PA = A_TRANS ? (BM + T_ROWS - 1) / T_ROWS : (BK * (BM / 4) + NTHREADS - 1) / NTHREADS;
   constexpr int PB = B_TRANS ? (BN + T_ROWS - 1) / T_ROWS : (BK * (BN / 4) + NTHREADS - 1) / NTHREADS;
+  // every thread owns an element of every piece (then the LDS stores need no exec mask: 3 scalar instructions each)
+  constexpr bool A_FULL = A_TRANS ? (BM % T_ROWS == 0) : ((BK * (BM / 4)) % NTHREADS == 0);
+  constexpr bool B_FULL = B_TRANS ? (BN % T_ROWS == 0) : ((BK * (BN / 4)) % NTHREADS == 0);
   constexpr int NP = PA + PB;  // pieces (one 16-byte load per thread each) per k-tile
   constexpr int KP = BK / 2;   // k-pairs = MFMA groups per k-tile
   static_assert(NP <= KP, "piece schedule: one load and one store slot per k-pair");
@@ -253,8 +267,17 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
   // Per-thread source pointers and LDS offsets, computed once.  Out-of-range rows / columns are CLAMPED to a valid
   // address instead of branched around (the garbage they bring only reaches output rows/columns the epilogue masks);
   // reduction rows past the segment end in TN are zeroed by a select after the load.
+  // Addresses: GATHER keeps one 64-bit pointer per piece; the plain GEMMs split every address into a block-uniform base
+  // (a buffer descriptor in SGPRs; the k-tile advance is the instruction's scalar offset) plus a per-thread 32-bit byte
+  // offset fixed for the whole k-loop, so a load is `buffer_load_dwordx4 v, v_off, s[rsrc], s_koff offen` with no vector
+  // arithmetic: VALU instructions issued from the k-loop take issue slots from the MFMAs of the same SIMD (measured:
+  // 46 extra v_cndmask per two k-steps cost 5-7 % on the long-K shapes; hipcc turns 64-bit per-thread pointers into
+  // one v_lshl_add_u64 per load).  All offsets from the block's base stay below 2^31 (checked on the host).
   const float* pa[PA];
   const float* pb[PB];
+  unsigned oa[PA], ob[PB];  // byte offsets from a_base / b_base
+  const char* a_base = nullptr;
+  const char* b_base = nullptr;
   int sa[PA], sb[PB];    // LDS offset of the piece (negative: this thread has no element in the piece)
   int ka[PA], kb[PB];    // direct loader: k row of the piece
   int gy[PA], gx[PA];    // GATHER (NT/NN): grid coordinates of this thread's A rows
@@ -275,6 +298,7 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
         pa[i] = Ag + (long)b * p.sH * p.sW * p.cC + 4 * t_kq;
       } else {
         pa[i] = Ag + (long)r * p.lda + 4 * t_kq + (long)kbase * BK;
+        oa[i] = (unsigned)(((long)(r - row0) * p.lda + 4 * t_kq) * 4);
       }
     } else {
       constexpr int QR = BM / 4;
@@ -283,8 +307,11 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
       ka[i] = kk;
       sa[i] = (kk < BK) ? kk * LDA_S + 4 * cq : -1;
       pa[i] = Ag + min(m0 + 4 * cq, p.M - 4);
+      oa[i] = (unsigned)(((long)min(kk, BK - 1) * p.lda + min(m0 + 4 * cq, p.M - 4)) * 4);  // kk >= BK: lane without an element
     }
   }
+  if (MODE == MODE_TN) a_base = reinterpret_cast<const char*>(Ag + (long)row0 * p.lda);
+  else a_base = reinterpret_cast<const char*>(Ag + (long)row0 * p.lda + (long)kbase * BK);
 #pragma unroll
   for (int i = 0; i < PB; i++) {
     kb[i] = 0;
@@ -293,6 +320,7 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
       sb[i] = (rl < BN) ? (4 * t_kq) * LDB_S + rl : -1;
       const int n = min(n0 + min(rl, BN - 1), p.N - 1);
       pb[i] = Bg + (long)n * p.ldb + 4 * t_kq + (long)kbase * BK;
+      ob[i] = (unsigned)(((long)(n - n0) * p.ldb + 4 * t_kq) * 4);
     } else {
       constexpr int QR = BN / 4;
       const int idx = tid + NTHREADS * i;
@@ -306,21 +334,58 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
           pb[i] = Bg + (nc - tn_tap * p.cC);  // channel offset inside the tap; the row part is added per load
         } else {
           pb[i] = Bg + nc;
+          ob[i] = (unsigned)(((long)min(kk, BK - 1) * p.ldb + nc) * 4);
         }
       } else {  // NN: B[K,N] rows are k
         pb[i] = Bg + (long)min(kk, BK - 1) * p.ldb + nc + (GATHER ? 0 : (long)kbase * BK * p.ldb);
+        ob[i] = (unsigned)(((long)min(kk, BK - 1) * p.ldb + nc) * 4);
       }
     }
   }
-  // piece q in [0, NP): q < PA -> A piece q, else B piece q - PA
-  auto load_piece = [&](f32x4 (&ra)[PA], f32x4 (&rb)[PB], int q, int kt) {
+  if (MODE == MODE_NT) b_base = reinterpret_cast<const char*>(Bg + (long)n0 * p.ldb + (long)kbase * BK);
+  else if (MODE == MODE_NN) b_base = reinterpret_cast<const char*>(Bg + (long)kbase * BK * p.ldb);
+  else b_base = reinterpret_cast<const char*>(Bg + (long)row0 * p.ldb);
+  // piece q in [0, NP): q < PA -> A piece q, else B piece q - PA.  tail == false (the bulk of the k-loop): tile kt is a
+  // complete tile strictly before the last one, so no clamp and no select is issued; tail == true: the last steps, where
+  // kt may be clamped and TN reduction rows past the segment end are zeroed.
+  auto make_rsrc = [](const char* base, long valid_floats) {
+    // readfirstlane: base and extent are block-uniform by construction, this makes them provably so (no waterfall
+    // loop).  The extent is the operand's valid span seen from the base: a stray offset reads 0 instead of faulting.
+    const unsigned long long u = reinterpret_cast<unsigned long long>(base);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    const long vb = valid_floats > 0 ? valid_floats * 4 : 0;
+    const int nrec = __builtin_amdgcn_readfirstlane((int)(vb < 0x7fffffffl ? vb : 0x7fffffffl));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, nrec,
+                                             0x00020000);
+  };
+  long a_valid, b_valid;
+  if (MODE == MODE_TN) {
+    a_valid = (long)(row_end - 1 - row0) * p.lda + p.M;
+    b_valid = (long)(row_end - 1 - row0) * p.ldb + p.N;
+    if (row_end <= row0) a_valid = b_valid = 0;
+  } else {
+    a_valid = (long)(row_end - 1 - row0) * p.lda + (p.K - (long)kbase * BK);
+    b_valid = MODE == MODE_NT ? (long)(p.N - 1 - n0) * p.ldb + (p.K - (long)kbase * BK)
+                              : (long)(p.K - (long)kbase * BK - 1) * p.ldb + p.N;
+  }
+  const __amdgpu_buffer_rsrc_t a_rsrc = make_rsrc(a_base, a_valid), b_rsrc = make_rsrc(b_base, b_valid);
+  auto ldg = [&](const __amdgpu_buffer_rsrc_t& rs, long soff, unsigned voff) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, (int)soff, 0);
+    return __builtin_bit_cast(f32x4, v);
+  };
+  auto load_piece = [&](f32x4 (&ra)[PA], f32x4 (&rb)[PB], int q, int kt, bool tail) {
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     if (q < PA) {
       if (MODE == MODE_TN) {
-        const int kr = row0 + kt * BK + ka[q];
-        const int krc = min(kr, row_end - 1);
-        f32x4 v = *reinterpret_cast<const f32x4*>(pa[q] + (long)krc * p.lda);
-        ra[q] = kr < row_end ? v : zero4;
+        if (!tail) {
+          ra[q] = ldg(a_rsrc, (long)kt * BK * p.lda * 4, oa[q]);
+        } else {
+          const int kr = row0 + kt * BK + ka[q];
+          const int krc = min(kr, row_end - 1);
+          f32x4 v = *reinterpret_cast<const f32x4*>(pa[q] + (long)krc * p.lda);
+          ra[q] = kr < row_end ? v : zero4;
+        }
       } else if (GATHER) {
         const int kg = kt + kbase;
         const int tap = (int)(((unsigned)kg * p.cInv) >> 16);  // k-tile -> tap (uniform), channel offset inside it
@@ -331,14 +396,14 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
         f32x4 v = *reinterpret_cast<const f32x4*>(pa[q] + off);
         ra[q] = (sy >= 0 && sx >= 0) ? v : zero4;
       } else {
-        ra[q] = *reinterpret_cast<const f32x4*>(pa[q] + kt * BK);
+        ra[q] = ldg(a_rsrc, (long)kt * BK * 4, oa[q]);
       }
     } else {
       const int i = q - PA;
       if (MODE == MODE_TN) {
-        const int kr = row0 + kt * BK + kb[i];
-        const int krc = min(kr, row_end - 1);
         if (GATHER) {
+          const int kr = row0 + kt * BK + kb[i];
+          const int krc = min(kr, row_end - 1);
           // reduction row = output position (b, oy, ox); B row = the input pixel this N-tile's tap reads for it
           const unsigned t = fast_div((unsigned)krc, (unsigned)p.rW, p.mRW);
           const int ox = krc - (int)t * p.rW;
@@ -350,12 +415,16 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
           const long off = (((long)b * p.sH + max(sy, 0)) * p.sW + max(sx, 0)) * p.cC;
           f32x4 v = *reinterpret_cast<const f32x4*>(pb[i] + off);
           rb[i] = ok ? v : zero4;
+        } else if (!tail) {
+          rb[i] = ldg(b_rsrc, (long)kt * BK * p.ldb * 4, ob[i]);
         } else {
+          const int kr = row0 + kt * BK + kb[i];
+          const int krc = min(kr, row_end - 1);
           f32x4 v = *reinterpret_cast<const f32x4*>(pb[i] + (long)krc * p.ldb);
           rb[i] = kr < row_end ? v : zero4;
         }
       } else if (MODE == MODE_NT) {
-        rb[i] = *reinterpret_cast<const f32x4*>(pb[i] + kt * BK);
+        rb[i] = ldg(b_rsrc, (long)kt * BK * 4, ob[i]);
       } else if (GATHER) {
         // NN gather (input gradient): B row k = (tap, co) lives at W[co][tap][:]  (ldb = 9 * Cin, + tap * N columns)
         const int kg = kt + kbase;
@@ -363,14 +432,21 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
         const int c0 = kg * BK - tap * p.cC;
         rb[i] = *reinterpret_cast<const f32x4*>(pb[i] + (long)c0 * p.ldb + tap * p.N);
       } else {
-        rb[i] = *reinterpret_cast<const f32x4*>(pb[i] + (long)kt * BK * p.ldb);
+        rb[i] = ldg(b_rsrc, (long)kt * BK * p.ldb * 4, ob[i]);
       }
     }
   };
-  auto store_piece = [&](const f32x4 (&ra)[PA], const f32x4 (&rb)[PB], int q, int buf) {
+  // live == false (uniform, tail steps only): the tile does not exist (index >= nk) and zeros are stored instead -- the
+  // k-loop runs an even number of steps without a branch between them, so the step after the last tile of an odd nk
+  // multiplies this all-zero stage
+  auto store_piece = [&](const f32x4 (&ra_)[PA], const f32x4 (&rb_)[PB], int q, int buf, bool live) {
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 ra[PA], rb[PB];
+    if (q < PA) ra[q] = live ? ra_[q] : z4;
+    else rb[q - PA] = live ? rb_[q - PA] : z4;
     if (q < PA) {
       float* a_s = As + buf * A_STAGE;
-      if (sa[q] >= 0) {
+      if (A_FULL || sa[q] >= 0) {
         if (A_TRANS) {
 #pragma unroll
           for (int j = 0; j < 4; j++) a_s[sa[q] + j * LDA_S] = ra[q][j];
@@ -381,7 +457,7 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
     } else {
       const int i = q - PA;
       float* b_s = Bs + buf * B_STAGE;
-      if (sb[i] >= 0) {
+      if (B_FULL || sb[i] >= 0) {
         if (B_TRANS) {
 #pragma unroll
           for (int j = 0; j < 4; j++) b_s[sb[i] + j * LDB_S] = rb[i][j];
@@ -407,20 +483,21 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
   f32x4 sa0[PA], sb0[PB], sa1[PA], sb1[PB];
   if (nk > 0) {
 #pragma unroll
-    for (int q = 0; q < NP; q++) load_piece(sa0, sb0, q, 0);
+    for (int q = 0; q < NP; q++) load_piece(sa0, sb0, q, 0, true);
 #pragma unroll
-    for (int q = 0; q < NP; q++) store_piece(sa0, sb0, q, 0);
+    for (int q = 0; q < NP; q++) store_piece(sa0, sb0, q, 0, true);
 #pragma unroll
-    for (int q = 0; q < NP; q++) load_piece(sa0, sb0, q, min(1, nk - 1));
+    for (int q = 0; q < NP; q++) load_piece(sa0, sb0, q, min(1, nk - 1), true);
   }
   __syncthreads();
 
-  auto k_step = [&](f32x4 (&ca)[PA], f32x4 (&cb)[PB], f32x4 (&na)[PA], f32x4 (&nb)[PB], int kt) {
+  auto k_step = [&](f32x4 (&ca)[PA], f32x4 (&cb)[PB], f32x4 (&na)[PA], f32x4 (&nb)[PB], int kt, bool tail) {
     // ca/cb hold tile kt+1 (to be stored), na/nb receive tile kt+2
     const int buf = kt & 1;
     // branch-free on purpose: a conditional around a load makes hipcc drain vmcnt(0) at the join, serialising the
-    // pipeline.  Past the end the last tile is simply re-loaded / re-stored into the idle buffer (never read).
-    const int kt_load = min(kt + 2, nk - 1);
+    // pipeline.  Past the end (tail steps) the last tile is simply re-loaded; a tile index >= nk is stored as zeros.
+    const int kt_load = tail ? min(kt + 2, nk - 1) : kt + 2;
+    const bool live = tail ? kt + 1 < nk : true;
     const float* a_s = As + buf * A_STAGE + wm0 + l31;
     const float* b_s = Bs + buf * B_STAGE + wn0 + l31;
     float a[TI], b[TJ];
@@ -442,8 +519,8 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
 #pragma unroll
         for (int j = 0; j < TJ; j++) xb[j] = b_s[krow * LDB_S + 32 * j];
       }
-      if (kk < NP) load_piece(na, nb, kk, kt_load);
-      if (kk >= KP - NP) store_piece(ca, cb, kk - (KP - NP), buf ^ 1);
+      if (kk < NP) load_piece(na, nb, kk, kt_load, tail);
+      if (kk >= KP - NP) store_piece(ca, cb, kk - (KP - NP), buf ^ 1, live);
       __builtin_amdgcn_sched_barrier(0);  // everything above is issued before this k-pair's MFMAs
       // operands swapped on purpose: D = (B fragment) x (A fragment) = the TRANSPOSED 32x32 tile, so that each lane
       // ends up with 4 consecutive output COLUMNS of one row -> 16-byte epilogue loads/stores
@@ -465,13 +542,14 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
   // loop is bound by the operand stream from L2/HBM, not by the matrix pipe.  Every tensor in HBM stays fp32 (master
   // weights, activations, gradients): no cast kernels, no fp16 copies.  A and B use the same (lane-half, element) -> k
   // assignment, so the sum over k is complete whatever order the hardware walks it in.
-  auto k_step16 = [&](f32x4 (&ca)[PA], f32x4 (&cb)[PB], f32x4 (&na)[PA], f32x4 (&nb)[PB], int kt) {
+  auto k_step16 = [&](f32x4 (&ca)[PA], f32x4 (&cb)[PB], f32x4 (&na)[PA], f32x4 (&nb)[PB], int kt, bool tail) {
     const int buf = kt & 1;
-    const int kt_load = min(kt + 2, nk - 1);
+    const int kt_load = tail ? min(kt + 2, nk - 1) : kt + 2;
+    const bool live = tail ? kt + 1 < nk : true;
     const float* a_s = As + buf * A_STAGE + wm0 + l31;
     const float* b_s = Bs + buf * B_STAGE + wn0 + l31;
 #pragma unroll
-    for (int q = 0; q < NP; q++) load_piece(na, nb, q, kt_load);
+    for (int q = 0; q < NP; q++) load_piece(na, nb, q, kt_load, tail);
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ks++) {
       f16x8 a[TI], b[TJ];
@@ -490,18 +568,32 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[j], a[i], acc[i][j], 0, 0, 0);
       if (ks == 0) {
 #pragma unroll
-        for (int q = 0; q < NP; q++) store_piece(ca, cb, q, buf ^ 1);
+        for (int q = 0; q < NP; q++) store_piece(ca, cb, q, buf ^ 1, live);
       }
     }
     __syncthreads();
   };
-  for (int kt = 0; kt < nk; kt += 2) {
+  // Two steps per iteration WITHOUT a branch between them (a conditional second step made hipcc drain vmcnt(0) at the
+  // loop header).  The bulk loop carries no clamp / select / zeroing at all; the last three or four steps run the
+  // `tail` variant, which also absorbs an odd nk by one extra step on an all-zero stage (see store_piece).
+  const int nk_bulk = max(0, nk - 3) & ~1;
+  int kt = 0;
+  for (; kt < nk_bulk; kt += 2) {
     if (F16) {
-      k_step16(sa0, sb0, sa1, sb1, kt);
-      if (kt + 1 < nk) k_step16(sa1, sb1, sa0, sb0, kt + 1);
+      k_step16(sa0, sb0, sa1, sb1, kt, false);
+      k_step16(sa1, sb1, sa0, sb0, kt + 1, false);
     } else {
-      k_step(sa0, sb0, sa1, sb1, kt);
-      if (kt + 1 < nk) k_step(sa1, sb1, sa0, sb0, kt + 1);
+      k_step(sa0, sb0, sa1, sb1, kt, false);
+      k_step(sa1, sb1, sa0, sb0, kt + 1, false);
+    }
+  }
+  for (; kt < nk; kt += 2) {
+    if (F16) {
+      k_step16(sa0, sb0, sa1, sb1, kt, true);
+      k_step16(sa1, sb1, sa0, sb0, kt + 1, true);
+    } else {
+      k_step(sa0, sb0, sa1, sb1, kt, true);
+      k_step(sa1, sb1, sa0, sb0, kt + 1, true);
     }
   }
 
