@@ -218,13 +218,15 @@ inline double quant_cost(long blocks) {
   return pc > 0 ? (double)rounds / pc : 1.0;
 }
 
-// Tile / k-step / split-K selection.  The rules are a small cost model fitted to scripts/gemm_sweep2.py on MI355X
-// (tile x k-step x slices over every GEMM shape of the ConvNeXt-T e8t2 training step; profiles/r02/gemm_sweep.txt):
-//  * NT/NN: candidates 128x128, 128x96, 64x128; cost = CU-round quantisation x padded-width waste x a penalty for
-//    leaving CUs with fewer than two workgroups x a small per-FLOP handicap of the smaller tiles.  K is sliced (with the
-//    in-kernel fix-up) only when fewer than 256 tiles exist and K is long.
-//  * TN: candidates 128x128, 128x96, 96x128 x slices 1..512 reduced by the second pass (never the in-kernel fix-up:
-//    on 64 KB slabs it measured slower); cost adds the slab round trip, 100*G/K of the GEMM's own time per slice.
+// Tile / k-step / split-K selection: a small cost model fitted to scripts/gemm_sweep2.py on MI355X (tile x k-step x slices
+// over every GEMM shape of the ConvNeXt-T e8t2 training step; profiles/r02/gemm_sweep_r02b.txt is the sweep of the
+// current kernel, refit: scripts/fit_gemm_nt.py, scripts/fit_gemm_tn.py):
+//  * NT/NN: (tile in 128x128, 128x96, 64x128) x (1..4 k-slices, only with < 256 tiles and a long K, in-kernel fix-up);
+//    cost = CU-round quantisation x padded-width waste x tile handicap x penalty for CUs with < 2 workgroups x 10 % per
+//    extra slice.  k-step 32 from K = 1024.
+//  * TN: (128x128, 128x96, 96x128) x slices 1..192 reduced by the second pass (never the in-kernel fix-up: on 64 KB slabs
+//    it measured slower); cost = quantisation x waste x handicap + the slab round trip, 60*G/K of the GEMM's own time per
+//    slice.  Since the k-loop lost its vector-ALU work the 96-wide tiles are as fast per FLOP as 128x128.
 // d->tuning (benchmarking aid, 0 in production): bits 0-3 tile+1, 4-7 k-step (1 = 16, 2 = 32), 8-15 slices,
 // bit 16: TN slices summed by the in-kernel fix-up instead of the second pass (so a literal 256 in the slices field
 // reads as `automatic + fix-up`: scripts/gemm_sweep2.py)
@@ -237,60 +239,65 @@ Cfg choose_cfg(const sm3_gemm_desc* d) {
   const bool have_counters = d->counters != nullptr;
   const int G = c.groups;
   if (d->mode != MODE_TN) {
+    // joint choice of (tile, k-slices): cost = CU-round quantisation x padded-width waste x tile handicap x a penalty for
+    // CUs left with fewer than two workgroups x 10 % per extra slice (fix-up traffic); refitted on
+    // profiles/r02/gemm_sweep_r02b.txt (regret 0.3 % of the summed NT/NN time of the training step)
     static const int cand[3] = {0, 1, 5};
-    static const double handicap[3] = {1.0, 1.02, 1.03};
+    static const double handicap[3] = {1.0, 1.04, 1.02};
+    int bk = d->K >= 1024 ? 32 : 16;
+    if (t_bk) bk = t_bk == 1 ? 16 : 32;
+    if (d->compute == 1) bk = t_bk == 1 ? 16 : 32;  // fp16 operands
+    if (d->K % bk) bk = 16;
+    const int kt = d->K / bk;
     double best = 0;
-    long best_tiles = 0;
+    int best_s = 1;
     c.tile = -1;
     for (int i = 0; i < 3; i++) {
+      if (t_tile >= 0 && t_tile != cand[i]) continue;
       int bm, bn;
       tile_dims(cand[i], bm, bn);
       const long tiles = (long)((d->M + bm - 1) / bm + (d->group_offsets ? G / 2 : 0)) * ((d->N + bn - 1) / bn);
+      const long slots = (long)((d->M + bm - 1) / bm + (d->group_offsets ? G : 0)) * ((d->N + bn - 1) / bn);
       const double waste = (double)pad_to(d->N, bn) / d->N;
-      const double pc = (double)tiles / kNumCU;
-      const double occ = pc < 1.0 ? 1.2 : (pc < 2.0 ? 1.0 + 0.2 * (2.0 - pc) : 1.0);
-      double cost = quant_cost(tiles) * handicap[i] * waste * occ;
-      if (c.tile < 0 || cost < best - 1e-9) { best = cost; c.tile = cand[i]; best_tiles = tiles; }
+      for (int s = 1; s <= 4; s++) {
+        if (s > 1 && (!have_counters || slots > COUNTER_SLOTS || d->splits == 1 || tiles >= kNumCU || kt < 24 ||
+                      kt / s < 6 || t_tile >= 0))
+          break;
+        const double pc = (double)tiles * s / kNumCU;
+        const double occ = pc < 1.0 ? 1.2 : (pc < 2.0 ? 1.0 + 0.05 * (2.0 - pc) : 1.0);
+        const double cost = quant_cost(tiles * s) * handicap[i] * waste * occ * (1.0 + 0.1 * (s - 1));
+        if (c.tile < 0 || cost < best - 1e-9) { best = cost; c.tile = cand[i]; best_s = s; }
+      }
     }
-    if (t_tile >= 0) c.tile = t_tile;
-    c.bk = (d->K >= 1024 || (c.tile == 1 && d->K >= 768)) ? 32 : 16;
+    if (c.tile < 0) { c.tile = t_tile >= 0 ? t_tile : 0; best_s = 1; }
+    c.bk = bk;
     if (c.tile == 3) c.bk = 16;
-    if (t_bk) c.bk = t_bk == 1 ? 16 : 32;
-    if (d->K % c.bk) c.bk = 16;
-    if (d->compute == 1) {  // fp16 operands: tiles 128x128 / 128x96 / 64x128
-      c.bk = t_bk == 1 ? 16 : 32;
-      if (c.tile != 0 && c.tile != 1 && c.tile != 5) c.tile = 0;
-    }
+    if (d->compute == 1 && c.tile != 0 && c.tile != 1 && c.tile != 5) c.tile = 0;  // fp16: 128x128 / 128x96 / 64x128
     tile_dims(c.tile, c.bm, c.bn);
     c.ntn = (d->N + c.bn - 1) / c.bn;
     // ragged groups: at most ceil(M/BM) + G row tiles exist; surplus blocks exit
     c.ntm = (d->M + c.bm - 1) / c.bm + (d->group_offsets ? G : 0);
-    const int kt = d->K / c.bk;
+    const int ktc = d->K / c.bk;
     const long tiles = (long)c.ntm * c.ntn;
     int s = 1;
     if (have_counters && tiles <= COUNTER_SLOTS) {
+      s = best_s;
       if (d->splits > 1) s = d->splits;
-      else if (d->splits <= 0 && best_tiles < kNumCU && kt >= 24 && t_tile < 0) {
-        double bc = 0;
-        for (int cs = 1; cs <= 4 && kt / cs >= 6; cs++) {
-          const double cost = quant_cost(best_tiles * cs) * (1.0 + 0.03 * (cs - 1));
-          if (cs == 1 || cost < bc - 1e-9) { bc = cost; s = cs; }
-        }
-      }
       if (t_splits) s = t_splits;
     }
-    if (s > kt) s = kt > 0 ? kt : 1;
-    c.ktps = (kt + s - 1) / s;
-    s = c.ktps > 0 ? (kt + c.ktps - 1) / c.ktps : 1;  // every slice owns >= 1 k-tile
+    if (s > ktc) s = ktc > 0 ? ktc : 1;
+    c.ktps = (ktc + s - 1) / s;
+    if (s > 1 && (c.ktps & 1)) c.ktps++;  // even number of k-tiles per slice: no phantom k-step (gemm_f32_kernel.h)
+    s = c.ktps > 0 ? (ktc + c.ktps - 1) / c.ktps : 1;  // every slice owns >= 1 k-tile
     c.splits = s;
     c.fixup = s > 1 ? 1 : 0;
     return c;
   }
   // ---- TN
   static const int cand[3] = {0, 1, 2};
-  static const double handicap[3] = {1.0, 1.13, 1.13};
+  static const double handicap[3] = {1.0, 0.97, 0.97};
   const int rows = d->K / G > 0 ? d->K / G : 1;
-  const double pen = d->K > 0 ? 100.0 * G / d->K : 0.0;
+  const double pen = d->K > 0 ? 60.0 * G / d->K : 0.0;
   double best = 0;
   int best_s = 1;
   c.tile = -1;
@@ -306,10 +313,7 @@ Cfg choose_cfg(const sm3_gemm_desc* d) {
       if (d->splits <= 0 && s > 192) break;  // beyond ~200 slices the second pass and the short k-loops cost more than
                                              // the extra workgroups bring (stage-0 weight gradients: 128-192 best)
       const long blocks = tiles * s;
-      const double pc = (double)blocks / kNumCU;
-      double occ = 1.0 + 0.15 * (pc < 3.0 ? 3.0 - pc : 0.0);
-      if (d->group_offsets && pc < 4.5) occ += 0.05 * (4.5 - pc);  // ragged expert segments: more, smaller work items
-      const double cost = quant_cost(blocks) * occ * handicap[i] * waste + pen * (s > 1 ? s : 0);
+      const double cost = quant_cost(blocks) * handicap[i] * waste + pen * (s > 1 ? s : 0);
       if (c.tile < 0 || cost < best - 1e-9) { best = cost; c.tile = cand[i]; best_s = s; }
     }
   }

@@ -96,7 +96,7 @@ template <class TL, int BK>
 constexpr int occupancy() {
   // 128x128 at k-step 16 needs ~150 VGPRs to keep its LDS read bases out of the loop: 3 waves per SIMD without spills
   // instead of 4 with scratch reloads and address arithmetic between the MFMAs
-  return (TL::TI * TL::TJ >= 6 || BK == 32) ? 2 : (TL::TI * TL::TJ == 4 ? 3 : 4);
+  return (TL::TI * TL::TJ >= 6 || BK == 32) ? 2 : (TL::TI * TL::TJ >= 3 ? 3 : 4);
 }
 
 // exact n / d for n * d < 2^32 with m = floor(2^32 / d) + 1 (d >= 2); d == 1 passes through
@@ -257,9 +257,6 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
   // direct loader (source k-major) of an operand with R columns: quad index tid + 256 i -> (k row, column quad)
   constexpr int PA = A_TRANS ? (BM + T_ROWS - 1) / T_ROWS : (BK * (BM / 4) + NTHREADS - 1) / NTHREADS;
   constexpr int PB = B_TRANS ? (BN + T_ROWS - 1) / T_ROWS : (BK * (BN / 4) + NTHREADS - 1) / NTHREADS;
-  // every thread owns an element of every piece (then the LDS stores need no exec mask: 3 scalar instructions each)
-  constexpr bool A_FULL = A_TRANS ? (BM % T_ROWS == 0) : ((BK * (BM / 4)) % NTHREADS == 0);
-  constexpr bool B_FULL = B_TRANS ? (BN % T_ROWS == 0) : ((BK * (BN / 4)) % NTHREADS == 0);
   constexpr int NP = PA + PB;  // pieces (one 16-byte load per thread each) per k-tile
   constexpr int KP = BK / 2;   // k-pairs = MFMA groups per k-tile
   static_assert(NP <= KP, "piece schedule: one load and one store slot per k-pair");
@@ -278,7 +275,7 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
   unsigned oa[PA], ob[PB];  // byte offsets from a_base / b_base
   const char* a_base = nullptr;
   const char* b_base = nullptr;
-  int sa[PA], sb[PB];    // LDS offset of the piece (negative: this thread has no element in the piece)
+  int sa[PA], sb[PB];    // LDS offset of the piece (lanes beyond the tile repeat its last row: no exec mask on the stores)
   int ka[PA], kb[PB];    // direct loader: k row of the piece
   int gy[PA], gx[PA];    // GATHER (NT/NN): grid coordinates of this thread's A rows
   int tn_tap = 0;        // GATHER (TN): the tap this N-tile belongs to (cC % BN == 0)
@@ -288,7 +285,7 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
     ka[i] = 0;
     if (A_TRANS) {
       const int rl = t_r + T_ROWS * i;
-      sa[i] = (rl < BM) ? (4 * t_kq) * LDA_S + rl : -1;
+      sa[i] = (4 * t_kq) * LDA_S + min(rl, BM - 1);  // surplus lanes repeat row BM-1 (same data, same slot)
       const int r = min(row0 + min(rl, BM - 1), row_end - 1);
       if (GATHER) {
         const unsigned t = fast_div((unsigned)r, (unsigned)p.rW, p.mRW);
@@ -304,8 +301,8 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
       constexpr int QR = BM / 4;
       const int idx = tid + NTHREADS * i;
       const int kk = idx / QR, cq = idx - kk * QR;
-      ka[i] = kk;
-      sa[i] = (kk < BK) ? kk * LDA_S + 4 * cq : -1;
+      ka[i] = min(kk, BK - 1);  // surplus lanes (kk >= BK) repeat k-row BK-1: same data into the same slot
+      sa[i] = min(kk, BK - 1) * LDA_S + 4 * cq;
       pa[i] = Ag + min(m0 + 4 * cq, p.M - 4);
       oa[i] = (unsigned)(((long)min(kk, BK - 1) * p.lda + min(m0 + 4 * cq, p.M - 4)) * 4);  // kk >= BK: lane without an element
     }
@@ -317,7 +314,7 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
     kb[i] = 0;
     if (B_TRANS) {
       const int rl = t_r + T_ROWS * i;
-      sb[i] = (rl < BN) ? (4 * t_kq) * LDB_S + rl : -1;
+      sb[i] = (4 * t_kq) * LDB_S + min(rl, BN - 1);
       const int n = min(n0 + min(rl, BN - 1), p.N - 1);
       pb[i] = Bg + (long)n * p.ldb + 4 * t_kq + (long)kbase * BK;
       ob[i] = (unsigned)(((long)(n - n0) * p.ldb + 4 * t_kq) * 4);
@@ -325,8 +322,8 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
       constexpr int QR = BN / 4;
       const int idx = tid + NTHREADS * i;
       const int kk = idx / QR, cq = idx - kk * QR;
-      kb[i] = kk;
-      sb[i] = (kk < BK) ? kk * LDB_S + 4 * cq : -1;
+      kb[i] = min(kk, BK - 1);
+      sb[i] = min(kk, BK - 1) * LDB_S + 4 * cq;
       const int nc = min(n0 + 4 * cq, p.N - 4);
       if (MODE == MODE_TN) {
         if (GATHER) {
@@ -446,7 +443,7 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
     else rb[q - PA] = live ? rb_[q - PA] : z4;
     if (q < PA) {
       float* a_s = As + buf * A_STAGE;
-      if (A_FULL || sa[q] >= 0) {
+      {
         if (A_TRANS) {
 #pragma unroll
           for (int j = 0; j < 4; j++) a_s[sa[q] + j * LDA_S] = ra[q][j];
@@ -457,7 +454,7 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
     } else {
       const int i = q - PA;
       float* b_s = Bs + buf * B_STAGE;
-      if (B_FULL || sb[i] >= 0) {
+      {
         if (B_TRANS) {
 #pragma unroll
           for (int j = 0; j < 4; j++) b_s[sb[i] + j * LDB_S] = rb[i][j];
