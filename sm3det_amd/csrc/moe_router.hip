@@ -33,15 +33,64 @@ constexpr int RT_THREADS = 64;  // one wavefront per workgroup
 constexpr int LPT = 4;          // lanes per token
 constexpr int RT_TOKENS = RT_THREADS / LPT;  // tokens per workgroup
 
-// cooperative, coalesced copy of the [64 tokens][P] feature tile into LDS (row stride P+1)
+// cooperative, coalesced copy of the [16 tokens][P] feature tile into LDS (row stride P+1).  Eight 16-byte loads per lane
+// are issued before the first LDS store (a load -> store loop body made every iteration a full L2/HBM round trip: the
+// 12 + 6 dependent trips of the two prologue loops were most of the kernel's 26 us).
 __device__ __forceinline__ void load_h_tile(const float* __restrict__ hcat, int ldh, int P, int t0, int T, float* hs) {
   const int nq = P >> 2, ldt = P + 1;
-  for (int i = threadIdx.x; i < RT_TOKENS * nq; i += RT_THREADS) {
-    const int r = i / nq, q = i - r * nq;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (t0 + r < T) v = ld4(hcat + (long)(t0 + r) * ldh + 4 * q);
-    float* d = hs + r * ldt + 4 * q;
-    d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+  const int total = RT_TOKENS * nq;
+  for (int base = 0; base < total; base += 8 * RT_THREADS) {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int i = min(base + u * RT_THREADS + (int)threadIdx.x, total - 1);
+      const int r = i / nq, q = i - r * nq;
+      v[u] = ld4(hcat + (long)min(t0 + r, T - 1) * ldh + 4 * q);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int i = base + u * RT_THREADS + (int)threadIdx.x;
+      if (i < total) {
+        const int r = i / nq, q = i - r * nq;
+        const f32x4 w = (t0 + r < T) ? v[u] : f32x4{0.f, 0.f, 0.f, 0.f};
+        float* d = hs + r * ldt + 4 * q;
+        d[0] = w[0]; d[1] = w[1]; d[2] = w[2]; d[3] = w[3];
+      }
+    }
+  }
+}
+
+// column-normalised similarity matrix (P, E) -> LDS rows of ET floats (zero padded); same batching
+template <int ET>
+__device__ __forceinline__ void load_snorm(const float* __restrict__ snorm, int P, int E, float* s_s) {
+  if (ET == E) {  // straight copy, P * E is a multiple of 4 (P is)
+    const int total = (P * ET) >> 2;
+    for (int base = 0; base < total; base += 8 * RT_THREADS) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) v[u] = ld4(snorm + 4 * (long)min(base + u * RT_THREADS + (int)threadIdx.x, total - 1));
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int i = base + u * RT_THREADS + (int)threadIdx.x;
+        if (i < total) st4(s_s + 4 * i, v[u]);
+      }
+    }
+  } else {
+    const int total = P * ET;
+    for (int base = 0; base < total; base += 8 * RT_THREADS) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int i = min(base + u * RT_THREADS + (int)threadIdx.x, total - 1);
+        const int p = i / ET, e = i - p * ET;
+        v[u] = snorm[p * E + min(e, E - 1)];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int i = base + u * RT_THREADS + (int)threadIdx.x;
+        if (i < total) s_s[i] = (i % ET) < E ? v[u] : 0.f;
+      }
+    }
   }
 }
 
@@ -60,11 +109,7 @@ __global__ __launch_bounds__(RT_THREADS) void moe_router_fwd_kernel(
   float* s_s = sm;                         // snorm, row stride ET (zero padded), 16-byte aligned rows
   float* hs = sm + (long)P * ET;           // [16][P+1]
   const bool linear = snorm == nullptr;
-  if (!linear)
-    for (int i = threadIdx.x; i < P * ET; i += RT_THREADS) {
-      const int p = i / ET, e = i - p * ET;
-      s_s[i] = e < E ? snorm[p * E + e] : 0.f;
-    }
+  if (!linear) load_snorm<ET>(snorm, P, E, s_s);
   const int t0 = blockIdx.x * RT_TOKENS;
   load_h_tile(hcat, ldh, P, t0, T, hs);
   __syncthreads();
@@ -83,7 +128,16 @@ __global__ __launch_bounds__(RT_THREADS) void moe_router_fwd_kernel(
 #pragma unroll
     for (int e = 0; e < ET; e++) dot[e] = 0.f;
     float nn = 0.f;
+    // per-token scattered operands requested before the dot loop: their round trip overlaps it
+    const float* h = hcat + (long)t * ldh;
+    float raw_n[ET], nz[ET];
+#pragma unroll
+    for (int e = 0; e < ET; e++) {
+      raw_n[e] = (e < E && train) ? h[P + e] : 0.f;
+      nz[e] = (e < E && train) ? noise[(long)t * E + e] : 0.f;
+    }
     if (!linear) {
+#pragma unroll 4
       for (int p = sub; p < P; p += LPT) {
         const float hv = hrow[p];
         nn += hv * hv;
@@ -100,7 +154,6 @@ __global__ __launch_bounds__(RT_THREADS) void moe_router_fwd_kernel(
     }
     const float hn = linear ? 1.f : sqrtf(nn);
     const float inv = 1.0f / fmaxf(hn, 1e-12f);  // F.normalize eps
-    const float* h = hcat + (long)t * ldh;
     float logit[ET], cl[ET], sg[ET];
 #pragma unroll
     for (int e = 0; e < ET; e++) {
@@ -108,8 +161,8 @@ __global__ __launch_bounds__(RT_THREADS) void moe_router_fwd_kernel(
       sg[e] = 1.f;
       logit[e] = cl[e];
       if (e < E && train) {
-        sg[e] = softplus_f(h[P + e]) + 1e-2f;
-        logit[e] = cl[e] + noise[(long)t * E + e] * sg[e];
+        sg[e] = softplus_f(raw_n[e]) + 1e-2f;
+        logit[e] = cl[e] + nz[e] * sg[e];
       }
     }
     // top-m selection (descending); ties -> lower index, like a stable descending sort
@@ -214,11 +267,7 @@ __global__ __launch_bounds__(RT_THREADS) void moe_router_bwd_kernel(
   float* s_s = sm;
   float* hs = sm + (long)P * ET;  // [16][P+1]: h on the way in, dh on the way out
   const bool linear = snorm == nullptr;
-  if (!linear)
-    for (int i = threadIdx.x; i < P * ET; i += RT_THREADS) {
-      const int p = i / ET, e = i - p * ET;
-      s_s[i] = e < E ? snorm[p * E + e] : 0.f;
-    }
+  if (!linear) load_snorm<ET>(snorm, P, E, s_s);
   const int t0 = blockIdx.x * RT_TOKENS;
   load_h_tile(hcat, ldh, P, t0, T, hs);
   __syncthreads();
@@ -330,6 +379,7 @@ __global__ __launch_bounds__(RT_THREADS) void moe_router_bwd_kernel(
         hrow[p] = a;
       }
     } else {
+#pragma unroll 4
     for (int p = sub; p < P; p += LPT) {
       const float* srow = s_s + p * ET;
       float a = 0.f;
@@ -339,6 +389,7 @@ __global__ __launch_bounds__(RT_THREADS) void moe_router_bwd_kernel(
     }
     proj = group_sum<LPT>(proj);
     if (hn < 1e-12f) proj = 0.f;  // clamp region of F.normalize: d/dh (h/eps) = dhh/eps
+#pragma unroll 4
     for (int p = sub; p < P; p += LPT) {
       const float* srow = s_s + p * ET;
       float a = 0.f;
