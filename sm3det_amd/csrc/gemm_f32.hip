@@ -451,6 +451,7 @@ int sm3_colsum_f32(const float* x, int ld, int m, int n, const int32_t* group_of
 // exists (the FPN 3x3 at 256^2 x 256 ch would need a 1.2 GB one).  Weight layout (Cout, 3, 3, Cin) = [Cout][9*Cin].
 static void conv_geometry(GemmParams& p, int cC, int sH, int sW, int rH, int rW, int stride, int transposed, int bk) {
   p.cC = cC; p.sH = sH; p.sW = sW; p.rH = rH; p.rW = rW; p.cS = stride; p.cT = transposed;
+  p.cU = !transposed ? (0 | 1 << 4 | 2 << 8) : (stride == 2 ? (1 | 1 << 4 | 0 << 8) : (2 | 1 << 4 | 0 << 8));
   const unsigned tpt = (unsigned)(cC / bk);
   p.cInv = (65536u + tpt - 1) / tpt;
   p.mRW = (unsigned)((1ull << 32) / (unsigned)rW + 1);
@@ -469,8 +470,9 @@ static GemmParams conv_params_zero() {
 }
 
 static bool conv_dims_ok(int B, int H, int W, int Cin, int Cout, int stride) {
+  // the gathered operand is addressed as descriptor base + 32-bit offsets, masked taps use an offset of 0x7fff0000
   return B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && (stride == 1 || stride == 2) &&
-         (long)B * H * W < (1l << 24);
+         (long)B * H * W < (1l << 24) && (long)B * H * W * (Cin > Cout ? Cin : Cout) * 4 < (1l << 30);
 }
 
 // Small pyramid levels have fewer 128x128 output tiles than the chip has CUs while K = 9*C is long: split K across

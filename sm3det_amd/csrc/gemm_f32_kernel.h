@@ -75,6 +75,7 @@ struct GemmParams {
   // (rH, rW) grid.  cT = 0: source = row * cS + d - 1 (forward / weight gradient);  cT = 1: source = (row - d + 1) / cS
   // where divisible (input gradient = transposed convolution).  cInv: (kt * cInv) >> 16 == kt / (cC / BK).
   int cC, sH, sW, rH, rW, cS, cT;
+  int cU;  // per-tap source offset u(d), d = 0..2, 4 bits each: d (forward), 2 - d (input gradient), 1 - d/2 (same, stride 2)
   unsigned cInv, mRW, mRH;  // mRW/mRH: ceil(2^32 / rW), ceil(2^32 / rH) for exact umulhi division of row indices
 };
 
@@ -278,10 +279,12 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
   int sa[PA], sb[PB];    // LDS offset of the piece (lanes beyond the tile repeat its last row: no exec mask on the stores)
   int ka[PA], kb[PB];    // direct loader: k row of the piece
   int gy[PA], gx[PA];    // GATHER (NT/NN): grid coordinates of this thread's A rows
+  unsigned m9[PA];       // GATHER (NT/NN): bit t set <=> tap t of this row reads a pixel inside the image
   int tn_tap = 0;        // GATHER (TN): the tap this N-tile belongs to (cC % BN == 0)
 #pragma unroll
   for (int i = 0; i < PA; i++) {
     gy[i] = gx[i] = 0;
+    m9[i] = 0;
     ka[i] = 0;
     if (A_TRANS) {
       const int rl = t_r + T_ROWS * i;
@@ -293,6 +296,24 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
         const unsigned b = fast_div(t, (unsigned)p.rH, p.mRH);
         gy[i] = (int)t - (int)b * p.rH;
         pa[i] = Ag + (long)b * p.sH * p.sW * p.cC + 4 * t_kq;
+        // Implicit im2col without per-load coordinate arithmetic: source pixel = (ay + uy(dy) - 1, ax + ux(dx) - 1) with a
+        // per-row part (ay, ax) and a per-tap part that is the same for every lane:
+        //   forward / weight gradient (cT = 0): ay = gy * stride,          uy(d) = d
+        //   input gradient, stride 1:           ay = gy,                   uy(d) = 2 - d
+        //   input gradient, stride 2:           ay = (gy + 1) >> 1,        uy(d) = 1 - d / 2   (taps of the wrong parity
+        //                                                                                      are masked in m9)
+        // so the address is  [base - (sW + 1) * cC]  +  lane offset (fixed)  +  scalar tap offset, and a lane whose tap
+        // falls outside the image swaps its offset for one beyond the descriptor's extent: the load returns 0.
+        const int ay = p.cT ? (p.cS == 2 ? (gy[i] + 1) >> 1 : gy[i]) : gy[i] * p.cS;
+        const int ax = p.cT ? (p.cS == 2 ? (gx[i] + 1) >> 1 : gx[i]) : gx[i] * p.cS;
+        oa[i] = (unsigned)(((((long)b * p.sH + ay) * p.sW + ax) * p.cC + 4 * t_kq) * 4);
+        m9[i] = 0;
+#pragma unroll
+        for (int tp = 0; tp < 9; tp++) {
+          const int sy = gather_coord(gy[i], tp / 3, p.cS, p.cT, p.sH);
+          const int sx = gather_coord(gx[i], tp % 3, p.cS, p.cT, p.sW);
+          if (sy >= 0 && sx >= 0) m9[i] |= 1u << tp;
+        }
       } else {
         pa[i] = Ag + (long)r * p.lda + 4 * t_kq + (long)kbase * BK;
         oa[i] = (unsigned)(((long)(r - row0) * p.lda + 4 * t_kq) * 4);
@@ -308,6 +329,7 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
     }
   }
   if (MODE == MODE_TN) a_base = reinterpret_cast<const char*>(Ag + (long)row0 * p.lda);
+  else if (GATHER) a_base = reinterpret_cast<const char*>(Ag) - (long)(p.sW + 1) * p.cC * 4;
   else a_base = reinterpret_cast<const char*>(Ag + (long)row0 * p.lda + (long)kbase * BK);
 #pragma unroll
   for (int i = 0; i < PB; i++) {
@@ -340,7 +362,7 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
     }
   }
   if (MODE == MODE_NT) b_base = reinterpret_cast<const char*>(Bg + (long)n0 * p.ldb + (long)kbase * BK);
-  else if (MODE == MODE_NN) b_base = reinterpret_cast<const char*>(Bg + (long)kbase * BK * p.ldb);
+  else if (MODE == MODE_NN) b_base = reinterpret_cast<const char*>(Bg + (GATHER ? 0 : (long)kbase * BK * p.ldb));
   else b_base = reinterpret_cast<const char*>(Bg + (long)row0 * p.ldb);
   // piece q in [0, NP): q < PA -> A piece q, else B piece q - PA.  tail == false (the bulk of the k-loop): tile kt is a
   // complete tile strictly before the last one, so no clamp and no select is issued; tail == true: the last steps, where
@@ -360,6 +382,10 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
     a_valid = (long)(row_end - 1 - row0) * p.lda + p.M;
     b_valid = (long)(row_end - 1 - row0) * p.ldb + p.N;
     if (row_end <= row0) a_valid = b_valid = 0;
+  } else if (GATHER) {
+    // gathered tensor: (M / (rH * rW)) images of sH x sW x cC, seen from the shifted base; NN weights: cC rows of ldb
+    a_valid = (long)(p.M / (p.rH * p.rW)) * p.sH * p.sW * p.cC + (long)(p.sW + 1) * p.cC;
+    b_valid = MODE == MODE_NT ? (long)(p.N - 1 - n0) * p.ldb + (p.K - (long)kbase * BK) : (long)p.cC * p.ldb;
   } else {
     a_valid = (long)(row_end - 1 - row0) * p.lda + (p.K - (long)kbase * BK);
     b_valid = MODE == MODE_NT ? (long)(p.N - 1 - n0) * p.ldb + (p.K - (long)kbase * BK)
@@ -387,11 +413,11 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
         const int kg = kt + kbase;
         const int tap = (int)(((unsigned)kg * p.cInv) >> 16);  // k-tile -> tap (uniform), channel offset inside it
         const int c0 = kg * BK - tap * p.cC;
-        const int sy = gather_coord(gy[q], tap / 3, p.cS, p.cT, p.sH);
-        const int sx = gather_coord(gx[q], tap % 3, p.cS, p.cT, p.sW);
-        const long off = ((long)max(sy, 0) * p.sW + max(sx, 0)) * p.cC + c0;
-        f32x4 v = *reinterpret_cast<const f32x4*>(pa[q] + off);
-        ra[q] = (sy >= 0 && sx >= 0) ? v : zero4;
+        const int dy = tap / 3, dx = tap - 3 * dy;
+        const int uy = (p.cU >> (4 * dy)) & 15, ux = (p.cU >> (4 * dx)) & 15;  // branch-free (see GemmParams::cU)
+        const long soff = ((long)(uy * p.sW + ux) * p.cC + c0) * 4;           // scalar
+        const unsigned voff = (m9[q] & (1u << tap)) ? oa[q] : 0x7fff0000u;   // 3 VALU per load
+        ra[q] = ldg(a_rsrc, soff, voff);
       } else {
         ra[q] = ldg(a_rsrc, (long)kt * BK * 4, oa[q]);
       }
@@ -427,7 +453,7 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
         const int kg = kt + kbase;
         const int tap = (int)(((unsigned)kg * p.cInv) >> 16);
         const int c0 = kg * BK - tap * p.cC;
-        rb[i] = *reinterpret_cast<const f32x4*>(pb[i] + (long)c0 * p.ldb + tap * p.N);
+        rb[i] = ldg(b_rsrc, ((long)c0 * p.ldb + (long)tap * p.N) * 4, ob[i]);
       } else {
         rb[i] = ldg(b_rsrc, (long)kt * BK * p.ldb * 4, ob[i]);
       }
