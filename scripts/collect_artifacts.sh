@@ -14,7 +14,7 @@ tail -c 300 $O/${TAG}_bench.json
 python $R/bench.py --amp --no-cpu-baseline --no-ops > $O/${TAG}_bench_amp.json 2> $O/${TAG}_bench_amp.err
 for MODE in serial overlap; do
   rm -rf /tmp/prof_$MODE
-  if [ $MODE = serial ]; then export SM3_WGRAD_STREAM=0; else unset SM3_WGRAD_STREAM; fi
+  if [ $MODE = serial ]; then export SM3_WGRAD_STREAM=0; else export SM3_WGRAD_STREAM=1; fi
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$MODE -o p -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-ops > $O/${TAG}_rocprof_$MODE.log 2>&1
   find /tmp/prof_$MODE -name "*kernel_stats.csv" -exec cp {} $O/${TAG}_kernel_stats_$MODE.csv \;
   grep -h '^{' $O/${TAG}_rocprof_$MODE.log | tail -1 > $O/${TAG}_bench_under_rocprof_$MODE.json

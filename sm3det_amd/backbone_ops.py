@@ -54,8 +54,11 @@ def _chk(t, name):
 # weight gradient) feed nothing in the dx chain.  They are enqueued on ONE side stream, forked after the tensors they
 # read exist and joined at the end of the block's backward, so the chip runs them underneath the latency-bound small
 # kernels of the dx chain (router, LayerNorm, combine, depthwise) and the tails of the dgrad GEMMs.  Works the same
-# eagerly and under hipGraph capture (the fork/join become graph edges).  SM3_WGRAD_STREAM=0 disables it.
-OVERLAP_WGRAD = os.environ.get('SM3_WGRAD_STREAM', '1') != '0'
+# eagerly and under hipGraph capture (the fork/join become graph edges).
+# OFF by default since the GEMM k-loop rework: with the GEMMs filling the chip, two of them sharing it lose more than the
+# small kernels gain from the overlap (training step 20.2 ms without, 20.6 ms with the side stream; it was worth 1.6 ms
+# when the GEMM family ran at 0.48 of peak).  SM3_WGRAD_STREAM=1 turns it back on.
+OVERLAP_WGRAD = os.environ.get('SM3_WGRAD_STREAM', '0') == '1'
 _SIDE = {}
 
 

@@ -735,10 +735,10 @@ int sm3_dwconv7_bwd_weight(const float* x, const float* du, float* dw49, float* 
     return SM3_ERR_INVALID_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (dbias == dw49 + (size_t)49 * C) {  // one (50, C) buffer [dw49; dbias]: one fill
-    (void)hipMemsetAsync(dw49, 0, sizeof(float) * 50 * C, st);
+    sm3_zero_async(dw49, sizeof(float) * 50 * C, st);
   } else {
-    (void)hipMemsetAsync(dw49, 0, sizeof(float) * 49 * C, st);
-    (void)hipMemsetAsync(dbias, 0, sizeof(float) * C, st);
+    sm3_zero_async(dw49, sizeof(float) * 49 * C, st);
+    sm3_zero_async(dbias, sizeof(float) * C, st);
   }
   if (sm3_dwconv7_lds_supported(H, W, C)) {
     sm3_dwconv7_lds_bwd_weight(x, du, dw49, dbias, B, H, W, C, st);

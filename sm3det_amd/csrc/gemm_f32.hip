@@ -221,7 +221,7 @@ inline double quant_cost(long blocks) {
 // Tile / k-step / split-K selection: a small cost model fitted to scripts/gemm_sweep2.py on MI355X (tile x k-step x slices
 // over every GEMM shape of the ConvNeXt-T e8t2 training step; profiles/r02/gemm_sweep_r02b.txt is the sweep of the
 // current kernel, refit: scripts/fit_gemm_nt.py, scripts/fit_gemm_tn.py):
-//  * NT/NN: (tile in 128x128, 128x96, 64x128) x (1..4 k-slices, only with < 256 tiles and a long K, in-kernel fix-up);
+//  * NT/NN: (tile in 128x128, 128x96, 64x128) x (1..8 k-slices, only with < 256 tiles and a long K, in-kernel fix-up);
 //    cost = CU-round quantisation x padded-width waste x tile handicap x penalty for CUs with < 2 workgroups x 10 % per
 //    extra slice.  k-step 32 from K = 1024.
 //  * TN: (128x128, 128x96, 96x128) x slices 1..192 reduced by the second pass (never the in-kernel fix-up: on 64 KB slabs
@@ -259,7 +259,7 @@ Cfg choose_cfg(const sm3_gemm_desc* d) {
       const long tiles = (long)((d->M + bm - 1) / bm + (d->group_offsets ? G / 2 : 0)) * ((d->N + bn - 1) / bn);
       const long slots = (long)((d->M + bm - 1) / bm + (d->group_offsets ? G : 0)) * ((d->N + bn - 1) / bn);
       const double waste = (double)pad_to(d->N, bn) / d->N;
-      for (int s = 1; s <= 4; s++) {
+      for (int s = 1; s <= 8; s++) {
         if (s > 1 && (!have_counters || slots > COUNTER_SLOTS || d->splits == 1 || tiles >= kNumCU || kt < 24 ||
                       kt / s < 6 || t_tile >= 0))
           break;
@@ -439,7 +439,7 @@ int sm3_colsum_f32(const float* x, int ld, int m, int n, const int32_t* group_of
   if (splits < 1) splits = 1;
   if (splits > COLSUM_SPLITS) splits = COLSUM_SPLITS;
   dim3 grid((n + 63) / 64, splits, groups);
-  (void)hipMemsetAsync(out, 0, sizeof(float) * (size_t)groups * n, (hipStream_t)stream);
+  sm3_zero_async(out, sizeof(float) * (size_t)groups * n, (hipStream_t)stream);
   colsum_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, ld, n, group_offsets, m, splits, out);
   return launch_status();
 }

@@ -840,7 +840,7 @@ int sm3_max_iou_assign(const float* boxes, int box_stride, int n, const float* g
   hipStream_t st = (hipStream_t)stream;
   int32_t* argmax = (int32_t*)workspace;
   unsigned* gmax = (unsigned*)((char*)workspace + align_up((size_t)n * sizeof(int32_t), 256));
-  (void)hipMemsetAsync(gmax, 0, sizeof(unsigned) * (size_t)(k > 0 ? k : 1), st);
+  sm3_zero_async(gmax, sizeof(unsigned) * (size_t)(k > 0 ? k : 1), st);
   const int blocks = (n + 255) / 256;
   max_iou_pass1_kernel<<<blocks, 256, 0, st>>>(boxes, box_stride, n, gts, gt_stride, k, rotated, max_overlaps, argmax,
                                                gmax);
@@ -886,7 +886,7 @@ static int nms_common(bool rotated, const float* boxes, int stride, const float*
                       void* ws, size_t ws_bytes, hipStream_t st) {
   if (n < 0 || !num_keep) return SM3_ERR_INVALID_ARG;
   if (n == 0) {
-    (void)hipMemsetAsync(num_keep, 0, sizeof(int32_t), st);
+    sm3_zero_async(num_keep, sizeof(int32_t), st);
     return launch_status();
   }
   if (!boxes || !keep || !ws) return SM3_ERR_INVALID_ARG;

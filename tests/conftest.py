@@ -1,7 +1,11 @@
 import os
 import sys
 
-import pytest
+# see bench.py: memset nodes of replayed linear hipGraphs (torch's reduction semaphores) lose their ordering with the
+# ROCm 7.2 packet-capture fast path; must be set before the HIP runtime is loaded
+os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')
+
+import pytest  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
