@@ -86,6 +86,58 @@ class MultiTensorAdamW(torch.optim.Optimizer):
         elif 'scale' in sd:
             self._scaler_cfg['init_scale'] = sd['scale']
 
+    # ------------------------------------------------------------------------- reference optimizer state
+    def load_reference_state(self, module, ref_state_dict, ref_param_keys=None):
+        """`resume_from` of a reference checkpoint: translate the state of the reference's ``torch.optim.AdamW`` (one
+        group per parameter in ``named_parameters()`` order -- mmcv ``DefaultOptimizerConstructor.add_params``,
+        optimizer/default_constructor.py:180-227; moments in the REFERENCE layouts: one tensor per expert Linear,
+        depthwise weights (C,1,7,7), 3x3 conv weights OIHW) into this optimizer's per-parameter state.
+
+        The moments have the shapes of the parameters they belong to, so they are pushed through the module's own
+        ``load_state_dict`` hooks (the ones that turn a reference ``state_dict`` into the fused / tap-major storage) on a
+        CPU shadow copy of ``module``.  ``ref_param_keys``: the reference's parameter names in optimizer order; default =
+        the parameter keys of ``module.state_dict()``, which are emitted in the reference's order.  The step counter is
+        one device scalar here: the reference's per-parameter ``step`` values must agree (they do: AdamW steps every
+        parameter that has a gradient, and the schedule needs one value)."""
+        import copy
+        buf = {n for n, _ in module.named_buffers()}
+        if ref_param_keys is None:
+            ref_param_keys = [k for k in module.state_dict().keys() if k not in buf]
+        state = ref_state_dict['state']
+        order = [i for g in ref_state_dict['param_groups'] for i in g['params']]
+        if len(order) != len(ref_param_keys):
+            raise ValueError(f'reference optimizer state has {len(order)} parameters, the model has '
+                             f'{len(ref_param_keys)} under the reference key schema')
+        shadow = copy.deepcopy(module).to('cpu')
+        by_name = dict(module.named_parameters())
+        mine = {id(p) for g in self.param_groups for p in g['params']}
+        steps = set()
+        for moment in ('exp_avg', 'exp_avg_sq'):
+            sd = {}
+            for key, idx in zip(ref_param_keys, order):
+                st = state.get(idx, state.get(str(idx)))
+                if st is None:
+                    continue  # never stepped (frozen / unused): stays at its zero-initialised state
+                sd[key] = st[moment].detach().to('cpu', torch.float32)
+                steps.add(float(st['step']))
+            with torch.no_grad():
+                for q in shadow.parameters():
+                    q.fill_(float('nan'))  # marks what the load below does not touch
+            res = shadow.load_state_dict(sd, strict=False)
+            if res.unexpected_keys:  # e.g. only some experts of a fused tensor: the hooks fuse all or nothing
+                raise ValueError(f'reference optimizer state names unknown parameters: {res.unexpected_keys[:4]}')
+            for name, q in shadow.named_parameters():
+                p = by_name[name]
+                if id(p) not in mine or bool(torch.isnan(q).any()):
+                    continue
+                self.state[p][moment] = q.detach().clone().to(p.device).contiguous()
+        if len(steps) > 1:
+            raise ValueError(f'reference optimizer state carries different step counts {sorted(steps)[:4]}')
+        if steps:
+            dev = next(iter(by_name.values())).device
+            self._step = torch.full((1,), steps.pop(), dtype=torch.float32, device=dev)
+        self._built = False  # pointer tables are rebuilt on the next step()
+
     # ------------------------------------------------------------------------------------------- tables
     def _grad_set(self):
         return frozenset(id(p) for g in self.param_groups for p in g['params'] if p.grad is not None)

@@ -76,3 +76,38 @@ def test_pretrained_load_equals_reference_init_weights():
         assert ref.get_layer_depth(n) == net.get_layer_depth(n), n
         assert ref.get_layer_depth('backbone.' + n, 'backbone.') == net.get_layer_depth('backbone.' + n, 'backbone.')
     assert ref.get_layer_depth('neck.x', 'backbone.') == net.get_layer_depth('neck.x', 'backbone.')
+
+
+def test_reference_optimizer_state_is_translated_through_the_state_dict_hooks():
+    """`resume_from` of a reference checkpoint: the reference's AdamW keeps one state entry per reference parameter
+    (per-expert Linear tensors, depthwise (C,1,7,7)); MultiTensorAdamW.load_reference_state must land them in the fused /
+    tap-major storage exactly where load_state_dict lands the weights."""
+    import torch
+    from sm3det_amd.convnext_moe import ConvNeXt_moe
+    from sm3det_amd.optim import MultiTensorAdamW
+    torch.manual_seed(0)
+    net = ConvNeXt_moe(arch=dict(depths=[1, 1, 1, 1], channels=[32, 32, 32, 32]), MoE_Block_inds=[[], [0], [], []],
+                       num_experts=4, top_k=2)
+    buf = {n for n, _ in net.named_buffers()}
+    ref = {k: v for k, v in net.state_dict().items() if k not in buf}   # reference keys / shapes / order
+    g = torch.Generator().manual_seed(1)
+    state = {i: dict(step=torch.tensor(7.0), exp_avg=torch.randn(v.shape, generator=g),
+                     exp_avg_sq=torch.rand(v.shape, generator=g)) for i, v in enumerate(ref.values())}
+    ref_sd = dict(state=state, param_groups=[dict(params=[i], lr=1e-4) for i in range(len(ref))])
+    opt = MultiTensorAdamW([dict(params=[p]) for p in net.parameters()], lr=1e-4)
+    opt.load_reference_state(net, ref_sd)
+    keys = list(ref.keys())
+    moe = net.stages[1][0].ffn
+    i = keys.index('stages.1.0.ffn.experts.2.pointwise_conv1.weight')
+    assert torch.equal(opt.state[moe.w1]['exp_avg'][2], state[i]['exp_avg'])
+    assert torch.equal(opt.state[moe.w1]['exp_avg_sq'][2], state[i]['exp_avg_sq'])
+    j = keys.index('stages.0.0.depthwise_conv.weight')
+    dw = net.stages[0][0].depthwise_conv
+    assert opt.state[dw.weight]['exp_avg'].shape == (49, 32)
+    assert torch.equal(opt.state[dw.weight]['exp_avg'], state[j]['exp_avg'].reshape(32, 49).t())
+    assert float(opt._step) == 7.0 and all('exp_avg' in opt.state[p] for p in net.parameters())
+    # a state that misses some experts of a fused tensor cannot be fused: rejected, not silently zero-filled
+    del state[i]
+    import pytest
+    with pytest.raises(ValueError):
+        opt.load_reference_state(net, ref_sd)
