@@ -158,6 +158,16 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
   constexpr int A_STAGE = BK * LDA_S, B_STAGE = BK * LDB_S;
   __shared__ __attribute__((aligned(16))) float smem[2 * (A_STAGE + B_STAGE)];
   float* As = smem;                // [2][BK][LDA_S]
+  // F16: the LDS image holds fp16, converted once when a piece is stored.  The 8 consecutive k of one row (one MFMA
+  // fragment of a lane) are 16 contiguous bytes: element (k, r) lives in half ((k / 8) * LD16 + r) * 8 + (k & 7), so a
+  // fragment is ONE conflict-free ds_read_b128 with no conversion or permute between it and the MFMA (the fp32 image
+  // needed 8 ds_read_b32 + 4 conversions per fragment).  LD16 = rows + 4 = 4 (mod 16) rows keeps the 8-byte transposed
+  // stores of a k-step-32 tile on distinct banks.
+  constexpr int LDA16 = BM + 4, LDB16 = BN + 4;                          // rows per k-octet
+  constexpr int A_ST16 = (BK / 8) * LDA16 * 4, B_ST16 = (BK / 8) * LDB16 * 4;  // dwords per stage
+  uint32_t* Aw = reinterpret_cast<uint32_t*>(smem);  // [2][BK/8][LDA16][4 dwords], then B
+  uint32_t* Bw = Aw + 2 * A_ST16;
+  static_assert(!F16 || 2 * (A_ST16 + B_ST16) <= 2 * (A_STAGE + B_STAGE), "F16 image fits the fp32 allocation");
   float* Bs = smem + 2 * A_STAGE;  // [2][BK][LDB_S]
 
   const int tid = threadIdx.x;
@@ -277,6 +287,7 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
   const char* a_base = nullptr;
   const char* b_base = nullptr;
   int sa[PA], sb[PB];    // LDS offset of the piece (lanes beyond the tile repeat its last row: no exec mask on the stores)
+  int ha[PA], hb[PB];    // F16 image: dword offset (transposed pieces, 8-byte stores) / half offset (direct pieces)
   int ka[PA], kb[PB];    // direct loader: k row of the piece
   int gy[PA], gx[PA];    // GATHER (NT/NN): grid coordinates of this thread's A rows
   unsigned m9[PA];       // GATHER (NT/NN): bit t set <=> tap t of this row reads a pixel inside the image
@@ -289,6 +300,7 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
     if (A_TRANS) {
       const int rl = t_r + T_ROWS * i;
       sa[i] = (4 * t_kq) * LDA_S + min(rl, BM - 1);  // surplus lanes repeat row BM-1 (same data, same slot)
+      ha[i] = ((t_kq >> 1) * LDA16 + min(rl, BM - 1)) * 4 + 2 * (t_kq & 1);
       const int r = min(row0 + min(rl, BM - 1), row_end - 1);
       if (GATHER) {
         const unsigned t = fast_div((unsigned)r, (unsigned)p.rW, p.mRW);
@@ -326,6 +338,14 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
       sa[i] = min(kk, BK - 1) * LDA_S + 4 * cq;
       pa[i] = Ag + min(m0 + 4 * cq, p.M - 4);
       oa[i] = (unsigned)(((long)min(kk, BK - 1) * p.lda + min(m0 + 4 * cq, p.M - 4)) * 4);  // kk >= BK: lane without an element
+      if (F16) {
+        // F16: a piece is FOUR CONSECUTIVE k OF ONE COLUMN (four coalesced 4-byte loads, lanes along the columns), so
+        // that it lands in the fp16 image as 8 contiguous bytes like a transposed piece; a piece of four columns at
+        // one k would scatter 2-byte stores 16 B apart (8-way bank conflicts: measured 13.5 vs 9.4 ms per step)
+        const int g4 = min(idx / BM, BK / 4 - 1), c = idx % BM;  // surplus units repeat the last k-quad
+        ha[i] = ((g4 >> 1) * LDA16 + c) * 4 + 2 * (g4 & 1);
+        oa[i] = (unsigned)(((long)(4 * g4) * p.lda + min(m0 + c, p.M - 1)) * 4);
+      }
     }
   }
   if (MODE == MODE_TN) a_base = reinterpret_cast<const char*>(Ag + (long)row0 * p.lda);
@@ -337,6 +357,7 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
     if (B_TRANS) {
       const int rl = t_r + T_ROWS * i;
       sb[i] = (4 * t_kq) * LDB_S + min(rl, BN - 1);
+      hb[i] = ((t_kq >> 1) * LDB16 + min(rl, BN - 1)) * 4 + 2 * (t_kq & 1);
       const int n = min(n0 + min(rl, BN - 1), p.N - 1);
       pb[i] = Bg + (long)n * p.ldb + 4 * t_kq + (long)kbase * BK;
       ob[i] = (unsigned)(((long)(n - n0) * p.ldb + 4 * t_kq) * 4);
@@ -359,6 +380,15 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
         pb[i] = Bg + (long)min(kk, BK - 1) * p.ldb + nc + (GATHER ? 0 : (long)kbase * BK * p.ldb);
         ob[i] = (unsigned)(((long)min(kk, BK - 1) * p.ldb + nc) * 4);
       }
+    }
+  }
+  if (F16 && !B_TRANS) {
+#pragma unroll
+    for (int i = 0; i < PB; i++) {
+      const int idx = tid + NTHREADS * i;
+      const int g4 = min(idx / BN, BK / 4 - 1), c = idx % BN;
+      hb[i] = ((g4 >> 1) * LDB16 + c) * 4 + 2 * (g4 & 1);
+      ob[i] = (unsigned)(((long)(4 * g4) * p.ldb + min(n0 + c, p.N - 1)) * 4);
     }
   }
   if (MODE == MODE_NT) b_base = reinterpret_cast<const char*>(Bg + (long)n0 * p.ldb + (long)kbase * BK);
@@ -397,10 +427,17 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, (int)soff, 0);
     return __builtin_bit_cast(f32x4, v);
   };
+  auto ldg1 = [&](const __amdgpu_buffer_rsrc_t& rs, long soff, unsigned voff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, (int)soff, 0));
+  };
   auto load_piece = [&](f32x4 (&ra)[PA], f32x4 (&rb)[PB], int q, int kt, bool tail) {
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     if (q < PA) {
-      if (MODE == MODE_TN) {
+      if (MODE == MODE_TN && F16) {
+        // rows past the segment end lie beyond the descriptor's extent and read 0: no clamp, no select, bulk or tail
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) ra[q][kk] = ldg1(a_rsrc, ((long)kt * BK + kk) * p.lda * 4, oa[q]);
+      } else if (MODE == MODE_TN) {
         if (!tail) {
           ra[q] = ldg(a_rsrc, (long)kt * BK * p.lda * 4, oa[q]);
         } else {
@@ -438,6 +475,9 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
           const long off = (((long)b * p.sH + max(sy, 0)) * p.sW + max(sx, 0)) * p.cC;
           f32x4 v = *reinterpret_cast<const f32x4*>(pb[i] + off);
           rb[i] = ok ? v : zero4;
+        } else if (F16) {
+#pragma unroll
+          for (int kk = 0; kk < 4; kk++) rb[i][kk] = ldg1(b_rsrc, ((long)kt * BK + kk) * p.ldb * 4, ob[i]);
         } else if (!tail) {
           rb[i] = ldg(b_rsrc, (long)kt * BK * p.ldb * 4, ob[i]);
         } else {
@@ -454,6 +494,9 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
         const int tap = (int)(((unsigned)kg * p.cInv) >> 16);
         const int c0 = kg * BK - tap * p.cC;
         rb[i] = ldg(b_rsrc, ((long)c0 * p.ldb + (long)tap * p.N) * 4, ob[i]);
+      } else if (F16) {  // NN: B rows are k
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) rb[i][kk] = ldg1(b_rsrc, ((long)kt * BK + kk) * p.ldb * 4, ob[i]);
       } else {
         rb[i] = ldg(b_rsrc, (long)kt * BK * p.ldb * 4, ob[i]);
       }
@@ -467,9 +510,17 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
     f32x4 ra[PA], rb[PB];
     if (q < PA) ra[q] = live ? ra_[q] : z4;
     else rb[q - PA] = live ? rb_[q - PA] : z4;
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    auto pack2 = [](float x, float y) {  // round-to-nearest-even, like a torch .half() cast
+      return __builtin_bit_cast(uint32_t, f16x2{(_Float16)x, (_Float16)y});
+    };
     if (q < PA) {
-      float* a_s = As + buf * A_STAGE;
-      {
+      if (F16) {
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        // every F16 piece is four consecutive k of one row / column -> 8 contiguous bytes
+        *reinterpret_cast<u32x2*>(Aw + buf * A_ST16 + ha[q]) = u32x2{pack2(ra[q][0], ra[q][1]), pack2(ra[q][2], ra[q][3])};
+      } else {
+        float* a_s = As + buf * A_STAGE;
         if (A_TRANS) {
 #pragma unroll
           for (int j = 0; j < 4; j++) a_s[sa[q] + j * LDA_S] = ra[q][j];
@@ -479,8 +530,11 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
       }
     } else {
       const int i = q - PA;
-      float* b_s = Bs + buf * B_STAGE;
-      {
+      if (F16) {
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<u32x2*>(Bw + buf * B_ST16 + hb[i]) = u32x2{pack2(rb[i][0], rb[i][1]), pack2(rb[i][2], rb[i][3])};
+      } else {
+        float* b_s = Bs + buf * B_STAGE;
         if (B_TRANS) {
 #pragma unroll
           for (int j = 0; j < 4; j++) b_s[sb[i] + j * LDB_S] = rb[i][j];
@@ -559,18 +613,19 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
     }
     __syncthreads();
   };
-  // F16 (mixed precision, the reference's `fp16 = dict(loss_scale='dynamic')` configs): same tiles, loaders and LDS
-  // image; the fp32 values are rounded to fp16 while the fragments are assembled (8 k-values per lane and operand) and
-  // multiplied by v_mfma_f32_32x32x16_f16 with fp32 accumulation -- 16x the matrix rate of the fp32 instruction, so the
-  // loop is bound by the operand stream from L2/HBM, not by the matrix pipe.  Every tensor in HBM stays fp32 (master
+  // F16 (mixed precision, the reference's `fp16 = dict(loss_scale='dynamic')` configs): same tiles and loaders; the fp32
+  // values are rounded to fp16 when a piece is stored to LDS (see Aw above), the fragments (8 k-values per lane and
+  // operand = 4 dwords) go from LDS straight into v_mfma_f32_32x32x16_f16 with fp32 accumulation -- 16x the matrix rate
+  // of the fp32 instruction, so the loop is bound by the operand stream, not by the matrix pipe.  Every tensor in HBM stays fp32 (master
   // weights, activations, gradients): no cast kernels, no fp16 copies.  A and B use the same (lane-half, element) -> k
   // assignment, so the sum over k is complete whatever order the hardware walks it in.
   auto k_step16 = [&](f32x4 (&ca)[PA], f32x4 (&cb)[PB], f32x4 (&na)[PA], f32x4 (&nb)[PB], int kt, bool tail) {
     const int buf = kt & 1;
     const int kt_load = tail ? min(kt + 2, nk - 1) : kt + 2;
     const bool live = tail ? kt + 1 < nk : true;
-    const float* a_s = As + buf * A_STAGE + wm0 + l31;
-    const float* b_s = Bs + buf * B_STAGE + wn0 + l31;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const uint32_t* a_w = Aw + buf * A_ST16 + (wm0 + l31) * 4;
+    const uint32_t* b_w = Bw + buf * B_ST16 + (wn0 + l31) * 4;
 #pragma unroll
     for (int q = 0; q < NP; q++) load_piece(na, nb, q, kt_load, tail);
 #pragma unroll
@@ -578,12 +633,10 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
       f16x8 a[TI], b[TJ];
 #pragma unroll
       for (int i = 0; i < TI; i++)
-#pragma unroll
-        for (int e = 0; e < 8; e++) a[i][e] = (_Float16)a_s[(16 * ks + 8 * lh + e) * LDA_S + 32 * i];
+        a[i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(a_w + ((2 * ks + lh) * LDA16 + 32 * i) * 4));
 #pragma unroll
       for (int j = 0; j < TJ; j++)
-#pragma unroll
-        for (int e = 0; e < 8; e++) b[j][e] = (_Float16)b_s[(16 * ks + 8 * lh + e) * LDB_S + 32 * j];
+        b[j] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(b_w + ((2 * ks + lh) * LDB16 + 32 * j) * 4));
 #pragma unroll
       for (int i = 0; i < TI; i++)
 #pragma unroll
