@@ -158,7 +158,8 @@ typedef struct sm3_gemm_desc {
   const float* rowscale;
   int32_t rows_per_scale;
   int32_t ld_aux;
-  float* colsum_out; /* EPI_GELU_BWD only, may be NULL */
+  float* colsum_out; /* NN + EPI_GELU_BWD: column sums of C per group (G, N); TN (fp32): column sums of A over each group's
+                        reduction rows (G, M) = the bias gradient next to the weight gradient dY^T X; may be NULL */
   int32_t* counters; /* ticket counters of the in-kernel split-K fix-up: sm3_gemm_f32_counter_slots() int32, ZERO on entry,
                         left zero on exit; one array per stream that may run GEMMs concurrently.  NULL: no in-kernel
                         fix-up (TN slices are then reduced by a second pass, NT/NN never slice K) */

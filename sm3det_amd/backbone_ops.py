@@ -99,6 +99,16 @@ def _tn(dy, x, M, N, rows, **kw):
     return out
 
 
+def _tn_bias(dy, x, M, N, rows, db, **kw):
+    """dW = dy^T x and db = column sums of dy in one launch: the fp32 TN kernel sums the rows of its A operand while it
+    loads them (no separate column-sum kernel, no zero-fill, dy is read once).  The fp16-operand mode keeps the
+    separate kernel."""
+    if LB.COMPUTE == 0:
+        return _tn(dy, x, M, N, rows, colsum_out=db, **kw)
+    colsum(dy, rows, M, db, offsets=kw.get('offsets'), num_groups=kw.get('num_groups', 1))
+    return _tn(dy, x, M, N, rows, **kw)
+
+
 # ------------------------------------------------------------------------------------------------ linear
 class _Linear(Function):
     @staticmethod
@@ -125,10 +135,7 @@ class _Linear(Function):
         N = w.shape[0]
         db = _e(N, like=x)
 
-        def wgrad():
-            colsum(dy, M, N, db)
-            return _tn(dy, x, N, K, M)
-        dw = _on_side(x.device, wgrad)
+        dw = _on_side(x.device, lambda: _tn_bias(dy, x, N, K, M, db))
         dx = None
         if ctx.needs_input_grad[0]:
             dx = _e(M, K, like=x)
@@ -172,9 +179,8 @@ class _LinearReLU(Function):
         if ctx.needs_input_grad[0]:
             dx = _e(M, K, like=x)
             gemm(LB.NN, dpre, w, dx, M, K, N)
-        dw = _tn(dpre, x, N, K, M)
         db = _e(N, like=x)
-        colsum(dpre, M, N, db)
+        dw = _tn_bias(dpre, x, N, K, M, db)
         return dx, dw, db
 
 
@@ -417,10 +423,7 @@ class _MoEBlock(Function):
         dev = x.device
         db2 = _e(E, C, like=x)
 
-        def wgrad2():
-            colsum(dyslot, S, C, db2, offsets=offsets, num_groups=E)
-            return _tn(dyslot, act, C, Hd, S, offsets=offsets, num_groups=E)
-        dw2 = _on_side(dev, wgrad2)
+        dw2 = _on_side(dev, lambda: _tn_bias(dyslot, act, C, Hd, S, db2, offsets=offsets, num_groups=E))
         dh, db1 = _e(S, Hd, like=x), _e(E, Hd, like=x)
         gemm(LB.NN, dyslot, w2, dh, S, Hd, C, epilogue=LB.EPI_GELU_BWD, aux_in=hpre, offsets=offsets, num_groups=E,
              colsum_out=db1)
@@ -443,7 +446,8 @@ class _MoEBlock(Function):
         linear = sim is None
 
         def gate_wgrad():
-            dwcat = _tn(dhcat, xn, PC, C, T)
+            dbcat = _e(PC, like=x)
+            dwcat = _tn_bias(dhcat, xn, PC, C, T, dbcat)
             if linear:  # d w_gate = (d hcat[:, :E])^T x,  d w_noise = (d hcat[:, P:P+E])^T x -- rows of dwcat
                 dwp.copy_(dwcat[:E].t())
                 dwn.copy_(dwcat[P:P + E].t())
@@ -454,8 +458,6 @@ class _MoEBlock(Function):
             dsn4 = _e(P, E4, like=x)
             gemm(LB.TN, hcat, dcn4, dsn4, P, E4, T, lda=PC, ldb=E4)
             dsn = dsn4 if E4 == E else dsn4[:, :E].contiguous()
-            dbcat = _e(PC, like=x)
-            colsum(dhcat, T, PC, dbcat)
             call('moe_gate_prep_bwd', dwcat, dbcat, dsn, ds_part, nblk, sim.contiguous(), temp, clamp_max, P, C, E,
                  dwp, dbp, dwn, dsim, dtemp)
         _on_side(dev, gate_wgrad)

@@ -104,7 +104,8 @@ __global__ __launch_bounds__(TCR_THREADS) void tile_colsum_reduce_kernel(const f
 template <int SL>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out,
                                                            long mn, int splits, int groups,
-                                                           const float* __restrict__ bias, int ncols, int relu) {
+                                                           const float* __restrict__ bias, int ncols, int relu,
+                                                           float* __restrict__ out2, long mn1) {
   constexpr int QB = 256 / SL;
   __shared__ f32x4 red[SL][QB];
   const int ql = threadIdx.x % QB, sl = threadIdx.x / QB;
@@ -139,19 +140,25 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 #pragma unroll
       for (int q = 0; q < 4; q++) s[q] = fmaxf(s[q], 0.f);
     }
-    *reinterpret_cast<f32x4*>(out + idx) = s;
+    // out2 != NULL: every slice carries a tail of mn - mn1 floats (TN column sums of A) that goes to its own tensor
+    if (out2 == nullptr) *reinterpret_cast<f32x4*>(out + idx) = s;
+    else if (e < mn1) *reinterpret_cast<f32x4*>(out + (idx / mn) * mn1 + e) = s;
+    else *reinterpret_cast<f32x4*>(out2 + (idx / mn) * (mn - mn1) + (e - mn1)) = s;
   }
 }
 
 void launch_splitk_reduce(const float* ws, float* out, long mn, int splits, int groups, const float* bias, int ncols,
-                          int relu, hipStream_t st) {
+                          int relu, hipStream_t st, float* out2 = nullptr, long mn1 = 0) {
   const long quads = mn * groups / 4;
   if (splits >= 64) {
-    splitk_reduce_kernel<16><<<(int)((quads + 15) / 16), 256, 0, st>>>(ws, out, mn, splits, groups, bias, ncols, relu);
+    splitk_reduce_kernel<16><<<(int)((quads + 15) / 16), 256, 0, st>>>(ws, out, mn, splits, groups, bias, ncols, relu,
+                                                                      out2, mn1);
   } else if (splits >= 8) {
-    splitk_reduce_kernel<4><<<(int)((quads + 63) / 64), 256, 0, st>>>(ws, out, mn, splits, groups, bias, ncols, relu);
+    splitk_reduce_kernel<4><<<(int)((quads + 63) / 64), 256, 0, st>>>(ws, out, mn, splits, groups, bias, ncols, relu,
+                                                                     out2, mn1);
   } else {
-    splitk_reduce_kernel<1><<<(int)((quads + 255) / 256), 256, 0, st>>>(ws, out, mn, splits, groups, bias, ncols, relu);
+    splitk_reduce_kernel<1><<<(int)((quads + 255) / 256), 256, 0, st>>>(ws, out, mn, splits, groups, bias, ncols, relu,
+                                                                       out2, mn1);
   }
 }
 
@@ -340,7 +347,8 @@ size_t slab_bytes(const sm3_gemm_desc* d, const Cfg& c) {
     const long tiles = (long)c.ntm * c.ntn * (d->mode == MODE_TN ? c.groups : 1);
     return (size_t)tiles * c.splits * c.bm * c.bn * sizeof(float);
   }
-  return (size_t)c.groups * c.splits * d->M * d->N * sizeof(float);  // TN raw slices in output layout
+  // TN raw slices in output layout (+ a tail of M column sums of A per slice when colsum_out is given)
+  return (size_t)c.groups * c.splits * ((size_t)d->M * d->N + (d->colsum_out ? d->M : 0)) * sizeof(float);
 }
 
 size_t colpart_bytes(const sm3_gemm_desc* d, const Cfg& c) {
@@ -399,16 +407,27 @@ int sm3_gemm_f32(const sm3_gemm_desc* d, void* workspace, size_t workspace_bytes
   p.colpart = cb ? (float*)((char*)workspace + sb) : nullptr;
   if (d->mode == MODE_TN) {
     float* out = d->C;
+    const long mn1 = (long)d->M * d->N;
+    const bool cs = d->colsum_out != nullptr;  // bias gradient = column sums of A, a by-product of the A loader
+    if (cs && (d->compute != 0 || c.fixup)) return SM3_ERR_UNSUPPORTED;
+    const long mn = mn1 + (cs ? d->M : 0);
     if (c.splits > 1 && !c.fixup) {  // raw slices to the workspace, separate reduce pass
       p.C = (float*)workspace;
       p.ldc = d->N;
+      p.strideC = mn;
+      p.csum = cs ? (float*)workspace + mn1 : nullptr;
+      p.csum_stride = mn;
+    } else {
+      p.csum = d->colsum_out;  // one slice: the sums are final
+      p.csum_stride = d->M;
     }
     dim3 grid(c.ntn * c.ntm, 1, c.groups * c.splits);
     const int rc = d->compute == 1 ? launch_tn16(p, c.tile, c.bk, grid, st) : launch_tn(p, c.tile, c.bk, 0, grid, st);
     if (rc) return rc;
     if (c.splits > 1 && !c.fixup) {
       if (d->ldc != d->N) return SM3_ERR_UNSUPPORTED;
-      launch_splitk_reduce((const float*)workspace, out, (long)d->M * d->N, c.splits, c.groups, nullptr, 0, 0, st);
+      launch_splitk_reduce((const float*)workspace, out, mn, c.splits, c.groups, nullptr, 0, 0, st,
+                           cs ? d->colsum_out : nullptr, mn1);
     }
     return launch_status();
   }

@@ -66,6 +66,8 @@ struct GemmParams {
   const float* aux_in;    // EPI_GELU_BWD: gelu'(h)[M,N];  EPI_BIAS_SCALE_RES: residual[M,N]
   float* aux_out;         // EPI_BIAS_GELU: gelu'(h)[M,N]; EPI_BIAS_SCALE_RES: y[M,N]
   float* colpart;         // EPI_GELU_BWD: per-row-tile column sums [row tiles][N] (bias gradient partials) or NULL
+  float* csum;            // TN (fp32): column sums of A over this launch's reduction rows -> csum[z * csum_stride + m],
+  long csum_stride;       //   z = group * splits + slice (the bias gradient as a by-product of the weight gradient) or NULL
   const float* gamma;     // [N] layer scale
   const float* rowscale;  // [M / rows_per_scale] (stochastic-depth keep/keep_prob per image) or NULL
   int rows_per_scale;
@@ -144,7 +146,7 @@ constexpr int smem_floats() {
   return 2 * BK * (lda + ldb);
 }
 
-template <int MODE, int EPI, int BK, class TL, int GATHER, int F16 = 0>
+template <int MODE, int EPI, int BK, class TL, int GATHER, int F16 = 0, int CSUM = 0>
 __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kernel(GemmParams p) {
   constexpr int BM = TL::BM, BN = TL::BN, TI = TL::TI, TJ = TL::TJ, WN = TL::WN, WM = TL::WM;
   // A tile is written transposed (k-contiguous source) in NT/NN, directly (k-major source) in TN; B transposed in NT.
@@ -502,6 +504,14 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
       }
     }
   };
+  // TN by-product: column sums of A (= the bias gradient next to the weight gradient dY^T X).  Only the workgroups of
+  // the first column tile accumulate (uniform branch around four vector adds per piece: no loads inside it); every
+  // piece passes through store_piece exactly once, already masked / zeroed where the tile does not exist.
+  // (CSUM is a template flag: hipcc turns the branch into predicated adds, which the plain TN launches must not pay)
+  const bool do_cs = CSUM && MODE == MODE_TN && p.csum != nullptr && tile_n == 0;
+  f32x4 csa[PA];
+#pragma unroll
+  for (int i = 0; i < PA; i++) csa[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   // live == false (uniform, tail steps only): the tile does not exist (index >= nk) and zeros are stored instead -- the
   // k-loop runs an even number of steps without a branch between them, so the step after the last tile of an odd nk
   // multiplies this all-zero stage
@@ -510,6 +520,7 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
     f32x4 ra[PA], rb[PB];
     if (q < PA) ra[q] = live ? ra_[q] : z4;
     else rb[q - PA] = live ? rb_[q - PA] : z4;
+    if (CSUM && q < PA && do_cs) csa[q] += ra[q];
     typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
     auto pack2 = [](float x, float y) {  // round-to-nearest-even, like a torch .half() cast
       return __builtin_bit_cast(uint32_t, f16x2{(_Float16)x, (_Float16)y});
@@ -671,6 +682,24 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
       k_step(sa0, sb0, sa1, sb1, kt, true);
       k_step(sa1, sb1, sa0, sb0, kt + 1, true);
     }
+  }
+
+  if (CSUM && do_cs) {  // fold the k rows of the tile through LDS (free after the loop)
+    constexpr int QRc = BM / 4;
+    float* red = smem;  // [BK][BM + 4]
+#pragma unroll
+    for (int i = 0; i < PA; i++) {
+      const int idx = tid + NTHREADS * i;
+      if (idx < BK * QRc) *reinterpret_cast<f32x4*>(red + (idx / QRc) * (BM + 4) + 4 * (idx % QRc)) = csa[i];
+    }
+    __syncthreads();
+    if (tid < BM && m0 + tid < p.M) {
+      float t = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < BK; kk++) t += red[kk * (BM + 4) + tid];
+      p.csum[(long)blockIdx.z * p.csum_stride + m0 + tid] = t;
+    }
+    __syncthreads();  // the epilogue stages through the same memory
   }
 
   // ---- split-K fix-up: publish this slice, the last arriver of the tile sums all slices in order ------------

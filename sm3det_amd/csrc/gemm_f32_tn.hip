@@ -6,7 +6,8 @@ namespace sm3gemm {
 
 template <int BK, class TL>
 static void go(const GemmParams& p, dim3 grid, hipStream_t st) {
-  gemm_f32_kernel<MODE_TN, EPI_NONE, BK, TL, 0><<<grid, NTHREADS, 0, st>>>(p);
+  if (p.csum) gemm_f32_kernel<MODE_TN, EPI_NONE, BK, TL, 0, 0, 1><<<grid, NTHREADS, 0, st>>>(p);  // + column sums of A
+  else gemm_f32_kernel<MODE_TN, EPI_NONE, BK, TL, 0><<<grid, NTHREADS, 0, st>>>(p);
 }
 
 int launch_tn(const GemmParams& p, int tile, int bk, int gather, dim3 grid, hipStream_t st) {

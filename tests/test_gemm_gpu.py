@@ -351,3 +351,24 @@ def test_every_epilogue_kind_on_every_tile(tile, bk):
             C = torch.full((M, N), float('nan'), device='cuda')
             LB.gemm(LB.NT, A, B, C, M, N, K, epilogue=epi, bias=bias if epi != LB.EPI_NONE else None)
             _close(C, f(y64))
+
+
+@pytest.mark.parametrize('splits', [0, 1, 3, 16])
+@pytest.mark.parametrize('E,counts,M,N', [(1, [5000], 96, 384), (1, [777], 384, 96), (8, [300, 0, 129, 1, 128, 500, 64, 7], 384, 96),
+                                          (4, [0, 0, 0, 1000], 224, 384), (1, [4096], 32, 256)])
+def test_tn_column_sums_of_a_as_a_by_product(E, counts, M, N, splits):
+    """TN with colsum_out: dW[g] = A_g^T B_g and db[g] = column sums of A_g from the same launch (bias gradient next to
+    the weight gradient), any slice count, ragged / empty groups, tile edges (M = 224, 32)."""
+    LB = _mods()
+    S = sum(counts)
+    A, B = _rand(S, M, seed=31), _rand(S, N, seed=32)
+    offs = torch.tensor(np.concatenate([[0], np.cumsum(counts)]), dtype=torch.int32, device='cuda') if E > 1 else None
+    dW = torch.full((E, M, N), float('nan'), device='cuda')
+    db = torch.full((E, M), float('nan'), device='cuda')
+    kw = dict(offsets=offs, num_groups=E) if E > 1 else {}
+    LB.gemm(LB.TN, A, B, dW, M, N, S, colsum_out=db, splits=splits, **kw)
+    bounds = np.concatenate([[0], np.cumsum(counts)])
+    refw = torch.stack([A[bounds[e]:bounds[e + 1]].double().t() @ B[bounds[e]:bounds[e + 1]].double() for e in range(E)])
+    refb = torch.stack([A[bounds[e]:bounds[e + 1]].double().sum(0) for e in range(E)])
+    _close(dW, refw)
+    assert (db.double() - refb).abs().max().item() <= 1e-4 * (refb.abs().max().item() + 1e-12) + 1e-6
