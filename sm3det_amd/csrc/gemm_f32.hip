@@ -601,7 +601,7 @@ int sm3_conv3x3_nhwc_bwd_weight(const float* x, const float* dy, float* dw, int 
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM), 1, p.splits);
   p.fixup = 0;
-  const int rc = launch_tn(p, 0, 16, 1, grid, st);
+  const int rc = launch_tn(p, 0, 16, (Wo % 16) == 0 ? 2 : 1, grid, st);
   if (rc) return rc;
   launch_splitk_reduce((const float*)workspace, dw, (long)p.M * p.N, p.splits, 1, nullptr, 0, 0, st);
   return launch_status();

@@ -374,6 +374,9 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
         if (GATHER) {
           tn_tap = n0 / p.cC;
           pb[i] = Bg + (nc - tn_tap * p.cC);  // channel offset inside the tap; the row part is added per load
+          // GATHER == 2 (rW % BK == 0: a k-tile of BK output positions lies inside one image row, so its first source
+          // pixel is the same for every lane): lane part = this lane's position inside the k-tile + channel offset
+          ob[i] = (unsigned)(((long)min(kk, BK - 1) * p.cS * p.cC + (nc - tn_tap * p.cC)) * 4);
         } else {
           pb[i] = Bg + nc;
           ob[i] = (unsigned)(((long)min(kk, BK - 1) * p.ldb + nc) * 4);
@@ -395,6 +398,7 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
   }
   if (MODE == MODE_NT) b_base = reinterpret_cast<const char*>(Bg + (long)n0 * p.ldb + (long)kbase * BK);
   else if (MODE == MODE_NN) b_base = reinterpret_cast<const char*>(Bg + (GATHER ? 0 : (long)kbase * BK * p.ldb));
+  else if (GATHER == 2) b_base = reinterpret_cast<const char*>(Bg) - (long)(p.sW + 1) * p.cC * 4;
   else b_base = reinterpret_cast<const char*>(Bg + (long)row0 * p.ldb);
   // piece q in [0, NP): q < PA -> A piece q, else B piece q - PA.  tail == false (the bulk of the k-loop): tile kt is a
   // complete tile strictly before the last one, so no clamp and no select is issued; tail == true: the last steps, where
@@ -414,6 +418,7 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
     a_valid = (long)(row_end - 1 - row0) * p.lda + p.M;
     b_valid = (long)(row_end - 1 - row0) * p.ldb + p.N;
     if (row_end <= row0) a_valid = b_valid = 0;
+    if (GATHER == 2) b_valid = (long)(p.K / (p.rH * p.rW)) * p.sH * p.sW * p.cC + (long)(p.sW + 1) * p.cC;
   } else if (GATHER) {
     // gathered tensor: (M / (rH * rW)) images of sH x sW x cC, seen from the shifted base; NN weights: cC rows of ldb
     a_valid = (long)(p.M / (p.rH * p.rW)) * p.sH * p.sW * p.cC + (long)(p.sW + 1) * p.cC;
@@ -463,7 +468,20 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
     } else {
       const int i = q - PA;
       if (MODE == MODE_TN) {
-        if (GATHER) {
+        if (GATHER == 2) {
+          // the k-tile's first output position and its source pixel on the scalar unit; per lane only the x-range test
+          const int r0 = row0 + kt * BK;
+          const unsigned t = fast_div((unsigned)r0, (unsigned)p.rW, p.mRW);
+          const int oxb = r0 - (int)t * p.rW;
+          const unsigned b = fast_div(t, (unsigned)p.rH, p.mRH);
+          const int oy = (int)t - (int)b * p.rH;
+          const int dy = tn_tap / 3, dx = tn_tap - 3 * dy;
+          const int syp = oy * p.cS + dy;  // source row + 1 (the base is shifted by one row and one pixel)
+          const bool yok = syp >= 1 && syp <= p.sH;
+          const long soff = ((((long)b * p.sH + syp) * p.sW + oxb * p.cS + dx) * p.cC) * 4;
+          const int sx = (oxb + kb[i]) * p.cS + dx - 1;
+          rb[i] = ldg(b_rsrc, soff, (yok && sx >= 0 && sx < p.sW) ? ob[i] : 0x7fff0000u);
+        } else if (GATHER) {
           const int kr = row0 + kt * BK + kb[i];
           const int krc = min(kr, row_end - 1);
           // reduction row = output position (b, oy, ox); B row = the input pixel this N-tile's tap reads for it

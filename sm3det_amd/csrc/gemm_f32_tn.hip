@@ -11,9 +11,10 @@ static void go(const GemmParams& p, dim3 grid, hipStream_t st) {
 }
 
 int launch_tn(const GemmParams& p, int tile, int bk, int gather, dim3 grid, hipStream_t st) {
-  if (gather) {
+  if (gather) {  // 2: every k-tile lies inside one image row (rW % 16 == 0): scalar source-pixel arithmetic
     if (tile != 0 || bk != 16) return SM3_ERR_INVALID_ARG;
-    gemm_f32_kernel<MODE_TN, EPI_NONE, 16, T128x128, 1><<<grid, NTHREADS, 0, st>>>(p);
+    if (gather == 2) gemm_f32_kernel<MODE_TN, EPI_NONE, 16, T128x128, 2><<<grid, NTHREADS, 0, st>>>(p);
+    else gemm_f32_kernel<MODE_TN, EPI_NONE, 16, T128x128, 1><<<grid, NTHREADS, 0, st>>>(p);
     return SM3_OK;
   }
   switch (tile * 100 + bk) {
