@@ -163,7 +163,7 @@ void launch_splitk_reduce(const float* ws, float* out, long mn, int splits, int 
 }
 
 // Column sums over row segments (bias gradients): out[g][n] += sum_{r in seg g} X[r][n]; `out` is zeroed by the
-// caller (memset on the same stream).  Block = 16 column quads (64 columns, 16 B per lane) x 16 row lanes; row
+// wrapper below (a zero-fill kernel on the same stream).  Block = 16 column quads (64 columns, 16 B per lane) x 16 row lanes; row
 // chunks are combined with fp32 L2 atomics (<= COLSUM_SPLITS adds per address).
 constexpr int COLSUM_SPLITS = 128;
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int ld, int N,

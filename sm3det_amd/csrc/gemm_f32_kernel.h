@@ -28,6 +28,15 @@
 // last-arriving block of a tile sums the slabs in slice order (deterministic) and runs the epilogue -- no second
 // kernel, no second pass over the output (cdna_hip_programming.md, in-launch split-K recipe).  The ticket counters
 // are a caller-provided zeroed array that the kernel leaves zeroed.
+//
+// The k-loop carries no vector-ALU work (every VALU instruction issued between the MFMAs of a SIMD takes issue time from
+// them): operands are addressed as buffer descriptor (SGPRs) + scalar k offset + a per-lane 32-bit offset fixed for the
+// whole loop; clamps, the TN row mask and the zero stage of an odd trip count live in a `tail` variant of the step that
+// runs the last 3-4 k-tiles only; two steps per iteration with no branch between them; lanes past a tile edge repeat the
+// tile's last row into the same LDS slot.  GATHER (implicit-GEMM 3x3 convolution) splits the source pixel into a per-row
+// part and a per-tap part that is equal for all lanes; masked taps read past the descriptor's extent (hardware zero).
+// F16 = 1 keeps fp32 tensors in HBM and an fp16 image in LDS (v_mfma_f32_32x32x16_f16, fp32 accumulation).
+// CSUM = 1 (TN): the workgroups of the first column tile also sum the rows of A they load (bias gradient).
 #pragma once
 #include "common.h"
 
