@@ -1,9 +1,17 @@
 #!/usr/bin/env python
 """bench.py -- headline benchmark of the SM3Det hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]            (N=1)
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config NAME] [--amp]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W                  (N>1, one rank per GPU over RCCL)
+
+`python bench.py --gpus N` with N > 1 and no torchrun environment launches its own N ranks (it re-executes itself under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`, the launch line of the reference's
+tools/dist_train.sh) and relays rank 0's JSON line, so both command forms work.  `--config` selects one of the BASELINE.json
+configurations from sm3det_amd/configs/baseline_configs.json (generated from the reference's own config files by
+scripts/make_bench_configs.py): main_SM3Det (#2, the default and the headline), SM3Det_convnext_t (#3, AMP), e16t2 (#4),
+SM3Det_convnext_b (#5, AMP), simple_joint (#1, no MoE); a config whose file sets `fp16 = dict(loss_scale='dynamic')` runs
+the AMP data path, `--amp` forces it on any config.
 
 Metric (BASELINE.json): train imgs/sec, SM3Det ConvNeXt-T e8t2 @1024^2, bs2/GPU.
 Workload timed here (config.workload): one TRAINING STEP of the hot path = the `main_SM3Det.py` backbone
@@ -36,21 +44,50 @@ sys.path.insert(0, ROOT)
 
 MI355X_FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
 MI355X_HBM_PEAK_GBS = 8000.0  # same guide: HBM3E ~8 TB/s
-BACKBONE_CFG = dict(arch='tiny', MoE_Block_inds=[[], [0, 2], [0, 2, 4, 6, 8], [0, 2]], num_experts=8, top_k=2,
-                    drop_path_rate=0.1)  # local_configs/main_SM3Det.py:13-21
 BATCH = 2
 RES = int(os.environ.get('SM3_BENCH_RES', '1024'))  # 1024 = BASELINE config; the override is a debugging aid only
+CONFIG_FILE = os.path.join(ROOT, 'sm3det_amd', 'configs', 'baseline_configs.json')
+DEFAULT_CONFIG = 'main_SM3Det'  # BASELINE.json config #2: the configuration `metric` is quoted on
 
 
-def build_model():
-    from sm3det_amd.convnext_moe import ConvNeXt_moe_MultiInput
+def load_config(name):
+    """one entry of sm3det_amd/configs/baseline_configs.json: the `model` / `fp16` / `optimizer` dicts of a reference
+    config file, exactly as mmcv.Config.fromfile yields them (scripts/make_bench_configs.py; the reference tree itself is
+    absent on the GPU box)"""
+    with open(CONFIG_FILE) as f:
+        cfgs = json.load(f)
+    if name not in cfgs:
+        raise SystemExit(f'--config {name!r}: choose from {sorted(cfgs)}')
+    return cfgs[name]
+
+
+def backbone_cfg(name):
+    bb = dict(load_config(name)['model']['backbone'])
+    bb.pop('init_cfg', None)  # Pretrained checkpoint path: no checkpoints exist here, weights are random-init
+    return bb
+
+
+def build_model(name=DEFAULT_CONFIG):
+    """the backbone of reference config `name`, built through the registry from the config file's own dict"""
+    from sm3det_amd import convnext_moe  # noqa: F401  (registers the classes)
+    from sm3det_amd.registry import MODELS
     torch.manual_seed(0)
-    net = ConvNeXt_moe_MultiInput(**BACKBONE_CFG)
+    net = MODELS.build(backbone_cfg(name))
     with torch.no_grad():  # layer scale 1e-6 would hide the FFN/MoE branch numerically; use O(1) like a trained net
         for n, p in net.named_parameters():
             if n.endswith('gamma'):
                 p.fill_(1.0)
     return net
+
+
+def describe_backbone(net):
+    blocks = [b for st in net.stages for b in st]
+    n_moe = sum(1 for b in blocks if b.MoE_cfg is not None)
+    arch = {tuple(v['channels']): k for k, v in type(net).arch_settings.items() if v['depths'] == list(net.depths)}
+    moe = next((b.ffn for b in blocks if b.MoE_cfg is not None), None)
+    return dict(arch=arch.get(tuple(net.channels), str(net.channels)), moe_blocks=n_moe, dense_blocks=len(blocks) - n_moe,
+                experts=(moe.num_experts if moe is not None else 0), top_k=(moe.k if moe is not None else 0),
+                params_m=round(sum(p.numel() for p in net.parameters()) / 1e6, 2))
 
 
 def loss_fn(outs, gate_loss, proj):
@@ -63,7 +100,7 @@ def loss_fn(outs, gate_loss, proj):
 CPU_THREADS = (8, 16, 32, 64)
 
 
-def _cpu_worker(kind):
+def _cpu_worker(kind, cfg_name=DEFAULT_CONFIG):
     """Runs in a SUBPROCESS with OMP_NUM_THREADS fixed before torch is imported (resizing torch's thread pool inside
     a live process stalled on the 128-thread host in round 1).  `step`: the CPU oracle (oracle/moe_oracle.py, the
     restatement of the reference module that tests pin to it) doing the bench's training step (fwd+bwd, fp32) on
@@ -72,24 +109,28 @@ def _cpu_worker(kind):
     out = {'threads': torch.get_num_threads()}
     if kind == 'step':
         from oracle import moe_oracle as MO
-        net = build_model()
+        net = build_model(cfg_name)
+        bcfg = backbone_cfg(cfg_name)
+        inds = bcfg.get('MoE_Block_inds', [[], [], [], []])
+        E, topk = bcfg.get('num_experts', 2), bcfg.get('top_k', 2)
         p = {k: v.detach().clone().requires_grad_(v.is_floating_point() and not k.endswith(('.mean', '.std')))
              for k, v in net.state_dict().items()}
         g = torch.Generator().manual_seed(0)
-        kw = dict(arch='tiny', moe_block_inds=BACKBONE_CFG['MoE_Block_inds'], num_experts=8, top_k=2, train=True)
+        kw = dict(arch=bcfg['arch'], moe_block_inds=inds, num_experts=E, top_k=topk, train=True)
 
         def run(b, res):
             x = torch.randn(b, 3, res, res, generator=g)
             toks, H = [], res // 4
-            for i, inds in enumerate(BACKBONE_CFG['MoE_Block_inds']):
+            for i, ii in enumerate(inds):
                 if i > 0:
                     H //= 2
-                toks += [b * H * H] * len(inds)
-            noise = [torch.randn(t, 8, generator=g) for t in toks]
+                toks += [b * H * H] * len([q for q in ii if q < net.depths[i]])
+            noise = [torch.randn(t, E, generator=g) for t in toks]
             for v in p.values():
                 v.grad = None
             t0 = time.perf_counter()
-            outs, gl = MO.backbone_forward(x, p, noise=noise, **kw)
+            res_ = MO.backbone_forward(x, p, noise=noise, **kw)
+            outs, gl = res_ if toks else (res_, 0.0)
             (sum((o * o).mean() for o in outs) + gl).backward()
             return time.perf_counter() - t0
         run(1, 512)
@@ -135,7 +176,7 @@ def _cpu_worker(kind):
     print('CPUWORKER ' + json.dumps(out), flush=True)
 
 
-def cpu_baseline():
+def cpu_baseline(cfg_name=DEFAULT_CONFIG):
     """`cpu_baseline` of the bench line: the same training step on this host's cores, one subprocess per thread count
     (SURVEY.md 8(d) protocol), best value reported with its thread count; plus the reference CPU ops per shape."""
     import subprocess
@@ -144,7 +185,7 @@ def cpu_baseline():
         env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), CUDA_VISIBLE_DEVICES='',
                    HIP_VISIBLE_DEVICES='')
         try:
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-worker', kind], env=env,
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-worker', kind, '--config', cfg_name], env=env,
                                capture_output=True, text=True, timeout=420)
             for line in r.stdout.splitlines():
                 if line.startswith('CPUWORKER '):
@@ -155,7 +196,9 @@ def cpu_baseline():
 
     ncpu = os.cpu_count() or 8
     per_threads, best = {}, None
-    for t in [t for t in CPU_THREADS if t <= ncpu] or [ncpu]:
+    # the headline config sweeps the thread counts; the others (bigger models, same protocol) use the one that won there
+    counts = CPU_THREADS if cfg_name == DEFAULT_CONFIG else (16,)
+    for t in [t for t in counts if t <= ncpu] or [ncpu]:
         w = worker('step', t)
         if 'step_seconds' in w:
             sec = sorted(w['step_seconds'])[1]  # median of the 3 timed steps
@@ -386,6 +429,22 @@ def ops_microbench():
     return {k: round(v, 1) for k, v in out.items()}
 
 
+def _self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this very command line under torch.distributed.run
+    (one process per GPU, rendezvous on 127.0.0.1 -- tools/dist_train.sh:8-19 of the reference does the same with
+    torch.distributed.launch) and relay what they print; rank 0 prints the JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:  # a free port for this job (several benches may share a host)
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr',
+           '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, OMP_NUM_THREADS=os.environ.get('OMP_NUM_THREADS', '8'))
+    r = subprocess.run(cmd, env=env)
+    sys.exit(r.returncode)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -394,19 +453,28 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-ops', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a captured hipGraph')
-    ap.add_argument('--amp', action='store_true', help='BASELINE config #3 arithmetic: fp16 GEMM operands (fp32 '
-                    'accumulation) + dynamic loss scaling; reported as its own dtype, never mixed with the fp32 line')
+    ap.add_argument('--config', default=DEFAULT_CONFIG, help='BASELINE.json configuration (a key of '
+                    'sm3det_amd/configs/baseline_configs.json): main_SM3Det (#2, default), SM3Det_convnext_t (#3), e16t2 (#4), '
+                    'SM3Det_convnext_b (#5), simple_joint (#1)')
+    ap.add_argument('--amp', action='store_true', help='mixed precision (the `fp16 = dict(loss_scale="dynamic")` switch of '
+                    'configs #3 / #5; implied by --config SM3Det_convnext_{t,b}): fp16 activations and GEMM operands, fp32 '
+                    'accumulation / master weights / LayerNorm / router / combine, dynamic loss scale; reported as its own '
+                    'dtype, never mixed with the fp32 line')
     ap.add_argument('--cpu-worker', choices=['step', 'ops'], help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_worker:
-        return _cpu_worker(args.cpu_worker)
+        return _cpu_worker(args.cpu_worker, args.config)
+    cfg_entry = load_config(args.config)
+    args.amp = bool(args.amp or cfg_entry.get('fp16'))
 
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        return _self_launch(args.gpus)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f'--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}')
-    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    if args.gpus != world:
+        raise SystemExit(f'--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks')
     # SM3_BENCH_BACKEND=gloo lets two ranks share ONE GPU (the 1-GPU dev box) to exercise the N>1 control flow --
     # graph A + bucket pack, eager all-reduce, graph B on the reduced buckets -- without RCCL; never used for numbers.
     backend = os.environ.get('SM3_BENCH_BACKEND', 'nccl')
@@ -432,7 +500,8 @@ def main():
     from sm3det_amd.data_parallel import BucketedGradReducer
     _lib.lib()  # fail loudly if the HIP extension is missing
 
-    net = build_model().cuda().train()
+    net = build_model(args.config).cuda().train()
+    desc = describe_backbone(net)
     if args.amp:
         from sm3det_amd import amp
         amp.wrap_fp16_model(net)  # what Fp16OptimizerHook.before_run does (mmcv/mmcv/runner/hooks/optimizer.py:245-249)
@@ -457,10 +526,16 @@ def main():
     x = torch.randn(BATCH, 3, RES, RES, generator=g).cuda()
     proj = None
 
+    zero = torch.zeros((), device='cuda')
+
+    def forward():
+        r = net(x, ['single'])
+        return r if desc['moe_blocks'] else (r, zero)  # config #1 has no MoE block: no gate loss
+
     def step():
         nonlocal proj
         reducer.zero_grad()
-        outs, gl = net(x, ['single'])
+        outs, gl = forward()
         if proj is None:
             gp = torch.Generator(device='cpu').manual_seed(1000 + rank)
             proj = [torch.randn(o.shape, generator=gp).cuda().contiguous(memory_format=torch.channels_last)
@@ -490,7 +565,7 @@ def main():
 
         def fwd_bwd():
             reducer.zero_grad()
-            outs, gl = net(x, ['single'])
+            outs, gl = forward()
             l = loss_fn(outs, gl, proj)
             opt.scale(l).backward()
             reducer.pack_all()
@@ -499,10 +574,11 @@ def main():
         def seg_late():
             """forward + backward of everything above the stage-1 output (tokens `hb`); same loss, split by term"""
             reducer.zero_grad()
-            outs, _ = net(x, ['single'])
+            outs, _ = forward()
             terms, hb = net._gate_loss_terms, net._boundary_tokens
-            l_late = sum(g for i, g in terms if i >= 2) / len(terms)
-            l_early = sum(g for i, g in terms if i < 2) / len(terms)
+            nt = max(len(terms), 1)
+            l_late = sum((g for i, g in terms if i >= 2), zero) / nt
+            l_early = sum((g for i, g in terms if i < 2), zero) / nt
             for i, (o, r) in enumerate(zip(outs, proj)):
                 t = (o * r).sum() * 1e-4
                 if i >= 2:
@@ -666,16 +742,22 @@ def main():
 
     result = None
     if rank == 0:
+        arch_name = {'tiny': 'ConvNeXt-T', 'base': 'ConvNeXt-B', 'small': 'ConvNeXt-S'}.get(desc['arch'], desc['arch'])
+        moe_name = f"e{desc['experts']}t{desc['top_k']}" if desc['moe_blocks'] else 'dense'
         result = {
-            'metric': 'train imgs/sec SM3Det ConvNeXt-T e8t2 @1024^2 bs2/GPU (hot path: MoE backbone train step)',
+            'metric': f'train imgs/sec SM3Det {arch_name} {moe_name} @{RES}^2 bs{BATCH}/GPU (hot path: MoE backbone train step)',
             'value': round(value, 3), 'unit': 'imgs/sec', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16' if args.amp else 'f32', 'data': 'synthetic',
-            'config': {'workload': ('SM3Det_convnext_t.py (AMP: fp16 GEMM operands, fp32 accumulate / master weights / '
-                                    'LayerNorm / router / combine, dynamic loss scale) = ' if args.amp else '') +
-                                   'main_SM3Det.py backbone (ConvNeXt_moe_MultiInput tiny, 8 experts top-2, 9 MoE + 9 '
-                                   'dense blocks) fwd+bwd + bucketed grad all-reduce + grad-clip(35)+AdamW (per-parameter lr); synthetic '
-                                   f'randn({BATCH},3,{RES},{RES}) per GPU, random-init weights; neck/heads timed separately in ops_us',
+            'config': {'workload': (f"{cfg_entry['file']} (BASELINE.json config #{cfg_entry['baseline_config']}) backbone, built "
+                                    f"from the config file's own dict: ConvNeXt_moe_MultiInput {desc['arch']}, "
+                                    f"{desc['experts']} experts top-{desc['top_k']}, {desc['moe_blocks']} MoE + "
+                                    f"{desc['dense_blocks']} dense blocks, {desc['params_m']} M parameters; " +
+                                    ('AMP (fp16 = dict(loss_scale="dynamic")): fp16 activations / GEMM operands, fp32 accumulate / '
+                                     'master weights / LayerNorm / router / combine, dynamic loss scale; ' if args.amp else '') +
+                                    'fwd+bwd + bucketed grad all-reduce + grad-clip(35)+AdamW (per-parameter lr); synthetic '
+                                    f'randn({BATCH},3,{RES},{RES}) per GPU, random-init weights; neck/heads timed separately in ops_us'),
+                       'name': args.config, 'baseline_config': cfg_entry['baseline_config'], 'backbone': desc,
                        'global_batch': world * BATCH, 'resolution': RES, 'parallelism': f'dp{world}',
                        'grad_buckets': reducer.num_buckets, 'hip_graph': bool(use_graph),
                        'wgrad_side_stream': bool(overlap_was), 'split_backward': bool(split and use_graph),
@@ -694,7 +776,7 @@ def main():
         if world == 1 and not args.no_ops:
             result['ops_us'] = ops_microbench()
         if world == 1 and not args.no_cpu_baseline:
-            result['cpu_baseline'] = cpu_baseline()
+            result['cpu_baseline'] = cpu_baseline(args.config)
         else:
             result['cpu_baseline'] = None
         print(json.dumps(result), flush=True)

@@ -26,12 +26,19 @@ TINY_E8 = dict(arch='tiny', MoE_Block_inds=[[], [0, 2], [0, 2, 4, 6, 8], [0, 2]]
 TINY_E16 = dict(arch='tiny', MoE_Block_inds=[[], [], [0, 2, 4, 6, 8], [0, 2]], num_experts=16, top_k=2,
                 drop_path_rate=0.1)  # ablation_moe_et_*e16t2_last2blocks.py (BASELINE config #4)
 
+BASE_E8 = dict(arch='base', MoE_Block_inds=[[], [0, 2], [i * 2 for i in range(14)], [0, 2]], num_experts=8, top_k=2,
+               drop_path_rate=0.1)   # local_configs/SM3Det_convnext_b.py:13-20 (BASELINE config #5: 18 MoE + 18 dense blocks)
+
 CASES = {
     'full_e8t2_b1': dict(cfg=TINY_E8, batch=1, res=1024, seed=11),
     'full_e8t2_b2': dict(cfg=TINY_E8, batch=2, res=1024, seed=12),   # the headline configuration
     'full_e16t2_b1': dict(cfg=TINY_E16, batch=1, res=1024, seed=13),
+    'full_e16t2_b2': dict(cfg=TINY_E16, batch=2, res=1024, seed=14),  # config #4 at its per-GPU batch
+    'full_base_b1': dict(cfg=BASE_E8, batch=1, res=1024, seed=15),    # config #5 (ConvNeXt-B, C = 128..1024)
 }
-ARCH_TINY = dict(depths=[3, 3, 9, 3], channels=[96, 192, 384, 768])
+ARCHS = {'tiny': dict(depths=[3, 3, 9, 3], channels=[96, 192, 384, 768]),
+         'base': dict(depths=[3, 3, 27, 3], channels=[128, 256, 512, 1024])}
+ARCH_TINY = ARCHS['tiny']
 N_OUT_SAMPLES, N_GRAD_SAMPLES, SMALL_TENSOR = 8192, 512, 768
 FRAGILE_REL_GAP = 1e-3  # tokens whose top-k margin / logit scale is below this are listed in the fixture
 
@@ -76,7 +83,7 @@ def moe_token_counts(cfg, batch, res):
     for i, inds in enumerate(cfg['MoE_Block_inds']):
         if i > 0:
             H //= 2
-        out += [batch * H * H] * len([q for q in inds if q < ARCH_TINY['depths'][i]])
+        out += [batch * H * H] * len([q for q in inds if q < ARCHS[cfg['arch']]['depths'][i]])
     return out
 
 
@@ -88,7 +95,7 @@ def make_inputs(case, noise_seed=None):
     ns = seed if noise_seed is None else noise_seed
     noise = [torch.randn(t, cfg['num_experts'], generator=_gen(f'noise{j}', ns))
              for j, t in enumerate(moe_token_counts(cfg, B, res))]
-    nblocks = sum(ARCH_TINY['depths'])
+    nblocks = sum(ARCHS[cfg['arch']]['depths'])
     dpr = torch.linspace(0, cfg['drop_path_rate'], nblocks).tolist()
     drop = []
     for j, r in enumerate(dpr):

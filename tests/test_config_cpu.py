@@ -90,3 +90,20 @@ def test_delete_key_and_duplicate_base_keys(tmp_path):
     (tmp_path / 'a2.py').write_text("lr = 0.2\n")
     with pytest.raises(KeyError):
         Config.fromfile(str(tmp_path / 'c.py'))
+
+
+def test_committed_bench_config_fixture_equals_the_live_reference_configs():
+    """sm3det_amd/configs/baseline_configs.json (what `bench.py --config` reads on the GPU box, where the reference tree
+    is absent) is exactly what scripts/make_bench_configs.py derives from the reference files today."""
+    import importlib.util
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('make_bench_configs', os.path.join(root, 'scripts', 'make_bench_configs.py'))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    with open(m.OUT) as f:
+        committed = json.load(f)
+    assert committed == json.loads(json.dumps(m.derive()))
+    assert committed['main_SM3Det']['model']['backbone']['MoE_Block_inds'] == [[], [0, 2], [0, 2, 4, 6, 8], [0, 2]]
+    assert committed['SM3Det_convnext_b']['fp16'] == {'loss_scale': 'dynamic'}
+    assert committed['e16t2']['model']['backbone']['num_experts'] == 16

@@ -19,11 +19,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _bench(extra_env):
+def _bench(extra_env, extra=()):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', MASTER_ADDR='127.0.0.1', MASTER_PORT='29541', RANK='0',
                LOCAL_RANK='0', WORLD_SIZE='1', SM3_BENCH_RES='512', **extra_env)
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1',
-                        '--no-ops', '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=600)
+                        '--no-ops', '--no-cpu-baseline'] + list(extra), env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1]
     return json.loads(line), r.stderr
@@ -40,3 +40,36 @@ def test_split_backward_graph_replay_with_rccl_collectives_world_size_1():
     assert plain['config']['dist_backend'] is None and plain['config']['split_backward'] is False
     # identical data, seeds and step count: the averaged (1-rank) gradients are the gradients
     assert abs(dist_run['loss'] - plain['loss']) <= 1e-4 * max(1.0, abs(plain['loss'])), (dist_run['loss'], plain['loss'])
+
+
+def test_bench_gpus2_self_launch_two_ranks_gloo_on_one_gpu():
+    """`python bench.py --gpus 2` with no launcher: the script starts its own two ranks (torch.distributed.run on
+    127.0.0.1) -- the form the driver's SCALE command uses.  On the 1-GPU test box the two ranks share the GPU and talk
+    over gloo (SM3_BENCH_BACKEND=gloo: same entry, same graph replay + split backward + finalize flow, host-staged
+    collectives instead of RCCL), each with its own synthetic shard; rank 0 prints ONE JSON line with n_gpus = 2 and the
+    replicas must stay identical (same averaged gradients applied on both)."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY='0', SM3_BENCH_RES='512', SM3_BENCH_BACKEND='gloo')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+                        '--no-ops', '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    cfg = out['config']
+    assert out['n_gpus'] == 2 and cfg['global_batch'] == 4 and cfg['parallelism'] == 'dp2'
+    assert cfg['dist_backend'] == 'gloo' and cfg['grad_buckets'] >= 2
+    assert cfg['hip_graph'] is True and cfg['split_backward'] is True, r.stderr[-2000:]
+    assert abs(cfg['replica_checksum_spread']) <= 1e-6 * 1e5, cfg  # checksum ~1e5: replicas equal to fp64 rounding
+    assert out['value'] > 0 and out['loss'] == out['loss']
+
+
+@pytest.mark.parametrize('config,amp', [('e16t2', False), ('SM3Det_convnext_b', True), ('simple_joint', False)])
+def test_bench_other_baseline_configs_run(config, amp):
+    """`bench.py --config NAME`: the other BASELINE.json configurations are built from the committed copy of the
+    reference's config dicts and step through the same graph-replayed training step (reduced resolution here; the
+    full-size lines are collected under profiles/)."""
+    out, err = _bench({}, extra=['--config', config])
+    assert out['config']['name'] == config and out['dtype'] == ('f16' if amp else 'f32')
+    assert out['config']['hip_graph'] is True, err[-1500:]
+    assert out['loss'] == out['loss'] and out['value'] > 0
