@@ -205,6 +205,9 @@ int sm3_sumpool2x_add(const float* dfine, const float* base, float* dcoarse, int
  * where the mmcv._ext boundary hands NCHW tensors to a kernel whose scatter pattern wants NHWC (RoIAlignRotated
  * backward: 4.1 ms on NCHW vs 0.41 ms on NHWC for 512 RoIs on a 256x256x256 level). */
 int sm3_transpose_f32(const float* src, float* dst, int batch, int rows, int cols, sm3_stream_t stream);
+/* dst[b][c][r] += src[b][r][c]: the accumulate form (the reference kernel atomically ADDS into grad_input,
+ * roi_align_rotated_cuda_kernel.cuh:129-200, so a caller-provided non-zero grad_input must survive). */
+int sm3_transpose_add_f32(const float* src, float* dst, int batch, int rows, int cols, sm3_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * MaxIoU target assignment: mmdet MaxIoUAssigner.assign_wrt_overlaps as configured by

@@ -32,6 +32,7 @@ def _declare(lib):
         'sm3_error_string': (ctypes.c_char_p, [I]),
         'sm3_box_iou_rotated': (I, [P, P, P, I, I, I, I, P]),
         'sm3_transpose_f32': (I, [P, P, I, I, I, P]),
+        'sm3_transpose_add_f32': (I, [P, P, I, I, I, P]),
         'sm3_max_iou_assign_workspace_bytes': (S, [I, I]),
         'sm3_max_iou_assign': (I, [P, I, I, P, I, I, I, F, F, F, I, P, P, P, P, P, S, P]),
         'sm3_argsort_desc_workspace_bytes': (S, [I]),

@@ -123,16 +123,42 @@ COMPUTE = 0  # 0: fp32 operands; 1: fp16 operands / fp32 accumulation (set by sm
 TUNING = int(__import__('os').environ.get('SM3_GEMM_TUNING', '0'))  # benchmarking override forwarded to sm3_gemm_desc.tuning (scripts/gemm_sweep2.py); 0 in production
 
 
+_SPARE = {}
+_SPARE_COUNT = 8
+
+
 def gemm_counters(device):
     """The zeroed ticket-counter array of the in-kernel split-K fix-up for torch's CURRENT stream on `device` (GEMMs on
     one stream run in order and may share it; the weight-gradient side stream gets its own).  The kernels leave it
-    zeroed, so it is filled exactly once, when it is created."""
+    zeroed, so it is filled exactly once, when it is created -- and it is created OUTSIDE any hipGraph capture: an
+    allocation + zero-fill made while a stream is capturing would live in that graph's private pool and be zeroed only when
+    the graph replays (a later eager GEMM or another capture on the same stream would then find stale tickets, no block
+    would draw the last ticket and the split-K output would silently never be written).  A stream first seen during a
+    capture therefore takes an array from a spare set that the first eager call on the device zeroed.  One array must not
+    be used by two graphs that are replayed CONCURRENTLY (they would share tickets); graphs replayed in order may."""
     from . import _lib
-    key = (device.index if device.index is not None else torch.cuda.current_device(),
-           torch.cuda.current_stream(device).cuda_stream)
+    dev = device.index if device.index is not None else torch.cuda.current_device()
+    key = (dev, torch.cuda.current_stream(device).cuda_stream)
     t = _COUNTERS.get(key)
-    if t is None:
-        t = _COUNTERS[key] = torch.zeros(_lib.lib().sm3_gemm_f32_counter_slots(), dtype=torch.int32, device=device)
+    if t is not None:
+        return t
+    capturing = torch.cuda.is_current_stream_capturing()
+    spare = _SPARE.get(dev)
+    if spare is None:
+        if capturing:
+            raise _lib.SM3Error('the first GEMM on this device is being issued inside a hipGraph capture: run one warm-up '
+                                'step eagerly first (the split-K ticket counters must be allocated and zeroed outside the '
+                                'capture)')
+        slots = _lib.lib().sm3_gemm_f32_counter_slots()
+        spare = _SPARE[dev] = list(torch.zeros(_SPARE_COUNT, slots, dtype=torch.int32, device=device).unbind(0))
+    if capturing:
+        if not spare:
+            raise _lib.SM3Error(f'more than {_SPARE_COUNT} capture streams issued GEMMs on device {dev} without an eager '
+                                'warm-up on them: no zeroed ticket-counter array is left')
+        t = spare.pop()
+    else:
+        t = torch.zeros(_lib.lib().sm3_gemm_f32_counter_slots(), dtype=torch.int32, device=device)
+    _COUNTERS[key] = t
     return t
 
 

@@ -61,11 +61,14 @@ int grid_for(long total) {
 
 // Batched 2-D transpose dst[b][c][r] = src[b][r][c] through a 32x33 LDS tile (NHWC <-> NCHW of a feature map:
 // rows = H*W, cols = C or the other way round).  Both sides move full 128-byte row segments.
+// ADD: dst += src^T (the mmcv RoIAlignRotated backward ACCUMULATES into the caller's grad_input).  Row tiles ride on
+// grid.x (no 65535 limit on H*W), column tiles on grid.y.
+template <bool ADD>
 __global__ __launch_bounds__(256) void transpose_f32_kernel(const float* __restrict__ src, float* __restrict__ dst,
                                                            int rows, int cols) {
   __shared__ float tile[32][33];
   const long base = (long)blockIdx.z * rows * cols;
-  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
 #pragma unroll
   for (int i = 0; i < 4; i++) {
@@ -76,7 +79,10 @@ __global__ __launch_bounds__(256) void transpose_f32_kernel(const float* __restr
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     const int c = c0 + ty + 8 * i, r = r0 + tx;
-    if (r < rows && c < cols) dst[base + (long)c * rows + r] = tile[tx][ty + 8 * i];
+    if (r < rows && c < cols) {
+      float* d = dst + base + (long)c * rows + r;
+      *d = ADD ? *d + tile[tx][ty + 8 * i] : tile[tx][ty + 8 * i];
+    }
   }
 }
 
@@ -106,9 +112,17 @@ int sm3_sumpool2x_add(const float* dfine, const float* base, float* dcoarse, int
 
 int sm3_transpose_f32(const float* src, float* dst, int batch, int rows, int cols, sm3_stream_t stream) {
   if (!src || !dst || batch <= 0 || rows <= 0 || cols <= 0 || batch > 65535) return SM3_ERR_INVALID_ARG;
-  dim3 grid((cols + 31) / 32, (rows + 31) / 32, batch);
+  dim3 grid((rows + 31) / 32, (cols + 31) / 32, batch);
   if (grid.y > 65535) return SM3_ERR_UNSUPPORTED;
-  transpose_f32_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(src, dst, rows, cols);
+  transpose_f32_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(src, dst, rows, cols);
+  return launch_status();
+}
+
+int sm3_transpose_add_f32(const float* src, float* dst, int batch, int rows, int cols, sm3_stream_t stream) {
+  if (!src || !dst || batch <= 0 || rows <= 0 || cols <= 0 || batch > 65535) return SM3_ERR_INVALID_ARG;
+  dim3 grid((rows + 31) / 32, (cols + 31) / 32, batch);
+  if (grid.y > 65535) return SM3_ERR_UNSUPPORTED;
+  transpose_f32_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(src, dst, rows, cols);
   return launch_status();
 }
 

@@ -747,12 +747,17 @@ __global__ __launch_bounds__(ROI_THREADS) void roi_align_rotated_bwd_kernel(
 // one thread per box walks the k ground-truth boxes.  rotated = 1: boxes (cx,cy,w,h,a), IoU of RBboxOverlaps2D =
 // rbbox_overlaps (rotate_iou2d_calculator.py:52-87: w,h clamped to >= 1e-3, then box_iou_rotated); rotated = 0: boxes
 // (x1,y1,x2,y2), mmdet bbox_overlaps 'iou' (eps 1e-6).
+// The rotated IoU is ONE out-of-line function: pass 2 finds a gt's low-quality matches by recomputing the IoU and testing
+// it for equality with the maximum pass 1 published, so both kernels must execute the very same instruction sequence (two
+// inlined copies may be scheduled / simplified differently by the compiler).
+__device__ __noinline__ float assign_iou_rotated(const float* __restrict__ g, const float* __restrict__ b) {
+  float gg[5] = {g[0], g[1], fmaxf(g[2], 1e-3f), fmaxf(g[3], 1e-3f), g[4]};
+  float bb[5] = {b[0], b[1], fmaxf(b[2], 1e-3f), fmaxf(b[3], 1e-3f), b[4]};
+  return single_box_iou_rotated(gg, bb, 0);
+}
+
 __device__ __forceinline__ float assign_iou(const float* __restrict__ g, const float* __restrict__ b, int rotated) {
-  if (rotated) {
-    float gg[5] = {g[0], g[1], fmaxf(g[2], 1e-3f), fmaxf(g[3], 1e-3f), g[4]};
-    float bb[5] = {b[0], b[1], fmaxf(b[2], 1e-3f), fmaxf(b[3], 1e-3f), b[4]};
-    return single_box_iou_rotated(gg, bb, 0);
-  }
+  if (rotated) return assign_iou_rotated(g, b);
   const float a1 = (g[2] - g[0]) * (g[3] - g[1]);
   const float a2 = (b[2] - b[0]) * (b[3] - b[1]);
   const float w = fmaxf(fminf(g[2], b[2]) - fmaxf(g[0], b[0]), 0.f);
@@ -780,7 +785,9 @@ __global__ __launch_bounds__(256) void max_iou_pass1_kernel(const float* __restr
       best = ov;
       bi = i;
     }
-    atomicMax(gt_max_bits + i, __float_as_uint(ov));
+    // a non-finite IoU (degenerate box with inf / NaN coordinates) has a bit pattern above every finite float: it must not
+    // become the gt's maximum and switch off its low-quality matching
+    if (ov >= 0.f && ov <= 2.f) atomicMax(gt_max_bits + i, __float_as_uint(ov));
   }
   max_ov[j] = k > 0 ? best : 0.f;
   argmax[j] = bi;

@@ -156,7 +156,8 @@ def roi_align_rotated_forward(input, rois, output, pooled_height, pooled_width, 
 def roi_align_rotated_backward(grad_output, rois, grad_input, pooled_height, pooled_width, spatial_scale,
                                sampling_ratio, aligned, clockwise):
     """pybind.cpp:766-770; positional order (grad_output, rois, grad_input) as the Python caller uses it
-    (mmcv/ops/roi_align_rotated.py:94-103).  ``grad_input`` must arrive zero-filled."""
+    (mmcv/ops/roi_align_rotated.py:94-103).  Like the reference kernel the gradient is ACCUMULATED into ``grad_input``
+    (the wrapper passes it zero-filled, :92), on every path."""
     require_gpu(grad_output, rois, grad_input)
     _f32c(rois, 'rois'); _f32c(grad_output, 'grad_output')
     if rois.size(0) and rois.size(1) != 6:
@@ -165,7 +166,7 @@ def roi_align_rotated_backward(grad_output, rois, grad_input, pooled_height, poo
     B, C, H, W = grad_input.shape
     with torch.cuda.device(grad_input.device):
         target, via_nhwc = grad_input, False
-        if layout == 0 and H * W >= 1024 and C >= 32 and rois.size(0) > 0:
+        if layout == 0 and H * W >= 1024 and C >= 32 and rois.size(0) > 0 and (C + 31) // 32 <= 65535:
             # NCHW gradient maps scatter one float per (RoI, channel, sample) across C planes; on NHWC memory a lane owns
             # a channel and the same scatter is coalesced (10x faster on the 256x256x256 level).  Accumulate into an NHWC
             # scratch map and transpose it into the caller's tensor: one extra pass over the map.
@@ -176,8 +177,9 @@ def roi_align_rotated_backward(grad_output, rois, grad_input, pooled_height, poo
                                                    float(spatial_scale), int(sampling_ratio), int(bool(aligned)),
                                                    int(bool(clockwise)), layout, stream_ptr()),
               'roi_align_rotated_backward')
-        if via_nhwc:  # (B, H*W, C) -> (B, C, H*W); overwrites grad_input (which arrived zero-filled)
-            check(lib().sm3_transpose_f32(ptr(target), ptr(grad_input), B, H * W, C, stream_ptr()), 'transpose_f32')
+        if via_nhwc:  # grad_input (B, C, H*W) += scratch (B, H*W, C)^T
+            check(lib().sm3_transpose_add_f32(ptr(target), ptr(grad_input), B, H * W, C, stream_ptr()),
+                  'transpose_add_f32')
 
 
 # ------------------------------------------------------------------------------------------- deform_conv

@@ -36,6 +36,7 @@ class MultiTensorAdamW(torch.optim.Optimizer):
         super().__init__(params, defaults)
         self.max_grad_norm = float(max_grad_norm) if max_grad_norm else 0.0
         self._built = False
+        self._n_steps_host = 0  # steps taken (host-side count; only used to flag late-joining parameters)
         self._last_hyper = None
         self._scaler = None
         self._scaler_cfg = None
@@ -160,6 +161,16 @@ class MultiTensorAdamW(torch.optim.Optimizer):
         for ti, (_, p) in enumerate(ps):
             st = self.state[p]
             if 'exp_avg' not in st:
+                if hasattr(self, '_step') and self._n_steps_host > 0:
+                    # ONE step counter serves every tensor (one bias correction per launch).  torch.optim.AdamW -- what
+                    # the reference uses -- keeps a step per parameter, so a parameter that receives its first gradient
+                    # after others have already stepped would start its bias correction at 1 there and at the global step
+                    # here.  No SM3Det config does that (all trainable parameters get a gradient every step, DDP demands
+                    # it); say so instead of diverging silently.
+                    import warnings
+                    warnings.warn('MultiTensorAdamW: a parameter received its first gradient after the optimizer had '
+                                  'already stepped; its Adam bias correction uses the global step (torch.optim.AdamW would '
+                                  'restart it at 1)')
                 st['exp_avg'] = torch.zeros_like(p)
                 st['exp_avg_sq'] = torch.zeros_like(p)
             for c in range((p.numel() + chunk - 1) // chunk):
@@ -183,8 +194,12 @@ class MultiTensorAdamW(torch.optim.Optimizer):
         self._partials = torch.empty(self._n_chunks, dtype=torch.float32, device=dev)
         self._built = True
         self._built_set = self._grad_set()
-        self._hyper_pin = torch.empty(2, len(ps), dtype=torch.float32, pin_memory=True)  # persistent staging: a
-        # non_blocking H2D copy out of a temporary pageable tensor may read freed memory
+        # persistent pinned staging (a non_blocking H2D copy out of a temporary pageable tensor may read freed memory), TWO
+        # slots used alternately, each guarded by its own event: a per-iteration lr schedule (warm-up, DynamicLrUpdaterHook)
+        # refills the slot whose copy was issued two updates ago -- long done -- instead of draining the stream every step
+        self._hyper_pin = torch.empty(2, 2, len(ps), dtype=torch.float32, pin_memory=True)
+        self._hyper_ev = [None, None]
+        self._hyper_slot = 0
         self.update_hyperparams(force=True)
 
     def refresh_grad_pointers(self):
@@ -213,11 +228,18 @@ class MultiTensorAdamW(torch.optim.Optimizer):
         lr = [self.param_groups[gi]['lr'] for gi, _ in self._params]
         wd = [self.param_groups[gi]['weight_decay'] for gi, _ in self._params]
         if force or (lr, wd) != self._last_hyper:
-            torch.cuda.current_stream().synchronize() if self._last_hyper is not None else None  # staging reuse
-            self._hyper_pin[0].copy_(torch.tensor(lr, dtype=torch.float32))
-            self._hyper_pin[1].copy_(torch.tensor(wd, dtype=torch.float32))
-            self._lr.copy_(self._hyper_pin[0], non_blocking=True)
-            self._wd.copy_(self._hyper_pin[1], non_blocking=True)
+            slot = self._hyper_slot
+            self._hyper_slot ^= 1
+            if self._hyper_ev[slot] is not None:
+                self._hyper_ev[slot].synchronize()  # the copy that last read this slot (two updates ago): no stream drain
+            pin = self._hyper_pin[slot]
+            pin[0].copy_(torch.tensor(lr, dtype=torch.float32))
+            pin[1].copy_(torch.tensor(wd, dtype=torch.float32))
+            self._lr.copy_(pin[0], non_blocking=True)
+            self._wd.copy_(pin[1], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._hyper_ev[slot] = ev
             self._last_hyper = (lr, wd)
 
     @torch.no_grad()
@@ -233,6 +255,7 @@ class MultiTensorAdamW(torch.optim.Optimizer):
             self.update_hyperparams()
         g0 = self.param_groups[0]
         b1, b2 = g0['betas']
+        self._n_steps_host += 1
         sc = self._ensure_scaler(self._step.device)
         cfg = self._scaler_cfg or dict(growth_factor=2.0, backoff_factor=0.5, growth_interval=0)
         LB.call('adamw_multi', self._p_ptrs, self._g_ptrs, self._m_ptrs, self._v_ptrs, self._numel, self._chunks,

@@ -302,6 +302,22 @@ def test_roi_align_rotated_bench_shape_256x256_level(channels_last):
     assert np.allclose(ggot, gexp, rtol=1e-4, atol=1e-4), np.abs(ggot - gexp).max()
 
 
+@pytest.mark.parametrize('hw,c', [(64, 64), (16, 8)])  # NHWC-scratch path (H*W >= 1024, C >= 32) and the direct NCHW path
+def test_roi_align_rotated_backward_accumulates_into_grad_input(hw, c):
+    """mmcv._ext.roi_align_rotated_backward ADDS into grad_input (atomicAdd in the reference kernel,
+    roi_align_rotated_cuda_kernel.cuh:129-200): a caller-provided non-zero tensor must survive on both internal paths."""
+    from sm3det_amd import mmcv_ext
+    O = _oracle()
+    rng = np.random.RandomState(5)
+    rois = synth.rois_for_level(40, 9, batch=1, extent=float(hw * 4))
+    go = rng.randn(40, c, 7, 7).astype(np.float32)
+    base = rng.randn(1, c, hw, hw).astype(np.float32)
+    gi = dev(base.copy())
+    mmcv_ext.roi_align_rotated_backward(dev(go), dev(rois), gi, 7, 7, 0.25, 2, True, True)
+    exp = base + O.roi_align_rotated_backward(go, rois, base.shape, 7, 7, 0.25, 2, True, True)
+    assert np.allclose(gi.cpu().numpy(), exp, rtol=1e-4, atol=1e-4)
+
+
 def test_box_iou_rotated_bench_shape_2000x64():
     ops, O = _ops(), _oracle()
     b1, b2 = synth.rotated_boxes(2000, 0), synth.rotated_boxes(64, 1)
