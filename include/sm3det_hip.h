@@ -222,6 +222,90 @@ int sm3_max_iou_assign(const float* boxes, int box_stride, int n, const float* g
                        float pos_iou_thr, float neg_iou_thr, float min_pos_iou, int match_low_quality,
                        const int64_t* gt_labels, int64_t* gt_inds, float* max_overlaps, int64_t* labels,
                        void* workspace, size_t workspace_bytes, sm3_stream_t stream);
+/* The same with a per-box validity mask (uint8, NULL = all valid): boxes with box_flags[j] == 0 take no part in the
+ * assignment -- gt_inds -1, max_overlaps 0, and they do not count towards a gt's best IoU.  This is the reference's
+ * `anchors = flat_anchors[inside_flags]` followed by `unmap` (oriented_rpn_head.py:67-76, :124-131, mmdet
+ * anchor_inside_flags with train_cfg.allowed_border) without the compaction: no data-dependent shape, no host sync. */
+int sm3_max_iou_assign_masked(const float* boxes, int box_stride, int n, const uint8_t* box_flags, const float* gts,
+                              int gt_stride, int k, int rotated, float pos_iou_thr, float neg_iou_thr,
+                              float min_pos_iou, int match_low_quality, const int64_t* gt_labels, int64_t* gt_inds,
+                              float* max_overlaps, int64_t* labels, void* workspace, size_t workspace_bytes,
+                              sm3_stream_t stream);
+
+/* obb2xyxy(., 'le90') (mmrotate/core/bbox/transforms.py:685-702): (n, stride >= 5) cx,cy,w,h,a -> (n,4) x1,y1,x2,y2. */
+int sm3_obb2xyxy_le90(const float* obb, int n, int stride, float* out, sm3_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Targets + losses of the two-stage branch on FIXED-SIZE sample blocks, sync-free.
+ *
+ * RPN: OrientedRPNHead._get_targets_single + RotatedRPNHead.get_targets / loss + loss_single
+ * (mmrotate/models/dense_heads/oriented_rpn_head.py:26-187, rotated_rpn_head.py:152-372) for use_sigmoid_cls,
+ * reg_decoded_bbox = False: only the sampled anchors carry a weight, so only they are visited.  Per image b the sampler
+ * hands `samples` slots: idx (flat anchor index over the concatenated levels, position-major then anchor), is_pos, valid;
+ * gt_inds (batch, total_anchors) is the assigner's output (i + 1 for a positive), gts (batch, max_gts, 5) the oriented
+ * ground truth (cx,cy,w,h,a), n_pos / n_neg (batch,) the sampled counts (avg_factor = sum_b max(n_pos,1) + max(n_neg,1)).
+ * A level's prediction element (image b, position p, channel ch) lives at ptr[b*stride[0] + p*stride[1] + ch*stride[2]]
+ * (floats; cls channel = anchor a, reg channel = 6 a + c): NHWC or NCHW maps, or views of a fused head output.
+ * forward: loss_cls[l], loss_bbox[l] per level (mmdet CrossEntropyLoss(use_sigmoid=True) / SmoothL1Loss(beta), each
+ * loss_weight * sum / (avg_factor + eps)).  backward: writes d loss / d prediction, times dloss_*[l], at the sampled
+ * anchors of the dcls / dreg maps, which the caller zero-filled. */
+#define SM3_RPN_MAX_LEVELS 8
+typedef struct {
+  const float* cls;
+  const float* reg;
+  long cls_stride[3], reg_stride[3];
+  float* dcls; /* backward only */
+  float* dreg;
+  long dcls_stride[3], dreg_stride[3];
+  long num_anchors; /* H * W * anchors_per_pos of this level */
+} sm3_rpn_loss_level;
+typedef struct {
+  sm3_rpn_loss_level level[SM3_RPN_MAX_LEVELS];
+  int num_levels, anchors_per_pos;
+  const float* anchors;   /* (total_anchors, 4) x1,y1,x2,y2 */
+  const int64_t* idx;     /* (batch, samples) */
+  const uint8_t* is_pos;  /* (batch, samples) */
+  const uint8_t* valid;   /* (batch, samples) */
+  const int64_t* gt_inds; /* (batch, total_anchors) */
+  const float* gts;       /* (batch, max_gts, 5) */
+  int batch, samples, total_anchors, max_gts;
+  const int64_t* n_pos;   /* (batch,) */
+  const int64_t* n_neg;
+  float means[6], stds[6]; /* MidpointOffsetCoder target_means / target_stds */
+  float beta, loss_weight_cls, loss_weight_bbox, pos_weight; /* pos_weight <= 0: 1 (train_cfg.pos_weight = -1) */
+} sm3_rpn_loss_desc;
+int sm3_rpn_loss_forward(const sm3_rpn_loss_desc* d, float* loss_cls, float* loss_bbox, sm3_stream_t stream);
+int sm3_rpn_loss_backward(const sm3_rpn_loss_desc* d, const float* dloss_cls, const float* dloss_bbox,
+                          sm3_stream_t stream);
+
+/* RCNN: RotatedBBoxHead._get_target_single / get_targets / loss (mmrotate/models/roi_heads/bbox_heads/
+ * rotated_bbox_head.py:141-356) for reg_class_agnostic, reg_decoded_bbox = False, DeltaXYWHAOBBoxCoder 'le90'.  Row i is
+ * one sampled RoI: valid[i]; labels[i] in [0, num_classes) = positive matched to gts[i], num_classes = background.
+ * forward: out3 = [loss_cls (softmax CE, avg_factor = max(#rows with weight > 0, 1)), loss_bbox (SmoothL1 over the
+ * positives / #valid rows), acc (top-1, per cent)]; counts2 = the two avg factors (kept for backward).
+ * backward: d cls_score (num_rois, ld_cls) and d bbox_pred (num_rois, ld_reg), every row written.
+ * With label_weights / bbox_targets given, the same kernels evaluate the reference's loss(cls_score, bbox_pred, rois,
+ * labels, label_weights, bbox_targets, bbox_weights) on targets a caller built with get_targets(). */
+typedef struct {
+  const float* cls_score;
+  const float* bbox_pred;
+  float* dcls_score; /* backward only */
+  float* dbbox_pred;
+  int ld_cls, ld_reg, num_classes, num_rois;
+  const int64_t* labels;
+  const uint8_t* valid;
+  const float* rois; /* (num_rois, 5) cx,cy,w,h,a */
+  const float* gts;  /* (num_rois, 5) */
+  const float* label_weights; /* optional (num_rois): the reference API's precomputed weights (valid may then be NULL) */
+  const float* bbox_targets;  /* optional (num_rois, 5): precomputed targets (rois / gts may then be NULL) */
+  float means[5], stds[5];
+  float norm_factor; /* 0 = None */
+  int edge_swap, proj_xy;
+  float beta, loss_weight_cls, loss_weight_bbox, pos_weight;
+} sm3_rcnn_loss_desc;
+int sm3_rcnn_loss_forward(const sm3_rcnn_loss_desc* d, float* out3, float* counts2, sm3_stream_t stream);
+int sm3_rcnn_loss_backward(const sm3_rcnn_loss_desc* d, const float* counts2, const float* dloss_cls,
+                           const float* dloss_bbox, sm3_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * GroupNorm (+ ReLU) on NHWC tokens: the normalisation of the GFL head's conv towers (local_configs/main_SM3Det.py:29-48

@@ -35,6 +35,7 @@ def _declare(lib):
         'sm3_transpose_add_f32': (I, [P, P, I, I, I, P]),
         'sm3_max_iou_assign_workspace_bytes': (S, [I, I]),
         'sm3_max_iou_assign': (I, [P, I, I, P, I, I, I, F, F, F, I, P, P, P, P, P, S, P]),
+        'sm3_max_iou_assign_masked': (I, [P, I, I, P, P, I, I, I, F, F, F, I, P, P, P, P, P, S, P]),
         'sm3_argsort_desc_workspace_bytes': (S, [I]),
         'sm3_argsort_desc_f32': (I, [P, I, P, P, S, P]),
         'sm3_nms_workspace_bytes': (S, [I]),
@@ -46,8 +47,9 @@ def _declare(lib):
         'sm3_roi_align_rotated_multilevel_forward': (I, [P, P, P, P, I, F, P, P, P, I, I, I, I, I, I, I, I, P]),
         'sm3_roi_align_rotated_multilevel_backward': (I, [P, P, P, P, P, P, I, F, I, I, I, I, I, I, I, I, P]),
     }
-    from . import _lib_backbone
+    from . import _lib_backbone, det_losses
     sig.update(_lib_backbone.signatures())
+    sig.update(det_losses.signatures())
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError => the .so is stale: fail loudly
         fn.restype = res

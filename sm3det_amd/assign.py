@@ -63,8 +63,10 @@ class MaxIoUAssigner:
         self.pos_iou_thr, self.neg_iou_thr, self.min_pos_iou = float(pos_iou_thr), float(neg_iou_thr), float(min_pos_iou)
         self.match_low_quality = bool(match_low_quality)
 
-    def assign(self, bboxes, gt_bboxes, gt_bboxes_ignore=None, gt_labels=None):
-        """bboxes (n, 4|5[+score]), gt_bboxes (k, 4|5) on the GPU -> AssignResult (device tensors, no sync)."""
+    def assign(self, bboxes, gt_bboxes, gt_bboxes_ignore=None, gt_labels=None, box_flags=None):
+        """bboxes (n, 4|5[+score]), gt_bboxes (k, 4|5) on the GPU -> AssignResult (device tensors, no sync).
+        box_flags (n,) uint8 / bool, optional: boxes with a zero flag are not candidates (gt_inds -1, no vote for a gt's
+        best IoU) -- the reference's `flat_anchors[inside_flags]` + `unmap` without the compaction."""
         require_gpu(bboxes, gt_bboxes)
         w = 5 if self.rotated else 4
         if bboxes.dim() != 2 or bboxes.size(1) < w or (gt_bboxes.numel() and gt_bboxes.size(1) < w):
@@ -80,10 +82,16 @@ class MaxIoUAssigner:
             with torch.cuda.device(b.device):
                 nb = lib().sm3_max_iou_assign_workspace_bytes(n, k)
                 ws = workspace(nb, b.device)
-                check(lib().sm3_max_iou_assign(ptr(b), b.size(1), n, ptr(g), g.size(1) if k else w, k, int(self.rotated),
-                                               self.pos_iou_thr, self.neg_iou_thr, self.min_pos_iou,
-                                               int(self.match_low_quality), ptr(gl), ptr(gt_inds), ptr(max_ov),
-                                               ptr(labels), ptr(ws), nb, stream_ptr()), 'max_iou_assign')
+                fl = None
+                if box_flags is not None:
+                    fl = box_flags.to(torch.uint8).contiguous()
+                    if fl.numel() != n:
+                        raise SM3Error('MaxIoUAssigner: box_flags must have one entry per box')
+                check(lib().sm3_max_iou_assign_masked(ptr(b), b.size(1), n, ptr(fl), ptr(g), g.size(1) if k else w, k,
+                                                      int(self.rotated), self.pos_iou_thr, self.neg_iou_thr,
+                                                      self.min_pos_iou, int(self.match_low_quality), ptr(gl),
+                                                      ptr(gt_inds), ptr(max_ov), ptr(labels), ptr(ws), nb,
+                                                      stream_ptr()), 'max_iou_assign')
         return AssignResult(k, gt_inds, max_ov, labels)
 
 

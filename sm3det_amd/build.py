@@ -32,6 +32,34 @@ def _hipcc():
     raise RuntimeError('hipcc not found')
 
 
+# A/B variants: the same ABI compiled with an extra define into its own objects and `libsm3det_hip_<name>.so`; selected at
+# run time with SM3DET_HIP_LIB=<path> (sm3det_amd/_lib.py).  Measurement aids, never loaded by default.
+VARIANTS = {
+    'gelu_exact': ['-DSM3_GELU_EXACT=1'],  # GELU epilogues through ocml erff/expf instead of the A&S 7.1.26 polynomial
+}
+
+
+def build_variant(name, verbose=False):
+    flags = VARIANTS[name]
+    vdir = os.path.join(CSRC, '_variant_' + name)
+    os.makedirs(vdir, exist_ok=True)
+    lib = os.path.join(CSRC, f'libsm3det_hip_{name}.so')
+    objs, procs = [], []
+    for s in sorted(glob.glob(os.path.join(CSRC, '*.hip'))):
+        o = os.path.join(vdir, os.path.basename(s)[:-4] + '.o')
+        objs.append(o)
+        cmd = [_hipcc()] + BASE_FLAGS + FILE_FLAGS.get(os.path.basename(s), []) + flags + ['-c', s, '-o', o]
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for s, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f'hipcc failed on {s}:\n{out.decode()}')
+    subprocess.check_call([_hipcc(), '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', lib] + objs)
+    return lib
+
+
 def build(force=False, verbose=False):
     srcs = sorted(glob.glob(os.path.join(CSRC, '*.hip')))
     hdrs = glob.glob(os.path.join(CSRC, '*.h')) + glob.glob(os.path.join(HERE, '..', 'include', '*.h'))
@@ -62,4 +90,7 @@ def build(force=False, verbose=False):
 
 
 if __name__ == '__main__':
-    print(build(force='-f' in sys.argv, verbose='-v' in sys.argv))
+    if '--variant' in sys.argv:
+        print(build_variant(sys.argv[sys.argv.index('--variant') + 1], verbose='-v' in sys.argv))
+    else:
+        print(build(force='-f' in sys.argv, verbose='-v' in sys.argv))

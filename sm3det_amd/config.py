@@ -126,10 +126,19 @@ def build_detector_pieces(model_cfg, skip_missing=True):
             raise KeyError(f"{cfg['type']} is not in the {MODELS.name} registry")
         out[name] = MODELS.build(cfg)
     for name in _PIECES:
-        build(name, model_cfg.get(name))
+        cfg = model_cfg.get(name)
+        if cfg is not None and name.endswith('_rpn_head'):
+            # TriSourceDetector.__init__ (trisource_H1stage_R2stage_detector.py:64-68): the modality's rpn train / test cfg
+            mod = name.split('_')[0]
+            tr, te = model_cfg.get(f'{mod}_train_cfg'), model_cfg.get(f'{mod}_test_cfg')
+            cfg = dict(cfg, train_cfg=(tr or {}).get('rpn'), test_cfg=(te or {}).get('rpn'))
+        build(name, cfg)
     for head in ('rgb_roi_head', 'ifr_roi_head'):
         h = model_cfg.get(head)
         if h is not None:
             for name in _ROI_PIECES:
                 build(f'{head}.{name}', h.get(name))
+            mod = head.split('_')[0]  # (:70-77): the whole RoI head with the modality's rcnn train / test cfg
+            tr, te = model_cfg.get(f'{mod}_train_cfg'), model_cfg.get(f'{mod}_test_cfg')
+            build(head, dict(h, train_cfg=(tr or {}).get('rcnn'), test_cfg=(te or {}).get('rcnn')))
     return out

@@ -377,15 +377,20 @@ int sm3_gemm_f32(const sm3_gemm_desc* d, void* workspace, size_t workspace_bytes
   if (d->mode == MODE_TN && d->epilogue != EPI_NONE) return SM3_ERR_INVALID_ARG;
   if (d->mode != MODE_NT && d->mode != MODE_NN && d->mode != MODE_TN) return SM3_ERR_INVALID_ARG;
   if (d->compute != 0 && d->compute != 1) return SM3_ERR_INVALID_ARG;
-  {  // the kernel addresses each operand as block base + 32-bit byte offset (buffer loads): keep the spans below 2^31
+  hipStream_t st = (hipStream_t)stream;
+  const Cfg c = choose_cfg(d);
+  {  // the kernel addresses each operand as block base + 32-bit byte offset (buffer loads): keep the spans below 2^31.
+     // TN rebases per k-slice (a_base = A + row0 * lda), so what must fit is ONE slice's rows (a ragged group may hold all
+     // of K), not the whole reduction: stage-0 weight gradients of any batch size pass as long as the slices are short.
     const long lim = (1l << 31) - 65536;
     const long ld = d->lda > d->ldb ? d->lda : d->ldb;
-    const long span = d->mode == MODE_TN ? (long)d->K * ld * 4
+    const long slice_rows = (d->K + c.splits - 1) / (c.splits > 0 ? c.splits : 1) + 4 * c.bk;
+    const long span = d->mode == MODE_TN ? slice_rows * ld * 4
                                          : ((long)256 * ld + d->K) * 4 + (d->mode == MODE_NN ? (long)d->K * d->ldb * 4 : 0);
     if (span >= lim) return SM3_ERR_UNSUPPORTED;
   }
-  hipStream_t st = (hipStream_t)stream;
-  const Cfg c = choose_cfg(d);
+  // every argument check happens before the first launch
+  if (d->mode == MODE_TN && c.splits > 1 && !c.fixup && d->ldc != d->N) return SM3_ERR_UNSUPPORTED;
   const size_t sb = align_up(slab_bytes(d, c), 256), cb = colpart_bytes(d, c);
   if ((sb + cb) && (!workspace || workspace_bytes < sb + cb)) return SM3_ERR_WORKSPACE;
   GemmParams p;
@@ -425,7 +430,6 @@ int sm3_gemm_f32(const sm3_gemm_desc* d, void* workspace, size_t workspace_bytes
     const int rc = d->compute == 1 ? launch_tn16(p, c.tile, c.bk, grid, st) : launch_tn(p, c.tile, c.bk, 0, grid, st);
     if (rc) return rc;
     if (c.splits > 1 && !c.fixup) {
-      if (d->ldc != d->N) return SM3_ERR_UNSUPPORTED;
       launch_splitk_reduce((const float*)workspace, out, mn, c.splits, c.groups, nullptr, 0, 0, st,
                            cs ? d->colsum_out : nullptr, mn1);
     }

@@ -132,6 +132,12 @@ __device__ __forceinline__ int gather_coord(int r, int dd, int stride, int trans
 // 7.1.26, |error| <= 1.5e-7 on erf, i.e. <= 7.5e-8 on Phi -- fp32 rounding level): ~16 VALU ops per element instead of
 // ~55 for ocml's erff + expf.
 __device__ __forceinline__ void gelu_erf_both(float h, float& y, float& dy) {
+#ifdef SM3_GELU_EXACT  // A/B build only (python -m sm3det_amd.build --variant gelu_exact): ocml erff / expf, ~55 VALU ops
+  const float cdf_ = 0.5f * (1.0f + erff(h * 0.70710678118654752440f));
+  y = h * cdf_;
+  dy = fmaf(h, 0.39894228040143267794f * expf(-0.5f * h * h), cdf_);
+  return;
+#endif
   const float e = __expf(-0.5f * h * h);  // exp(-u^2)
   const float u = fabsf(h) * 0.70710678118654752440f;
   const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, u, 1.0f));

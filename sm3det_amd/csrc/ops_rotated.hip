@@ -773,9 +773,15 @@ __global__ __launch_bounds__(256) void max_iou_pass1_kernel(const float* __restr
                                                            const float* __restrict__ gts, int gt_stride, int k,
                                                            int rotated, float* __restrict__ max_ov,
                                                            int32_t* __restrict__ argmax,
-                                                           unsigned* __restrict__ gt_max_bits) {
+                                                           unsigned* __restrict__ gt_max_bits,
+                                                           const uint8_t* __restrict__ flags) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
+  if (flags && !flags[j]) {  // not a candidate (outside the image): no IoU, no vote for a gt's maximum
+    max_ov[j] = 0.f;
+    argmax[j] = 0;
+    return;
+  }
   const float* b = boxes + (long)j * box_stride;
   float best = -1.f;
   int bi = 0;
@@ -803,9 +809,15 @@ __global__ __launch_bounds__(256) void max_iou_pass2_kernel(const float* __restr
                                                            float neg_thr, float min_pos, int match_low_quality,
                                                            const int64_t* __restrict__ gt_labels,
                                                            int64_t* __restrict__ gt_inds,
-                                                           int64_t* __restrict__ labels) {
+                                                           int64_t* __restrict__ labels,
+                                                           const uint8_t* __restrict__ flags) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
+  if (flags && !flags[j]) {
+    gt_inds[j] = -1;
+    if (labels) labels[j] = -1;
+    return;
+  }
   int a = -1;
   if (k == 0) {
     a = 0;  // no ground truth: everything is background (max_iou_assigner.py: assigned_gt_inds[:] = 0)
@@ -834,10 +846,11 @@ size_t sm3_max_iou_assign_workspace_bytes(int n, int k) {
   return align_up((size_t)(n > 0 ? n : 1) * sizeof(int32_t), 256) + (size_t)(k > 0 ? k : 1) * sizeof(unsigned);
 }
 
-int sm3_max_iou_assign(const float* boxes, int box_stride, int n, const float* gts, int gt_stride, int k, int rotated,
-                       float pos_iou_thr, float neg_iou_thr, float min_pos_iou, int match_low_quality,
-                       const int64_t* gt_labels, int64_t* gt_inds, float* max_overlaps, int64_t* labels,
-                       void* workspace, size_t workspace_bytes, sm3_stream_t stream) {
+int sm3_max_iou_assign_masked(const float* boxes, int box_stride, int n, const uint8_t* box_flags, const float* gts,
+                              int gt_stride, int k, int rotated, float pos_iou_thr, float neg_iou_thr,
+                              float min_pos_iou, int match_low_quality, const int64_t* gt_labels, int64_t* gt_inds,
+                              float* max_overlaps, int64_t* labels, void* workspace, size_t workspace_bytes,
+                              sm3_stream_t stream) {
   if (n < 0 || k < 0 || (rotated ? (box_stride < 5 || gt_stride < 5) : (box_stride < 4 || gt_stride < 4)))
     return SM3_ERR_INVALID_ARG;
   if (n == 0) return SM3_OK;
@@ -850,11 +863,20 @@ int sm3_max_iou_assign(const float* boxes, int box_stride, int n, const float* g
   sm3_zero_async(gmax, sizeof(unsigned) * (size_t)(k > 0 ? k : 1), st);
   const int blocks = (n + 255) / 256;
   max_iou_pass1_kernel<<<blocks, 256, 0, st>>>(boxes, box_stride, n, gts, gt_stride, k, rotated, max_overlaps, argmax,
-                                               gmax);
+                                               gmax, box_flags);
   max_iou_pass2_kernel<<<blocks, 256, 0, st>>>(boxes, box_stride, n, gts, gt_stride, k, rotated, max_overlaps, argmax,
                                                gmax, pos_iou_thr, neg_iou_thr, min_pos_iou, match_low_quality,
-                                               gt_labels, gt_inds, labels);
+                                               gt_labels, gt_inds, labels, box_flags);
   return launch_status();
+}
+
+int sm3_max_iou_assign(const float* boxes, int box_stride, int n, const float* gts, int gt_stride, int k, int rotated,
+                       float pos_iou_thr, float neg_iou_thr, float min_pos_iou, int match_low_quality,
+                       const int64_t* gt_labels, int64_t* gt_inds, float* max_overlaps, int64_t* labels,
+                       void* workspace, size_t workspace_bytes, sm3_stream_t stream) {
+  return sm3_max_iou_assign_masked(boxes, box_stride, n, nullptr, gts, gt_stride, k, rotated, pos_iou_thr, neg_iou_thr,
+                                   min_pos_iou, match_low_quality, gt_labels, gt_inds, max_overlaps, labels, workspace,
+                                   workspace_bytes, stream);
 }
 
 int sm3_box_iou_rotated(const float* boxes1, const float* boxes2, float* ious, int n1, int n2, int mode_flag,

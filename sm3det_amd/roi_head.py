@@ -163,3 +163,159 @@ class RotatedShared2FCBBoxHead(nn.Module):
         b = torch.cat([self.fc_cls.bias, self.fc_reg.bias, x.new_zeros(pad)], 0)
         o = ops.linear(x, w, b)
         return o[:, :nc], o[:, nc:nc + nr]
+
+    # ------------------------------------------------------------------------------------------ targets + loss
+    def _coder(self):
+        if getattr(self, '_bbox_coder', None) is None:
+            from .rpn_head import DeltaXYWHAOBBoxCoder
+            cfg = dict(self.bbox_coder_cfg or dict(type='DeltaXYWHAOBBoxCoder', angle_range='le90'))
+            if cfg.pop('type', 'DeltaXYWHAOBBoxCoder') != 'DeltaXYWHAOBBoxCoder':
+                raise NotImplementedError('only DeltaXYWHAOBBoxCoder (every SM3Det config) is implemented')
+            self._bbox_coder = DeltaXYWHAOBBoxCoder(**cfg)
+        return self._bbox_coder
+
+    bbox_coder = property(_coder)
+
+    def _loss_cfg(self):
+        lc = dict(self.loss_cls_cfg or dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0))
+        lb = dict(self.loss_bbox_cfg or dict(type='SmoothL1Loss', beta=1.0, loss_weight=1.0))
+        if lc.get('type') != 'CrossEntropyLoss' or lc.get('use_sigmoid', False) or lb.get('type') != 'SmoothL1Loss':
+            raise NotImplementedError('the RCNN losses of the SM3Det configs are softmax CrossEntropyLoss + SmoothL1Loss')
+        if not self.reg_class_agnostic:
+            raise NotImplementedError('reg_class_agnostic=False is not used by any SM3Det config')
+        return float(lc.get('loss_weight', 1.0)), float(lb.get('loss_weight', 1.0)), float(lb.get('beta', 1.0))
+
+    def get_targets(self, sampling_results, gt_bboxes, gt_labels, rcnn_train_cfg, concat=True):
+        """rotated_bbox_head.py:209-273 (+ _get_target_single :141-207): per image labels / label_weights / bbox_targets /
+        bbox_weights of [positives | negatives]; targets through the DeltaXYWHAOBBoxCoder encode kernel."""
+        pw = float((rcnn_train_cfg or {}).get('pos_weight', -1))
+        out = [[], [], [], []]
+        for res in sampling_results:
+            npos, nneg = res.pos_bboxes.size(0), res.neg_bboxes.size(0)
+            n = npos + nneg
+            dev = res.pos_bboxes.device
+            labels = torch.full((n,), self.num_classes, dtype=torch.long, device=dev)
+            lw = torch.zeros(n, device=dev)
+            bt, bw = torch.zeros(n, 5, device=dev), torch.zeros(n, 5, device=dev)
+            if npos:
+                labels[:npos] = res.pos_gt_labels
+                lw[:npos] = 1.0 if pw <= 0 else pw
+                bt[:npos] = self.bbox_coder.encode(res.pos_bboxes[:, :5], res.pos_gt_bboxes[:, :5])
+                bw[:npos] = 1
+            if nneg:
+                lw[-nneg:] = 1.0
+            for o, v in zip(out, (labels, lw, bt, bw)):
+                o.append(v)
+        return tuple(torch.cat(o, 0) for o in out) if concat else tuple(out)
+
+    def loss(self, cls_score, bbox_pred, rois, labels, label_weights, bbox_targets, bbox_weights,
+             reduction_override=None):
+        """rotated_bbox_head.py:275-356 on precomputed targets (bbox_weights is 1 on the positives by construction):
+        dict(loss_cls, acc, loss_bbox)."""
+        from . import det_losses
+        if reduction_override is not None:
+            raise NotImplementedError('reduction_override is not used by the SM3Det training path')
+        w_cls, w_bbox, beta = self._loss_cfg()
+        l_cls, l_box, acc = det_losses.rcnn_loss(cls_score.float(), bbox_pred.float(), labels, None, None, None,
+                                                 self.num_classes, self.bbox_coder, beta, w_cls, w_bbox,
+                                                 label_weights=label_weights, bbox_targets=bbox_targets)
+        return dict(loss_cls=l_cls, acc=acc, loss_bbox=l_box)
+
+    def loss_fused(self, cls_score, bbox_pred, labels, valid, rois, gts, pos_weight=-1.0):
+        """get_targets + loss in one kernel pair on a fixed-size sample block: rois (N, 5) sampled boxes, gts (N, 5) their
+        matched ground truth, labels (N,) (num_classes = background), valid (N,)."""
+        from . import det_losses
+        w_cls, w_bbox, beta = self._loss_cfg()
+        l_cls, l_box, acc = det_losses.rcnn_loss(cls_score.float(), bbox_pred.float(), labels, valid, rois, gts,
+                                                 self.num_classes, self.bbox_coder, beta, w_cls, w_bbox, pos_weight)
+        return dict(loss_cls=l_cls, acc=acc, loss_bbox=l_box)
+
+
+@_REG.register_module()
+class OrientedStandardRoIHead(nn.Module):
+    """``mmrotate/models/roi_heads/oriented_standard_roi_head.py`` (on ``rotate_standard_roi_head.py:13-78``): RoI
+    extractor + box head + the training path ``forward_train`` (:31-95) / ``_bbox_forward_train`` (:97-124).
+
+    ``forward_train`` accepts the reference's ``proposal_list`` (list of (n_i, 5+) tensors) or the sync-free fixed-size
+    block ``((B, P, 6) tensor, (B,) counts)`` the RPN head emits; either way assignment + sampling + targets + loss cost
+    no host synchronisation: per image a masked MaxIoU assignment, ``add_gt_as_proposals``, the fixed-size sampler, then
+    ONE RoI-extractor launch, the head's GEMMs and ONE fused target-encode + loss kernel for all images."""
+
+    def __init__(self, bbox_roi_extractor=None, bbox_head=None, shared_head=None, train_cfg=None, test_cfg=None,
+                 pretrained=None, init_cfg=None, version='oc'):
+        super().__init__()
+        if shared_head is not None:
+            raise NotImplementedError('shared_head is not used by any SM3Det config')
+        self.train_cfg, self.test_cfg, self.version, self.init_cfg = train_cfg, test_cfg, version, init_cfg
+        self.bbox_roi_extractor = _REG.build(bbox_roi_extractor) if bbox_roi_extractor is not None else None
+        self.bbox_head = _REG.build(bbox_head) if bbox_head is not None else None
+        self.bbox_assigner = self.bbox_sampler = None
+        if train_cfg:
+            from .assign import BBOX_ASSIGNERS, BBOX_SAMPLERS
+            self.bbox_assigner = BBOX_ASSIGNERS.build(train_cfg['assigner'])
+            self.bbox_sampler = BBOX_SAMPLERS.build(train_cfg['sampler'])
+
+    @property
+    def with_bbox(self):
+        return self.bbox_head is not None
+
+    def init_weights(self):
+        if self.bbox_head is not None:
+            self.bbox_head.init_weights()
+
+    def _bbox_forward(self, x, rois):
+        """rotate_standard_roi_head.py:150-165"""
+        feats = self.bbox_roi_extractor(x[:self.bbox_roi_extractor.num_inputs], rois)
+        cls_score, bbox_pred = self.bbox_head(feats)
+        return dict(cls_score=cls_score, bbox_pred=bbox_pred, bbox_feats=feats)
+
+    def sample_fixed(self, proposals, counts, gt_bboxes, gt_labels, generator=None):
+        """Assign + sample every image on the device.  proposals (B, P, 5+), counts (B,) or None -> dict of fixed-size
+        blocks: rois (B*S, 6) [batch index | box], labels (B*S,), valid (B*S,), gts (B*S, 5), n_pos / n_neg (B,)."""
+        B, P = proposals.shape[0], proposals.shape[1]
+        dev = proposals.device
+        S, C = self.bbox_sampler.num, self.bbox_head.num_classes
+        slot = torch.arange(P, device=dev)
+        rois, labels, valids, gts_out, npos, nneg = [], [], [], [], [], []
+        for i in range(B):
+            boxes = proposals[i, :, :5].contiguous()
+            g, gl = gt_bboxes[i].float()[:, :5].contiguous(), gt_labels[i].long()
+            k = int(g.shape[0])
+            flags = (slot < counts[i]).to(torch.uint8) if counts is not None else None
+            ar = self.bbox_assigner.assign(boxes, g, None, gl, box_flags=flags)
+            gt_inds, lab = ar.gt_inds, ar.labels
+            if self.bbox_sampler.add_gt_as_proposals and k > 0:  # BaseSampler.sample: gts first, self-matched
+                boxes = torch.cat([g, boxes], 0)
+                gt_inds = torch.cat([torch.arange(1, k + 1, device=dev), gt_inds])
+                lab = torch.cat([gl, lab])
+            idx, is_pos, valid, n_pos, n_neg = self.bbox_sampler.sample_fixed(gt_inds, generator)
+            sel = boxes[idx]
+            unit = sel.new_tensor([0.0, 0.0, 1.0, 1.0, 0.0])
+            sel = torch.where(valid[:, None], sel, unit)  # unused slots: a harmless unit box (their rows carry no weight)
+            gsel = g[(gt_inds[idx] - 1).clamp(min=0)] if k > 0 else sel.new_zeros(S, 5)
+            rois.append(torch.cat([sel.new_full((S, 1), float(i)), sel], 1))
+            labels.append(torch.where(is_pos, lab[idx], torch.full_like(lab[idx], C)))
+            valids.append(valid)
+            gts_out.append(gsel)
+            npos.append(n_pos)
+            nneg.append(n_neg)
+        return dict(rois=torch.cat(rois), labels=torch.cat(labels), valid=torch.cat(valids), gts=torch.cat(gts_out),
+                    n_pos=torch.stack(npos), n_neg=torch.stack(nneg))
+
+    def forward_train(self, x, img_metas, proposal_list, gt_bboxes, gt_labels, gt_bboxes_ignore=None, gt_masks=None,
+                      generator=None, return_samples=False):
+        if isinstance(proposal_list, (tuple, list)) and len(proposal_list) == 2 and torch.is_tensor(proposal_list[0]) \
+                and proposal_list[0].dim() == 3:
+            proposals, counts = proposal_list
+        else:  # the reference's list of per-image (n_i, 5+) proposals: pad to one block (shapes are host-side facts)
+            P = max([int(p.shape[0]) for p in proposal_list] + [1])
+            proposals = proposal_list[0].new_zeros(len(proposal_list), P, 5)
+            for i, p in enumerate(proposal_list):
+                proposals[i, :p.shape[0]] = p[:, :5]
+            counts = torch.tensor([int(p.shape[0]) for p in proposal_list], device=proposals.device)
+        smp = self.sample_fixed(proposals.detach(), counts, gt_bboxes, gt_labels, generator)
+        res = self._bbox_forward(x, smp['rois'])
+        pw = float((self.train_cfg or {}).get('pos_weight', -1))
+        losses = self.bbox_head.loss_fused(res['cls_score'], res['bbox_pred'], smp['labels'], smp['valid'],
+                                           smp['rois'][:, 1:], smp['gts'], pw)
+        return (losses, smp) if return_samples else losses

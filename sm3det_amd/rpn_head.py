@@ -12,10 +12,14 @@ Mirrors, for the part that is in the reference tree:
   device kernels, and there is ONE host sync per image (the variable-length result) instead of one per op;
 * ``MidpointOffsetCoder.decode`` (``mmrotate/core/bbox/coder/delta_midpointoffset_rbbox_coder.py:53-84``).
 
-Not mirrored (they live in mmdet 2.x, which the reference does not vendor -- SURVEY.md Appendix A): ``AnchorHead``'s loss
-/ target machinery (``MaxIoUAssigner``, ``RandomSampler``, ``anchor_inside_flags`` ...).  ``grid_anchors`` restates
-mmdet's ``AnchorGenerator.grid_priors`` for the ``scales x ratios`` form the config uses, flagged [memory].
-No CPU fallback.
+* ``OrientedRPNHead._get_targets_single`` / ``loss_single`` and ``RotatedRPNHead.get_targets`` / ``loss``
+  (``oriented_rpn_head.py:26-187``, ``rotated_rpn_head.py:152-372``) as ``loss()`` / ``forward_train()``: masked MaxIoU
+  assignment (``anchor_inside_flags`` as a per-anchor flag instead of a compaction), the sync-free sampler and ONE fused
+  target-encode + loss kernel over the sampled anchors (``sm3det_amd/det_losses.py``).
+
+mmdet 2.x pieces the reference does not vendor are restated and flagged: ``grid_anchors`` / ``valid_flags`` /
+``anchor_inside_flags`` (``AnchorGenerator``, [memory]), the assigner / sampler rules (``assign.py``) and the loss
+formulas (``CrossEntropyLoss(use_sigmoid)``, ``SmoothL1Loss``).  No CPU fallback.
 """
 import torch
 import torch.nn as nn
@@ -169,8 +173,20 @@ class OrientedRPNHead(nn.Module):
         bc = dict(bbox_coder or dict(type='MidpointOffsetCoder', angle_range=version))
         bc.pop('type', None)
         self.bbox_coder = MidpointOffsetCoder(**bc)
-        self.loss_cls_cfg, self.loss_bbox_cfg = loss_cls, loss_bbox
+        self.loss_cls_cfg = dict(loss_cls or dict(type='CrossEntropyLoss', use_sigmoid=True, loss_weight=1.0))
+        self.loss_bbox_cfg = dict(loss_bbox or dict(type='SmoothL1Loss', beta=1.0 / 9.0, loss_weight=1.0))
+        if self.loss_cls_cfg.get('type', 'CrossEntropyLoss') != 'CrossEntropyLoss' or \
+                self.loss_bbox_cfg.get('type', 'SmoothL1Loss') != 'SmoothL1Loss':
+            raise NotImplementedError('the RPN losses of the SM3Det configs are CrossEntropyLoss(use_sigmoid) + SmoothL1Loss')
         self.train_cfg, self.test_cfg, self.init_cfg = train_cfg, test_cfg, init_cfg
+        self.num_classes, self.reg_decoded_bbox, self.sampling = 1, False, True  # RotatedRPNHead / AnchorHead defaults
+        self.assigner = self.sampler = None
+        if train_cfg is not None:
+            from .assign import BBOX_ASSIGNERS, BBOX_SAMPLERS
+            self.assigner = BBOX_ASSIGNERS.build(train_cfg['assigner'])
+            self.sampler = BBOX_SAMPLERS.build(train_cfg.get('sampler', dict(type='RandomSampler', num=256,
+                                                                             pos_fraction=0.5)))
+        self._anchor_cache = {}
         self._init_layers()
 
     def _init_layers(self):
@@ -308,6 +324,99 @@ class OrientedRPNHead(nn.Module):
             out[i, :m] = dets
             counts[i] = cnt
         return out, counts
+
+    # ------------------------------------------------------------------------------------------ targets + loss
+    def _train_anchors(self, sizes, pad_shape, img_shape, device):
+        """(levels' anchors, concatenated anchors, inside flags uint8) for one (feature sizes, image shape): built once
+        and cached -- [memory] mmdet AnchorGenerator.grid_priors / valid_flags(pad_shape) / anchor_inside_flags(
+        img_shape, train_cfg.allowed_border), the inputs of `_get_targets_single` (oriented_rpn_head.py:63-69)."""
+        key = (tuple(sizes), tuple(pad_shape[:2]), tuple(img_shape[:2]), str(device))
+        hit = self._anchor_cache.get(key)
+        if hit is not None:
+            return hit
+        strides = self.anchor_cfg['strides']
+        lvl = grid_anchors(sizes, strides, self.anchor_cfg.get('scales', [8]), self.anchor_cfg.get('ratios', [1.0]),
+                           device='cpu')
+        flags = []
+        for (H, W), s in zip(sizes, strides):  # valid_flags: positions whose cell starts inside the padded image
+            vh, vw = min(-(-int(pad_shape[0]) // s), H), min(-(-int(pad_shape[1]) // s), W)
+            v = torch.zeros(H, W, dtype=torch.bool)
+            v[:vh, :vw] = True
+            flags.append(v.reshape(-1, 1).expand(H * W, self.num_anchors).reshape(-1))
+        flat, valid = torch.cat(lvl), torch.cat(flags)
+        border = (self.train_cfg or {}).get('allowed_border', 0)
+        if border >= 0:
+            ih, iw = int(img_shape[0]), int(img_shape[1])
+            valid = valid & (flat[:, 0] >= -border) & (flat[:, 1] >= -border) & (flat[:, 2] < iw + border) & \
+                (flat[:, 3] < ih + border)
+        out = ([a.to(device) for a in lvl], flat.to(device), valid.to(torch.uint8).to(device))
+        self._anchor_cache[key] = out
+        return out
+
+    def loss(self, cls_scores, bbox_preds, gt_bboxes, img_metas, gt_bboxes_ignore=None, generator=None,
+             return_samples=False):
+        """RotatedRPNHead.loss (rotated_rpn_head.py:305-372) with OrientedRPNHead's targets (oriented_rpn_head.py:26-134)
+        and loss_single (:136-187): per image masked MaxIoU assignment of the anchors against obb2xyxy(gt) and the
+        sync-free sampler; then ONE kernel over the sampled anchors of all images and levels.  Returns
+        dict(loss_rpn_cls=[per level], loss_rpn_bbox=[per level]) like the reference.
+        gt_bboxes: list of (k_i, 5) oriented boxes per image (on the GPU); img_metas: list of dicts with 'img_shape'
+        (and optionally 'pad_shape')."""
+        from . import det_losses
+        if self.assigner is None:
+            raise RuntimeError('OrientedRPNHead.loss needs train_cfg (assigner / sampler)')
+        if gt_bboxes_ignore is not None and any(g is not None and g.numel() for g in gt_bboxes_ignore):
+            raise NotImplementedError('gt_bboxes_ignore is not used by any SM3Det config')
+        B = cls_scores[0].shape[0]
+        dev = cls_scores[0].device
+        sizes = [tuple(c.shape[-2:]) for c in cls_scores]
+        idxs, poss, vals, gtis, npos, nneg = [], [], [], [], [], []
+        kmax = max([int(g.shape[0]) for g in gt_bboxes] + [1])
+        gts = torch.zeros(B, kmax, 5, device=dev)
+        for i in range(B):
+            meta = img_metas[i]
+            shape = meta['img_shape']
+            _, flat, inside = self._train_anchors(sizes, meta.get('pad_shape', shape), shape, dev)
+            g = gt_bboxes[i].float()
+            k = int(g.shape[0])
+            if k:
+                gts[i, :k] = g[:, :5]
+            ar = self.assigner.assign(flat, det_losses.obb2xyxy(g, self.version) if k else g.new_zeros(0, 4), None, None,
+                                      box_flags=inside)
+            idx, is_pos, valid, n_pos, n_neg = self.sampler.sample_fixed(ar.gt_inds, generator)
+            idxs.append(idx); poss.append(is_pos); vals.append(valid); gtis.append(ar.gt_inds)
+            npos.append(n_pos); nneg.append(n_neg)
+        idx, is_pos, valid = torch.stack(idxs), torch.stack(poss), torch.stack(vals)
+        gt_inds, n_pos, n_neg = torch.stack(gtis), torch.stack(npos), torch.stack(nneg)
+        pw = float((self.train_cfg or {}).get('pos_weight', -1))
+        l_cls, l_box = det_losses.rpn_loss(
+            [c.float() for c in cls_scores], [r.float() for r in bbox_preds], flat, idx, is_pos, valid, gt_inds, gts,
+            n_pos, n_neg, self.num_anchors, self.bbox_coder.means, self.bbox_coder.stds,
+            beta=float(self.loss_bbox_cfg.get('beta', 1.0)), loss_weight_cls=float(self.loss_cls_cfg.get('loss_weight', 1.0)),
+            loss_weight_bbox=float(self.loss_bbox_cfg.get('loss_weight', 1.0)), pos_weight=pw)
+        losses = dict(loss_rpn_cls=list(l_cls.unbind(0)), loss_rpn_bbox=list(l_box.unbind(0)))
+        if return_samples:
+            return losses, dict(idx=idx, is_pos=is_pos, valid=valid, gt_inds=gt_inds, n_pos=n_pos, n_neg=n_neg,
+                                anchors=flat, inside=inside)
+        return losses
+
+    def forward_train(self, x, img_metas, gt_bboxes, gt_labels=None, gt_bboxes_ignore=None, proposal_cfg=None,
+                      fixed_size=True, generator=None):
+        """mmdet BaseDenseHead.forward_train as RotatedRPNHead inherits it: heads -> loss -> proposals.  Returns
+        (losses, proposals): with ``fixed_size`` (default) proposals = ((B, max_per_img, 6) tensor, (B,) counts), sync-free;
+        otherwise the reference's list of (n_i, 6) tensors (one host sync per image)."""
+        cls_scores, bbox_preds = self(x)
+        losses = self.loss(cls_scores, bbox_preds, gt_bboxes, img_metas, gt_bboxes_ignore, generator=generator)
+        if proposal_cfg is None:
+            return losses
+        with torch.no_grad():
+            if fixed_size:
+                shape = img_metas[0]['img_shape']
+                lvl, _, _ = self._train_anchors([tuple(c.shape[-2:]) for c in cls_scores],
+                                                img_metas[0].get('pad_shape', shape), shape, cls_scores[0].device)
+                props = self.get_bboxes_fixed(cls_scores, bbox_preds, shape, proposal_cfg, mlvl_anchors=lvl)
+            else:
+                props = self.get_bboxes(cls_scores, bbox_preds, img_metas, proposal_cfg)
+        return losses, props
 
     def get_bboxes(self, cls_scores, bbox_preds, img_metas=None, cfg=None, rescale=False, mlvl_anchors=None):
         """per-image proposals (list of (n,6) tensors) from the multi-level head outputs"""

@@ -115,8 +115,17 @@ def make(case):
     net64 = copy.deepcopy(net).double()
     for b, rs in zip([b for st in net64.stages for b in st], drop):
         b.drop_path = _FixedDrop(rs.double())
-    with torch.no_grad(), _Recorder([n.double() for n in noise], E, k) as rec64:
+    with _Recorder([n.double() for n in noise], E, k) as rec64:
         outs64, gl64 = net64(x.double(), ['single'])
+        FC.loss_of(outs64, gl64, seed).backward()
+    # ... and of every parameter gradient (same metric as compare_grad): a gradient that is a badly conditioned sum --
+    # d(temperature) is ONE number summed over all tokens and experts with mixed signs -- has a floor well above 1e-4
+    packed = FC.pack_grads({kk: p.grad for kk, p in net.named_parameters() if p.grad is not None})
+    grad_floor = {kk: FC.compare_grad(kk, p.grad.float(), packed) for kk, p in net64.named_parameters()
+                  if p.grad is not None}
+    worst_floor = max(grad_floor.items(), key=lambda kv: kv[1][0])
+    print(f'{case}: fp32-vs-fp64 gradient floor of the reference itself: worst {worst_floor}; temperature: '
+          f'{[round(v[0], 6) for kk, v in grad_floor.items() if kk.endswith("temperature")]}', flush=True)
     same_routing = all(torch.equal(torch.sort(a[1][:, :k], 1)[0], torch.sort(b[1][:, :k], 1)[0])
                        for a, b in zip(rec.topk, rec64.topk))
     floor = []
@@ -131,7 +140,7 @@ def make(case):
               outs=[FC.summarise_output(i, o) for i, o in enumerate(outs)],
               gate_loss=float(gl.detach()), loss=float(L.detach()),
               routing=routing, expert_counts=counts, fp32_floor=floor, fp64_same_routing=same_routing,
-              grads=FC.pack_grads({kk: p.grad for kk, p in net.named_parameters() if p.grad is not None}),
+              grads=packed, grad_fp32_floor={kk: (float(v[0]), float(v[1])) for kk, v in grad_floor.items()},
               torch_version=torch.__version__, reference_seconds=dt, reference_threads=torch.get_num_threads())
     path = os.path.join(FC.GOLDEN, case + '.pt')
     torch.save(fx, path)

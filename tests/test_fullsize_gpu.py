@@ -37,6 +37,12 @@ pytestmark = pytest.mark.gpu
 
 FWD_TOL, BWD_TOL = 1e-4, 1e-3
 FLIP_MARGIN = 2e-4
+# AMP (configs #3 / #5, `fp16 = dict(loss_scale='dynamic')`): SURVEY.md 8(c) compares the fp16 data path with the fp32
+# reference at 2e-2.  The gate projection then sees fp16-rounded operands, which moves a logit by ~1e-3 of its scale, so
+# tokens whose k-th / (k+1)-th margin is below AMP_FLIP_MARGIN may legitimately route the other way; every such token
+# must be on the fixture's near-tie list (which lists margins up to 1e-2) and the swap must be k-th <-> runner-up.
+AMP_TOL = 2e-2
+AMP_FLIP_MARGIN = 5e-3
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -51,7 +57,20 @@ def _moe_blocks(net):
 
 @pytest.mark.parametrize('case', list(FC.CASES))
 def test_full_size_values_vs_reference_fixture(case):
+    _run_case(case, amp=False)
+
+
+@pytest.mark.parametrize('case', ['full_e8t2_b2', 'full_base_b1'])
+def test_full_size_amp_data_path_vs_fp32_reference_fixture(case):
+    """configs #3 (ConvNeXt-T e8t2, the headline batch) and #5 (ConvNeXt-B) under `wrap_fp16_model` at 1024^2 against the
+    reference module's fp32 results: element-wise 2e-2 on outputs and on every parameter gradient, routing flips only at
+    near-ties of the reference."""
+    _run_case(case, amp=True)
+
+
+def _run_case(case, amp):
     from sm3det_amd.convnext_moe import ConvNeXt_moe_MultiInput
+    FWD_TOL, BWD_TOL, FLIP_MARGIN = (AMP_TOL, AMP_TOL, AMP_FLIP_MARGIN) if amp else (1e-4, 1e-3, 2e-4)
     fx = FC.load(case)
     cfg, seed = fx['cfg'], fx['seed']
     E, k = cfg['num_experts'], cfg['top_k']
@@ -59,12 +78,17 @@ def test_full_size_values_vs_reference_fixture(case):
     net = ConvNeXt_moe_MultiInput(**cfg)
     net.load_state_dict(FC.seeded_state_dict(net.state_dict(), seed), strict=True)
     net = net.cuda().train()
+    if amp:
+        from sm3det_amd import amp as _amp
+        _amp.wrap_fp16_model(net)
+        assert net.fp16_enabled is True
     x, noise, drop = FC.make_inputs(case, noise_seed=fx['noise_seed'])
     outs, gl = net(x.cuda(), ['single'], noise=[n.cuda() for n in noise], drop_scale=[d.cuda() for d in drop])
+    assert all(o.dtype == torch.float32 for o in outs)  # LayerNorm2d outputs are fp32 under autocast too
     L = FC.loss_of(outs, gl, seed)
     L.backward()
     torch.cuda.synchronize()
-    report = dict(case=case)
+    report = dict(case=case, amp=bool(amp))
 
     # ---- routing, token by token -------------------------------------------------------------------------------
     first_flip_stage, n_flips = None, 0
@@ -98,36 +122,46 @@ def test_full_size_values_vs_reference_fixture(case):
             tol = max(FWD_TOL, 4.0 * fx['fp32_floor'][i][name]) if name == 'samples' else FWD_TOL
             stats[name] = dict(max=float(e.max()), p999=float(torch.quantile(e, 0.999)), median=float(e.median()),
                                tol=tol, reference_fp32_floor=fx['fp32_floor'][i][name])
+            stats[name]['frac_above_tol'] = float((e > tol).double().mean())
             if strict:
                 assert float(e.max()) < tol, (case, f'out{i}', name, stats[name])
             else:
-                assert float((e > tol).double().mean()) <= 5e-3, (case, f'out{i}', name, stats[name])
+                # downstream of a flipped token: the token and its 7x7 neighbourhoods in later blocks differ by design
+                assert stats[name]['frac_above_tol'] <= (2e-2 if amp else 5e-3), (case, f'out{i}', name, stats[name])
             assert float(e.median()) < FWD_TOL / 10, (case, f'out{i}', name, stats[name])
         report[f'out{i}'] = dict(strict=strict, **stats)
     gl_err = abs(float(gl) - fx['gate_loss']) / abs(fx['gate_loss'])
-    assert gl_err < (FWD_TOL if n_flips == 0 else 1e-3), (case, float(gl), fx['gate_loss'])
+    assert gl_err < (FWD_TOL if n_flips == 0 else max(FWD_TOL, 1e-3)), (case, float(gl), fx['gate_loss'])
     report['gate_loss_rel_err'] = gl_err
 
     # ---- every parameter gradient ------------------------------------------------------------------------------
     grads = _ref_key_grads(net)
     table = fx['grads']['table']
     assert set(table) <= set(grads), sorted(set(table) - set(grads))[:5]
+    # tolerance per tensor: 1e-3 (AMP: 2e-2), or 4x the REFERENCE'S OWN fp32-vs-fp64 distance for that gradient where that
+    # is larger (stored in the fixture by the generator, same metric) -- it is for d(temperature), ONE number = a sum over
+    # all tokens and experts of dlogit * logit with mixed signs, whose cancellation amplifies fp32 rounding on either side
+    floor = fx.get('grad_fp32_floor', {})
     worst = (0.0, None)
     worst_l2 = (0.0, None)
+    loosened = {}
     for key in table:
         e, l2 = FC.compare_grad(key, grads[key], fx['grads'])
-        if key.endswith('temperature'):
-            e, l2 = e / 3.0, l2 / 3.0  # one number = a sum over all tokens and experts with mixed signs (see test_backbone_gpu)
-        if e > worst[0]:
-            worst = (e, key)
-        if l2 > worst_l2[0]:
-            worst_l2 = (l2, key)
+        fe, fl2 = floor.get(key, (0.0, 0.0))
+        te, tl2 = max(BWD_TOL, 4.0 * fe), max(BWD_TOL, 4.0 * fl2)
+        if te > BWD_TOL or tl2 > BWD_TOL:
+            loosened[key] = dict(err=e, l2=l2, reference_fp32_floor=(fe, fl2))
+        if e / te > worst[0]:
+            worst = (e / te, key, e)
+        if l2 / tl2 > worst_l2[0]:
+            worst_l2 = (l2 / tl2, key, l2)
+    report['grads_with_reference_floor_above_tol'] = loosened
     report['grads'] = dict(n=len(table), worst_elementwise=worst, worst_l2=worst_l2)
     os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
-    with open(os.path.join(ROOT, 'gpurun_out', f'fullsize_{case}.json'), 'w') as f:
+    with open(os.path.join(ROOT, 'gpurun_out', f'fullsize_{case}{"_amp" if amp else ""}.json'), 'w') as f:
         json.dump(report, f, indent=1)
     print('\n' + json.dumps(report))
-    assert worst[0] < BWD_TOL, (case, worst)
-    assert worst_l2[0] < BWD_TOL, (case, worst_l2)
+    assert worst[0] < 1.0, (case, worst)        # error / tolerance
+    assert worst_l2[0] < 1.0, (case, worst_l2)
     for n, p in net.named_parameters():
         assert p.grad is not None, n
