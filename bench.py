@@ -460,12 +460,14 @@ def main():
                     'configs #3 / #5; implied by --config SM3Det_convnext_{t,b}): fp16 activations and GEMM operands, fp32 '
                     'accumulation / master weights / LayerNorm / router / combine, dynamic loss scale; reported as its own '
                     'dtype, never mixed with the fp32 line')
+    ap.add_argument('--fp32', action='store_true', help='run the model of an AMP config in fp32 (diagnostic line: the MFMA '
+                    'roofline of the ConvNeXt-B shapes); the config label says so')
     ap.add_argument('--cpu-worker', choices=['step', 'ops'], help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_worker:
         return _cpu_worker(args.cpu_worker, args.config)
     cfg_entry = load_config(args.config)
-    args.amp = bool(args.amp or cfg_entry.get('fp16'))
+    args.amp = bool(args.amp or cfg_entry.get('fp16')) and not args.fp32
 
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -754,7 +756,9 @@ def main():
                                     f"{desc['experts']} experts top-{desc['top_k']}, {desc['moe_blocks']} MoE + "
                                     f"{desc['dense_blocks']} dense blocks, {desc['params_m']} M parameters; " +
                                     ('AMP (fp16 = dict(loss_scale="dynamic")): fp16 activations / GEMM operands, fp32 accumulate / '
-                                     'master weights / LayerNorm / router / combine, dynamic loss scale; ' if args.amp else '') +
+                                     'master weights / LayerNorm / router / combine, dynamic loss scale; ' if args.amp else
+                                     ('run in fp32 although the config file enables AMP (--fp32, diagnostic); '
+                                      if cfg_entry.get('fp16') else '')) +
                                     'fwd+bwd + bucketed grad all-reduce + grad-clip(35)+AdamW (per-parameter lr); synthetic '
                                     f'randn({BATCH},3,{RES},{RES}) per GPU, random-init weights; neck/heads timed separately in ops_us'),
                        'name': args.config, 'baseline_config': cfg_entry['baseline_config'], 'backbone': desc,
