@@ -375,58 +375,87 @@ def ops_microbench():
     rcnn_asg = MaxIoUAssigner(pos_iou_thr=0.5, neg_iou_thr=0.5, min_pos_iou=0.5, match_low_quality=False,
                               iou_calculator=dict(type='RBboxOverlaps2D'))
     out['max_iou_assign_rcnn_2000x8_rotated'] = timeit(lambda: rcnn_asg.assign(prb, grb))
-    # ---- second named workload (never part of `value`): the two-stage branch chained as the detector chains it --
-    # backbone -> neck -> Oriented-RPN tower -> proposals (fixed-size, sync-free) -> MaxIoU assignment + random sampling
-    # (512 RoIs / image) -> fused multi-level RoI extractor -> Shared2FC head, forward + backward, bs 2 @ 1024^2, replayed
-    # from ONE hipGraph.  Losses are surrogates (the real ones are mmdet code); no optimizer step.
+    # ---- second named workload (never part of `value`): the two-stage (RGB / IR) branch as the detector chains it ----
+    # TriSourceDetector.forward_train for a batch of RGB images (trisource_H1stage_R2stage_detector.py:235-369): backbone ->
+    # MultitaskFPN -> OrientedRPNHead.forward_train (tower, masked MaxIoU assignment of 261 888 anchors / image, sampler,
+    # fused target-encode + BCE / SmoothL1 losses, fixed-size proposals: top-2000 per level, decode, NMS 0.8) ->
+    # OrientedStandardRoIHead.forward_train (rotated MaxIoU assignment, add_gt_as_proposals, 512 RoIs / image, fused
+    # multi-level RoIAlignRotated, Shared2FC head, fused target-encode + CE / SmoothL1 losses) -> backward -> grad-clip +
+    # AdamW over every parameter.  All pieces are built from the reference config's own `model` dict (committed copy) with
+    # the modality's train / test cfg, the losses are the REAL ones; sync-free and replayed from two hipGraphs.  Not in it:
+    # the SAR branch (GFL head: its towers are `gfl_head_fwd_bwd_bs1_5levels` above; ATSS / QFL / DFL / GIoU are mmdet code
+    # that is not built) and the data pipeline.
+    from sm3det_amd.config import build_detector_pieces
+    from sm3det_amd.optim import MultiTensorAdamW
+    torch.manual_seed(1)
+    pcs = build_detector_pieces(load_config(DEFAULT_CONFIG)['model'])
+    fpn2, rpn2, roi2 = pcs['neck'].cuda(), pcs['rgb_rpn_head'].cuda(), pcs['rgb_roi_head'].cuda()
+    rpn2.init_weights()
+    roi2.init_weights()
     bb = build_model().cuda().train()
     img = torch.randn(BATCH, 3, RES, RES, device='cuda')
-    mods = (bb, fpn, rpn, head)
-    sampler = RandomSampler(num=512, pos_fraction=0.25, neg_pos_ub=-1, add_gt_as_proposals=False)
+    mods = (bb, fpn2, rpn2, roi2)
     gts = [dev(synth.rotated_boxes(8, 40 + i)) for i in range(BATCH)]
-    lvl_sizes = [(RES // s, RES // s) for s in (4, 8, 16, 32, 64)]
-    anchors = _ga(lvl_sizes, [4, 8, 16, 32, 64], [8], [0.5, 1.0, 2.0], device='cuda')
-    prop_cfg = dict(nms_pre=2000, max_per_img=2000, nms=dict(type='nms', iou_threshold=0.8), min_bbox_size=0)
-    bidx = torch.arange(BATCH, device='cuda', dtype=torch.float32).view(BATCH, 1, 1).expand(BATCH, 512, 1)
+    gls = [torch.randint(0, 26, (8,), generator=torch.Generator().manual_seed(50 + i)).cuda() for i in range(BATCH)]
+    metas = [dict(img_shape=(RES, RES, 3), pad_shape=(RES, RES, 3)) for _ in range(BATCH)]
+    prop_cfg = load_config(DEFAULT_CONFIG)['model']['rgb_train_cfg']['rpn_proposal']
+    sl_params = [q for m in mods for q in m.parameters() if q.requires_grad]
+    sl_opt = MultiTensorAdamW([dict(params=[q]) for q in sl_params], lr=1e-4, betas=(0.9, 0.999), weight_decay=0.05,
+                              max_grad_norm=35.0)
+    sl_losses = {}
+
+    def slice_fwd_bwd():
+        for q in sl_params:
+            q.grad = None
+        feats_, gl_ = bb(img, ['single'])
+        pyr = fpn2(feats_)
+        rpn_losses, props = rpn2.forward_train(pyr, metas, gts, proposal_cfg=prop_cfg)
+        roi_losses = roi2.forward_train(pyr, metas, props, gts, gls)
+        terms = dict(gate_loss=gl_, loss_rpn_cls=sum(rpn_losses['loss_rpn_cls']), loss_rpn_bbox=sum(rpn_losses['loss_rpn_bbox']),
+                     loss_cls=roi_losses['loss_cls'], loss_bbox=roi_losses['loss_bbox'])
+        loss = sum(terms.values())  # BaseDetector._parse_losses: every key containing 'loss'
+        loss.backward()
+        sl_losses.update({k: v.detach() for k, v in terms.items()}, acc=roi_losses['acc'].detach())
+        return loss
 
     def slice_step():
-        for m in mods:
-            for q in m.parameters():
-                q.grad = None
-        feats_, gl_ = bb(img, ['single'])
-        pyr = fpn(feats_)
-        cls_, reg_ = rpn(pyr)
-        with torch.no_grad():
-            props, _cnt = rpn.get_bboxes_fixed(cls_, reg_, (RES, RES, 3), prop_cfg, mlvl_anchors=anchors)
-            sel = []
-            for i in range(BATCH):
-                ar = rcnn_asg.assign(props[i, :, :5].contiguous(), gts[i])
-                idx, _is_pos, _valid, _, _ = sampler.sample_fixed(ar.gt_inds)
-                sel.append(props[i, :, :5][idx])
-            rois_ = torch.cat([bidx, torch.stack(sel)], -1).view(-1, 6)
-        a, b = head(ext(pyr[:4], rois_))
-        loss = (gl_ + (a * a).mean() + (b * b).mean() + sum((c * c).mean() for c in cls_)
-                + sum((r * r).mean() for r in reg_))
-        loss.backward()
-        return loss
+        slice_fwd_bwd()
+        sl_opt.step()
 
     # everything about the slice runs on a NON-default stream: autograd caches each parameter's AccumulateGrad node with
     # the stream of its first use, and a node bound to the legacy default stream drags that stream into a later capture
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
-        out['detector_slice_eager_fwd_bwd_bs2_1024'] = timeit(slice_step, n=3)
+        out['detector_slice_eager_train_step_bs2_1024'] = timeit(slice_step, n=3)
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
+    first = {k: float(v) for k, v in sl_losses.items()}
     try:
-        gslice = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gslice):
-            slice_step()
-        out['detector_slice_fwd_bwd_bs2_1024'] = timeit(gslice.replay, n=5)
+        g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1):
+            slice_fwd_bwd()
+        keep = [q.grad for q in sl_params]  # noqa: F841  (the tensors the graph writes the gradients to)
+        g1.replay()
+        sl_opt.refresh_grad_pointers()
+        with torch.cuda.graph(g2, pool=g1.pool()):
+            sl_opt.step()
+
+        def replay():
+            g1.replay()
+            g2.replay()
+        out['detector_slice_train_step_bs2_1024'] = timeit(replay, n=5)
     except Exception as e:  # noqa: BLE001
         print(f'[bench] detector slice: hipGraph capture failed ({type(e).__name__}: {e})', file=sys.stderr)
-        out['detector_slice_fwd_bwd_bs2_1024'] = out['detector_slice_eager_fwd_bwd_bs2_1024']
-    return {k: round(v, 1) for k, v in out.items()}
+        out['detector_slice_train_step_bs2_1024'] = out['detector_slice_eager_train_step_bs2_1024']
+    torch.cuda.synchronize()
+    extra = dict(losses_first_step={k: round(v, 5) for k, v in first.items()},
+                 losses_last_step={k: round(float(v), 5) for k, v in sl_losses.items()},
+                 params_m=round(sum(q.numel() for q in sl_params) / 1e6, 2))
+    res = {k: round(v, 1) for k, v in out.items()}
+    res['detector_slice'] = extra
+    return res
+
 
 
 def _self_launch(n):
@@ -443,6 +472,65 @@ def _self_launch(n):
     env = dict(os.environ, OMP_NUM_THREADS=os.environ.get('OMP_NUM_THREADS', '8'))
     r = subprocess.run(cmd, env=env)
     sys.exit(r.returncode)
+
+
+MI355X_VALU_LANE_OPS = 256 * 4 * 32 * 2.4e9  # 256 CUs x 4 SIMD-32 x 2.4 GHz: fp32 lane-instructions / s (= 157.3 TF / 2)
+
+
+def ops_roofline(us):
+    """achieved-vs-roofline of the hot path (b) operators from their `ops_us` timings.  Algorithmic work per call is
+    SURVEY.md 8(d)'s: RoIAlignRotated = HBM gather / scatter (output + each touched feature map once, backward zero-fill +
+    accumulate), box_iou_rotated / NMS = VALU (pair tests; the instruction count per pair is measured with rocprofv3
+    SQ_INSTS_VALU and committed under profiles/r03/ops_pmc.json), DeformConv2d forward = MFMA GEMM + HBM-bound sampling."""
+    pmc = {}
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r03', 'ops_pmc.json')) as f:
+            pmc = json.load(f)
+    except Exception:
+        pass
+    out = {}
+
+    def hbm(name, key, nbytes):
+        if key in us:
+            gbs = nbytes / (us[key] * 1e-6) / 1e9
+            out[name] = dict(bound='hbm', algorithmic_mb=round(nbytes / 1e6, 1), us=us[key], achieved=round(gbs, 1),
+                             peak=MI355X_HBM_PEAK_GBS, unit='GB/s', frac=round(gbs / MI355X_HBM_PEAK_GBS, 4),
+                             traffic=pmc.get(name, {}).get('hbm_bytes'))
+
+    def valu(name, key, pairs, what):
+        if key in us:
+            rate = pairs / (us[key] * 1e-6)
+            ipp = pmc.get(name, {}).get('valu_lane_instr_per_pair')
+            peak = MI355X_VALU_LANE_OPS / ipp if ipp else None
+            out[name] = dict(bound='valu', work=what, pairs=int(pairs), us=us[key], achieved=round(rate / 1e9, 3),
+                             unit='G pairs/s', valu_lane_instr_per_pair=ipp,
+                             peak=round(peak / 1e9, 3) if peak else None, frac=round(rate / peak, 4) if peak else None,
+                             serial_floor_us=pmc.get(name, {}).get('serial_floor_us'))
+    n, C, HW = 512, 256, 256 * 256
+    fmap, roi_out = 1 * C * HW * 4, n * C * 49 * 4
+    hbm('roi_align_rotated_fwd_nchw', 'roi_align_rotated_fwd_512x256x7x7', roi_out + fmap + n * 24)
+    hbm('roi_align_rotated_fwd_nhwc', 'roi_align_rotated_fwd_nhwc', roi_out + fmap + n * 24)
+    hbm('roi_align_rotated_bwd_nchw', 'roi_align_rotated_bwd_512x256x7x7', roi_out + 2 * fmap)
+    hbm('roi_align_rotated_bwd_nhwc', 'roi_align_rotated_bwd_nhwc', roi_out + 2 * fmap)
+    valu('box_iou_rotated_2000x512', 'box_iou_rotated_2000x512', 2000 * 512, 'N*M rotated pair IoUs')
+    valu('box_iou_rotated_2000x64', 'box_iou_rotated_2000x64', 2000 * 64, 'N*M rotated pair IoUs')
+    valu('nms_rotated_10000', 'nms_rotated_10000', 10000 * 9999 / 2, 'N(N-1)/2 rotated pair tests (mask) + serial sweep')
+    valu('nms_rotated_2000', 'nms_rotated_2000', 2000 * 1999 / 2, 'N(N-1)/2 rotated pair tests (mask) + serial sweep')
+    valu('nms_8768', 'nms_8768', 8768 * 8767 / 2, 'N(N-1)/2 horizontal pair tests (mask) + serial sweep')
+    if 'deform_conv2d_fwd_2x256x128x128' in us:
+        fl = 2.0 * 2 * 128 * 128 * 256 * 256 * 9
+        t = us['deform_conv2d_fwd_2x256x128x128'] * 1e-6
+        out['deform_conv2d_fwd'] = dict(bound='mfma', algorithmic_gflop=round(fl / 1e9, 1), us=round(t * 1e6, 1),
+                                        achieved=round(fl / t / 1e12, 2), peak=MI355X_FP32_MFMA_PEAK_TFLOPS,
+                                        unit='TFLOP/s', frac=round(fl / t / 1e12 / MI355X_FP32_MFMA_PEAK_TFLOPS, 4),
+                                        algorithmic_mb=round(2 * 128 * 128 * (256 + 256 + 18) * 4 / 1e6, 1))
+    if 'deform_conv2d_bwd_2x256x128x128' in us:
+        fl = 2.0 * 2.0 * 2 * 128 * 128 * 256 * 256 * 9  # input-gradient GEMM + weight-gradient GEMM
+        t = us['deform_conv2d_bwd_2x256x128x128'] * 1e-6
+        out['deform_conv2d_bwd'] = dict(bound='mfma', algorithmic_gflop=round(fl / 1e9, 1), us=round(t * 1e6, 1),
+                                        achieved=round(fl / t / 1e12, 2), peak=MI355X_FP32_MFMA_PEAK_TFLOPS,
+                                        unit='TFLOP/s', frac=round(fl / t / 1e12 / MI355X_FP32_MFMA_PEAK_TFLOPS, 4))
+    return out
 
 
 def main():
@@ -779,6 +867,14 @@ def main():
         }
         if world == 1 and not args.no_ops:
             result['ops_us'] = ops_microbench()
+            result['ops_roofline'] = ops_roofline(result['ops_us'])
+            t_slice = result['ops_us'].get('detector_slice_train_step_bs2_1024')
+            if t_slice:  # second named value, never mixed into `value`: see ops_microbench()
+                result['full_slice_imgs_per_sec'] = round(BATCH / (t_slice * 1e-6), 2)
+                result['full_slice_workload'] = (
+                    'two-stage (RGB) branch of main_SM3Det.py as one training step at bs2 1024^2: backbone + MultitaskFPN + '
+                    'OrientedRPNHead.forward_train (real targets + losses + proposals) + OrientedStandardRoIHead.forward_train '
+                    '(real targets + losses) + backward + clip + AdamW; excludes the SAR GFL branch and the data pipeline')
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(args.config)
         else:

@@ -168,7 +168,12 @@ typedef struct sm3_gemm_desc {
                         bit 16 TN: slices summed by the in-kernel fix-up instead of the second pass */
   int32_t compute;   /* 0: fp32 operands (v_mfma_f32_32x32x2_f32, exact).  1: operands rounded to fp16 on the fly, fp32
                         accumulation (v_mfma_f32_32x32x16_f16) -- the arithmetic autocast gives nn.Linear in the reference's
-                        AMP configs (fp16 = dict(loss_scale='dynamic')); all tensors stay fp32 in memory */
+                        AMP configs (fp16 = dict(loss_scale='dynamic')) */
+  int32_t io;        /* compute == 1 only: which tensors are STORED as fp16 (the AMP data path; 0 = everything fp32 in
+                        memory, rounded in the loader).  Bits: 1 A, 2 B, 4 C, 8 aux_in / aux_out.  Supported: NT {1 with
+                        epilogue none / bias / bias+scale+residual, 1|4|8 with bias+GELU}; NN {1 with none, 4|8 with
+                        GELU'}; TN {2, 1|2}.  Flagged pointers address _Float16 elements; leading dimensions stay in
+                        elements; weights, biases, residual and colsum outputs are always fp32 */
 } sm3_gemm_desc;
 int sm3_gemm_f32_counter_slots(void);
 size_t sm3_gemm_f32_workspace_bytes(const sm3_gemm_desc* desc);
@@ -357,7 +362,8 @@ int sm3_stem_patchify(const float* x, float* a, int B, int H, int W, sm3_stream_
 
 /* ---------------------------------------------------------------------------------------------------------
  * LayerNorm over the channel dim of token rows (LayerNorm2d, convnext_moe.py:30-47; block norm :351).
- * out_mode 0: y[t] ; out_mode 1: patch-major rows feeding the 2x2/s2 downsample conv (:549-556) as one GEMM.
+ * out_mode 0: y[t] ; out_mode 1: patch-major rows feeding the 2x2/s2 downsample conv (:549-556) as one GEMM;
+ * out_mode 2 (forward only): y[t] stored as fp16 (_Float16* passed as float*): the AMP data path's GEMM operand.
  * mean/rstd (T) are saved for the backward (may be NULL).  bwd: dwdb = [dw (C) | db (C)], overwritten;
  * accumulate_dx != 0 adds into dx. */
 int sm3_layernorm_fwd(const float* x, const float* w, const float* b, float eps, float* y, float* mean, float* rstd,

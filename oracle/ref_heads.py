@@ -1,0 +1,165 @@
+"""Import the REFERENCE head classes -- ``mmrotate/models/dense_heads/{rotated_rpn_head,oriented_rpn_head}.py`` and
+``mmrotate/models/roi_heads/bbox_heads/rotated_bbox_head.py`` -- unmodified from /root/reference, so that their own
+``loss`` / ``get_targets`` / ``_get_targets_single`` / ``loss_single`` code pins oracle/loss_oracle.py.
+
+TEST INFRASTRUCTURE ONLY (CPU tests in the build container; the GPU box has no /root/reference).
+
+Stand-ins registered in ``sys.modules`` for the duration of the import (mmdet / mmcv are not
+importable here): ``mmcv.ops.batched_nms`` (never called by the loss path), ``mmcv.runner.{force_fp32, auto_fp16,
+BaseModule}`` (identity decorators / nn.Module), ``mmcv.utils.to_2tuple``, ``mmdet.core.{anchor_inside_flags,
+images_to_levels, multi_apply, unmap}``, ``mmdet.models.losses.accuracy``, ``mmdet.models.utils.build_linear_layer``,
+``mmdet.models.dense_heads.anchor_head.AnchorHead`` (empty nn.Module: every method on the loss path is defined in the
+reference files themselves), ``<pkg>.builder.{ROTATED_HEADS, build_loss}`` -- the mmdet functions come from
+oracle/loss_oracle.py (restated, unpinned) -- and ``mmrotate.core.{obb2xyxy, build_bbox_coder, multiclass_nms_rotated}``
+where obb2xyxy and the coders are the LIVE reference ones (oracle/ref_rpn.py)."""
+import importlib.util
+import os
+import sys
+
+import torch.nn as nn
+
+from oracle import loss_oracle as LO
+from oracle import ref_rpn
+from oracle.ref_moe import REF_ROOT, _Registry, _mod
+
+_PKG = '_sm3det_ref_pkg_heads'
+FILES = {
+    f'{_PKG}.dense_heads.rotated_rpn_head': ('mmrotate', 'models', 'dense_heads', 'rotated_rpn_head.py'),
+    f'{_PKG}.dense_heads.oriented_rpn_head': ('mmrotate', 'models', 'dense_heads', 'oriented_rpn_head.py'),
+    f'{_PKG}.roi_heads.bbox_heads.rotated_bbox_head': ('mmrotate', 'models', 'roi_heads', 'bbox_heads',
+                                                       'rotated_bbox_head.py'),
+}
+
+
+def available():
+    return ref_rpn.available() and all(os.path.exists(os.path.join(REF_ROOT, *p)) for p in FILES.values())
+
+
+def load():
+    """-> (rotated_rpn_head module, oriented_rpn_head module, rotated_bbox_head module)"""
+    if not available():
+        raise FileNotFoundError(os.path.join(REF_ROOT, *list(FILES.values())[0]))
+    if all(k in sys.modules for k in FILES):
+        return tuple(sys.modules[k] for k in FILES)
+    T, C, X = ref_rpn.load()
+    ident = lambda *a, **k: (lambda f: f)  # noqa: E731
+
+    def build_bbox_coder(cfg):
+        cfg = dict(cfg)
+        t = cfg.pop('type')
+        return {'MidpointOffsetCoder': C.MidpointOffsetCoder, 'DeltaXYWHAOBBoxCoder': X.DeltaXYWHAOBBoxCoder}[t](**cfg)
+
+    class _Base(nn.Module):
+        def __init__(self, init_cfg=None):
+            super().__init__()
+            self.init_cfg = init_cfg
+
+    def _never(*a, **k):
+        raise AssertionError('not on the loss path')
+
+    shims = {
+        'mmcv': _mod('mmcv'), 'mmcv.ops': _mod('mmcv.ops', batched_nms=_never),
+        'mmcv.runner': _mod('mmcv.runner', force_fp32=ident, auto_fp16=ident, BaseModule=_Base),
+        'mmcv.utils': _mod('mmcv.utils', to_2tuple=lambda v: (v, v) if not isinstance(v, (tuple, list)) else tuple(v)),
+        'mmdet': _mod('mmdet'),
+        'mmdet.core': _mod('mmdet.core', anchor_inside_flags=LO.anchor_inside_flags, images_to_levels=LO.images_to_levels,
+                           multi_apply=LO.multi_apply, unmap=LO.unmap),
+        'mmdet.models': _mod('mmdet.models'), 'mmdet.models.dense_heads': _mod('mmdet.models.dense_heads'),
+        'mmdet.models.dense_heads.anchor_head': _mod('mmdet.models.dense_heads.anchor_head',
+                                                     AnchorHead=type('AnchorHead', (nn.Module,), {})),
+        'mmdet.models.losses': _mod('mmdet.models.losses', accuracy=LO.accuracy),
+        'mmdet.models.utils': _mod('mmdet.models.utils',
+                                   build_linear_layer=lambda cfg, *a, **k: nn.Linear(*a, **k)),
+        'mmrotate': _mod('mmrotate'),
+        'mmrotate.core': _mod('mmrotate.core', obb2xyxy=T.obb2xyxy, build_bbox_coder=build_bbox_coder,
+                              multiclass_nms_rotated=_never),
+        _PKG: _mod(_PKG, __path__=[]),
+        f'{_PKG}.builder': _mod(f'{_PKG}.builder', ROTATED_HEADS=_Registry(), build_loss=LO.build_loss),
+        f'{_PKG}.dense_heads': _mod(f'{_PKG}.dense_heads', __path__=[]),
+        f'{_PKG}.roi_heads': _mod(f'{_PKG}.roi_heads', __path__=[]),
+        f'{_PKG}.roi_heads.bbox_heads': _mod(f'{_PKG}.roi_heads.bbox_heads', __path__=[]),
+    }
+    saved = {k: sys.modules.get(k) for k in shims}
+    sys.modules.update(shims)
+    try:
+        mods = []
+        for name, parts in FILES.items():
+            spec = importlib.util.spec_from_file_location(name, os.path.join(REF_ROOT, *parts))
+            mod = importlib.util.module_from_spec(spec)
+            sys.modules[name] = mod
+            spec.loader.exec_module(mod)
+            mods.append(mod)
+    finally:
+        for k, v in saved.items():
+            if k.startswith(_PKG):
+                continue
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    return tuple(mods)
+
+
+class _Cfg(dict):
+    __getattr__ = dict.__getitem__
+
+
+class _FixedSampling:
+    """stands in for SamplingResult + sampler: the positives / negatives are the ones the caller chose"""
+
+    def __init__(self, pos_inds, neg_inds, bboxes, gt_bboxes, assign_gt_inds, gt_labels=None):
+        self.pos_inds, self.neg_inds = pos_inds, neg_inds
+        self.pos_bboxes, self.neg_bboxes = bboxes[pos_inds], bboxes[neg_inds]
+        self.pos_assigned_gt_inds = assign_gt_inds[pos_inds] - 1
+        self.pos_gt_bboxes = gt_bboxes[self.pos_assigned_gt_inds] if gt_bboxes.numel() else gt_bboxes.view(-1, 4)
+        self.pos_gt_labels = gt_labels[self.pos_assigned_gt_inds] if gt_labels is not None else None
+
+
+def make_reference_rpn_head(mlvl_anchors, assign_cfg, picks, means, stds, beta, allowed_border=0, pos_weight=-1):
+    """A live-reference OrientedRPNHead object with just the attributes its loss path reads (AnchorHead.__init__ is
+    mmdet code and is not run): anchors from `mlvl_anchors` (all valid), assigner = oracle/assign_oracle.py's MaxIoU rule
+    on the inside anchors, sampler = `picks[i]` = (pos flat indices, neg flat indices) of image i -- translated to the
+    compacted inside-anchor numbering the reference works in."""
+    import numpy as np
+    import torch
+    from oracle import assign_oracle
+    _, O, _ = load()
+    _, C, _ = ref_rpn.load()
+    head = O.OrientedRPNHead.__new__(O.OrientedRPNHead)
+    nn.Module.__init__(head)
+    head.version, head.num_classes, head.cls_out_channels, head.use_sigmoid_cls = 'le90', 1, 1, True
+    head.sampling, head.reg_decoded_bbox = True, False
+    head.train_cfg = _Cfg(allowed_border=allowed_border, pos_weight=pos_weight)
+    head.bbox_coder = C.MidpointOffsetCoder(target_means=means, target_stds=stds, angle_range='le90')
+    head.loss_cls = LO.CrossEntropyLoss(use_sigmoid=True, loss_weight=1.0)
+    head.loss_bbox = LO.SmoothL1Loss(beta=beta, loss_weight=1.0)
+    head.anchor_generator = _Cfg(num_levels=len(mlvl_anchors))
+    state = {'img': 0}
+
+    def get_anchors(featmap_sizes, img_metas, device='cpu'):
+        n = len(img_metas)
+        return ([[a.clone() for a in mlvl_anchors] for _ in range(n)],
+                [[torch.ones(a.shape[0], dtype=torch.bool) for a in mlvl_anchors] for _ in range(n)])
+
+    class _Assigner:
+        def assign(self, anchors, gt_hbboxes, gt_bboxes_ignore, gt_labels):
+            gi, mo, _, _ = assign_oracle.max_iou_assign(anchors.numpy(), gt_hbboxes.numpy(), False, **assign_cfg)
+            return _Cfg(gt_inds=torch.from_numpy(gi), max_overlaps=torch.from_numpy(np.asarray(mo)))
+
+    class _Sampler:
+        def sample(self, assign_result, anchors, gt_hbboxes):
+            i = state['img']
+            state['img'] += 1
+            flat = torch.cat(mlvl_anchors)
+            inside = LO.anchor_inside_flags(flat, torch.ones(flat.shape[0], dtype=torch.bool), (10 ** 9, 10 ** 9), -1)
+            inside = state['inside']
+            remap = torch.cumsum(inside.long(), 0) - 1  # flat index -> index among the inside anchors
+            pos, neg = remap[picks[i][0].long()], remap[picks[i][1].long()]
+            gi = assign_result.gt_inds
+            assert bool((gi[pos] > 0).all()) and bool((gi[neg] == 0).all()), 'the picks disagree with the assignment'
+            return _FixedSampling(pos, neg, anchors, gt_hbboxes, gi)
+
+    head.get_anchors = get_anchors
+    head.assigner, head.sampler = _Assigner(), _Sampler()
+    head._oracle_state = state
+    return head

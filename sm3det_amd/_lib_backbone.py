@@ -22,6 +22,7 @@ class GemmDesc(ctypes.Structure):
         ('bias', P), ('aux_in', P), ('aux_out', P), ('gamma', P), ('rowscale', P),
         ('rows_per_scale', ctypes.c_int32), ('ld_aux', ctypes.c_int32),
         ('colsum_out', P), ('counters', P), ('tuning', ctypes.c_int32), ('compute', ctypes.c_int32),
+        ('io', ctypes.c_int32),
     ]
 
 
@@ -162,10 +163,15 @@ def gemm_counters(device):
     return t
 
 
+IO_A16, IO_B16, IO_C16, IO_X16 = 1, 2, 4, 8  # sm3_gemm_desc.io: tensors stored as fp16 (the AMP data path)
+
+
 def gemm(mode, A, B, C, M, N, K, *, epilogue=EPI_NONE, bias=None, aux_in=None, aux_out=None, gamma=None,
          rowscale=None, rows_per_scale=1, offsets=None, num_groups=1, splits=0, lda=None, ldb=None, ldc=None,
          ld_aux=None, colsum_out=None):
-    """Enqueue one GEMM of the family on torch's current stream.  All tensors fp32, on the current device.
+    """Enqueue one GEMM of the family on torch's current stream.  Tensors fp32 on the current device -- or, under
+    COMPUTE == 1, fp16 for the operands / outputs the AMP data path stores as half: the `io` flags are derived from the
+    tensors' dtypes, and a combination the library does not implement fails loudly.
     splits: 0 = let the library choose the split-K factor, 1 = none."""
     from . import _lib
     L = _lib.lib()
@@ -197,6 +203,13 @@ def gemm(mode, A, B, C, M, N, K, *, epilogue=EPI_NONE, bias=None, aux_in=None, a
     d.counters = _p(gemm_counters(C.device))
     d.tuning = TUNING
     d.compute = COMPUTE
+    h = torch.float16
+    aux = aux_in if aux_in is not None else aux_out
+    d.io = ((IO_A16 if A.dtype == h else 0) | (IO_B16 if B.dtype == h else 0) | (IO_C16 if C.dtype == h else 0) |
+            (IO_X16 if (aux is not None and aux.dtype == h) else 0))
+    if d.io and not COMPUTE:
+        from ._lib import SM3Error
+        raise SM3Error('fp16 tensors reached an fp32 GEMM (outside amp.autocast)')
     ws = None
     nbytes = L.sm3_gemm_f32_workspace_bytes(ctypes.byref(d))
     if nbytes:
@@ -206,9 +219,11 @@ def gemm(mode, A, B, C, M, N, K, *, epilogue=EPI_NONE, bias=None, aux_in=None, a
     if PROFILE is not None and PROFILE_SHAPES:
         tag += f' {M}x{N}x{K} g{num_groups} e{epilogue} s{splits}'
     # algorithmic bytes: each operand read once, the output (and the epilogue's auxiliary tensor) written once
-    nb_alg = 4.0 * (rows * (M if mode == TN else K) + (rows if mode == TN else K) * N + M * N * max(num_groups if mode == TN else 1, 1))
+    ea, eb, ec = A.element_size(), B.element_size(), C.element_size()
+    nb_alg = (ea * rows * (M if mode == TN else K) + eb * (rows if mode == TN else K) * N +
+              ec * M * N * max(num_groups if mode == TN else 1, 1))
     if epilogue in (EPI_BIAS_GELU, EPI_BIAS_SCALE_RES, EPI_GELU_BWD):
-        nb_alg += 4.0 * M * N * (2 if epilogue == EPI_BIAS_SCALE_RES else 1)
+        nb_alg += (aux.element_size() if aux is not None else 4.0) * M * N * (2 if epilogue == EPI_BIAS_SCALE_RES else 1)
     with _Prof(tag, 2.0 * rows * N * (M if mode == TN else K), nb_alg):
         _lib.check(L.sm3_gemm_f32(ctypes.byref(d), _p(ws), nbytes, _lib.stream_ptr()), 'gemm_f32')
 

@@ -231,13 +231,27 @@ def layer_norm(x, w, b, eps, patch_major=False, H=0, W=0):
 
 
 # ------------------------------------------------------------------------------------------------ shared block pieces
+def _half():
+    """AMP data path (amp.autocast / wrap_fp16_model): the LayerNorm output that feeds the GEMMs and the three 4C-wide
+    tensors of a block (GELU output, GELU', their gradient) live in HBM as fp16 -- what autocast makes of the reference's
+    FFN (nn.Linear outputs are half tensors, mmcv/mmcv/runner/fp16_utils.py:71-149).  Weights, biases, the residual stream,
+    LayerNorm statistics, router, combine and every C-wide gradient stay fp32.  SM3_AMP_STORAGE=fp32 keeps the round-2
+    behaviour (fp32 tensors, operands rounded in the GEMM loader) for A/B measurements."""
+    return torch.float16 if (LB.COMPUTE == 1 and AMP_HALF_STORAGE) else torch.float32
+
+
+AMP_HALF_STORAGE = os.environ.get('SM3_AMP_STORAGE', 'fp16') != 'fp32'
+
+
 def _dw_ln_forward(x, w49, bdw, lnw, lnb, eps, B, H, W, C):
     T = B * H * W
     u = _e(T, C, like=x)
     call('dwconv7_fwd', x, w49, bdw, None, u, B, H, W, C, 0, nbytes=8.0 * T * C)
-    xn = _e(T, C, like=x)
+    hd = _half()
+    xn = _e(T, C, like=x, dtype=hd)
     mean, rstd = _e(T, like=x), _e(T, like=x)
-    call('layernorm_fwd', u, lnw, lnb, float(eps), xn, mean, rstd, T, C, 0, H, W, nbytes=8.0 * T * C)
+    call('layernorm_fwd', u, lnw, lnb, float(eps), xn, mean, rstd, T, C, 2 if hd == torch.float16 else 0, H, W,
+         nbytes=(4.0 + xn.element_size()) * T * C)
     return u, xn, mean, rstd
 
 
@@ -267,7 +281,7 @@ class _DenseBlock(Function):
         T, C = x.shape
         Hd = w1.shape[0]
         u, xn, mean, rstd = _dw_ln_forward(x, w49, bdw, lnw, lnb, eps, B, H, W, C)
-        hpre, act = _e(T, Hd, like=x), _e(T, Hd, like=x)
+        hpre, act = _e(T, Hd, like=x, dtype=xn.dtype), _e(T, Hd, like=x, dtype=xn.dtype)
         gemm(LB.NT, xn, w1, act, T, Hd, C, epilogue=LB.EPI_BIAS_GELU, bias=b1, aux_out=hpre)  # hpre := gelu'(h)
         y, out = _e(T, C, like=x), _e(T, C, like=x)
         gemm(LB.NT, act, w2, out, T, C, Hd, epilogue=LB.EPI_BIAS_SCALE_RES, bias=b2, aux_in=x, aux_out=y,
@@ -296,7 +310,7 @@ class _DenseBlock(Function):
         _deferred_reduce(ws, T, C, 2 * C, dgdb)
         dgamma, db2 = dgdb[0], dgdb[1]
         dw2 = _on_side(dev, lambda: _tn(dy, act, C, Hd, T))
-        dh, db1 = _e(T, Hd, like=x), _e(Hd, like=x)
+        dh, db1 = _e(T, Hd, like=x, dtype=hpre.dtype), _e(Hd, like=x)
         gemm(LB.NN, dy, w2, dh, T, Hd, C, epilogue=LB.EPI_GELU_BWD, aux_in=hpre, colsum_out=db1)
         dw1 = _on_side(dev, lambda: _tn(dh, xn, Hd, C, T))
         dxn = _e(T, C, like=x)  # not dy's buffer: the side-stream wgrad may still be reading dy
@@ -370,10 +384,14 @@ class _MoEBlock(Function):
         nb = _lib.lib().sm3_moe_plan_workspace_bytes(T, E)
         ws = _lib.workspace(nb, x.device)
         call('moe_plan', top_idx, m, T, E, k, offsets, slot_token, token_slot, ws, nb)
-        xslot = _e(S, C, like=x)
-        call('moe_dispatch', xn, slot_token, xslot, S, C, nbytes=8.0 * S * C)
+        xslot = _e(S, C, like=x, dtype=xn.dtype)
+        if xn.dtype == torch.float16:  # a row gather: half rows of C elements move as C / 2 32-bit words
+            call('moe_dispatch', xn.view(torch.float32), slot_token, xslot.view(torch.float32), S, C // 2,
+                 nbytes=4.0 * S * C)
+        else:
+            call('moe_dispatch', xn, slot_token, xslot, S, C, nbytes=8.0 * S * C)
         # experts: grouped GEMM pair over the expert-major slots
-        hpre, act = _e(S, Hd, like=x), _e(S, Hd, like=x)
+        hpre, act = _e(S, Hd, like=x, dtype=xn.dtype), _e(S, Hd, like=x, dtype=xn.dtype)
         gemm(LB.NT, xslot, w1, act, S, Hd, C, epilogue=LB.EPI_BIAS_GELU, bias=b1, aux_out=hpre, offsets=offsets,
              num_groups=E)
         yslot = _e(S, C, like=x)
@@ -424,7 +442,7 @@ class _MoEBlock(Function):
         db2 = _e(E, C, like=x)
 
         dw2 = _on_side(dev, lambda: _tn_bias(dyslot, act, C, Hd, S, db2, offsets=offsets, num_groups=E))
-        dh, db1 = _e(S, Hd, like=x), _e(E, Hd, like=x)
+        dh, db1 = _e(S, Hd, like=x, dtype=hpre.dtype), _e(E, Hd, like=x)
         gemm(LB.NN, dyslot, w2, dh, S, Hd, C, epilogue=LB.EPI_GELU_BWD, aux_in=hpre, offsets=offsets, num_groups=E,
              colsum_out=db1)
         dw1 = _on_side(dev, lambda: _tn(dh, xslot, Hd, C, S, offsets=offsets, num_groups=E))

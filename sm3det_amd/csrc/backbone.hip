@@ -115,8 +115,10 @@ __global__ __launch_bounds__(PR_THREADS) void partials_reduce_kernel(const float
 // ============================================================================================== LayerNorm rows
 // out_mode 0: y row = token; 1: patch-major rows for the 2x2/s2 downsample conv: token (b,h,w) -> row
 // (b,h/2,w/2), column block ((h&1)*2 + (w&1))*C  (so the conv becomes one NT GEMM with K = 4C).
+// out_mode 2: token rows like mode 0, stored as fp16 (the AMP data path: the block norm's output only feeds GEMMs whose
+// operands are rounded to half anyway -- the reference's autocast casts it on entry to nn.Linear).
 __device__ __forceinline__ long ln_out_offset(long tok, int C, int mode, int H, int W) {
-  if (mode == 0) return tok * C;
+  if (mode == 0 || mode == 2) return tok * C;
   const int w = tok % W;
   const long t2 = tok / W;
   const int h = t2 % H;
@@ -165,7 +167,16 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 #pragma unroll
     for (int i = 0; i < NV; i++) {
       const int q = lg + i * G;
-      if (q < nq) st4(y + ob + 4 * q, (v[i] - mean) * rstd * ld4(w + 4 * q) + ld4(b + 4 * q));
+      if (q < nq) {
+        const f32x4 o = (v[i] - mean) * rstd * ld4(w + 4 * q) + ld4(b + 4 * q);
+        if (mode == 2) {
+          typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+          *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(y) + ob + 4 * q) =
+              f16x4{(_Float16)o[0], (_Float16)o[1], (_Float16)o[2], (_Float16)o[3]};
+        } else {
+          st4(y + ob + 4 * q, o);
+        }
+      }
     }
     if (lg == 0) {
       if (mean_o) mean_o[tok] = mean;
@@ -664,7 +675,7 @@ int sm3_stem_patchify(const float* x, float* a, int B, int H, int W, sm3_stream_
 
 int sm3_layernorm_fwd(const float* x, const float* w, const float* b, float eps, float* y, float* mean, float* rstd,
                       long T, int C, int out_mode, int H, int W, sm3_stream_t stream) {
-  if (!x || !w || !b || !y || T < 0 || C <= 0 || (C & 3)) return SM3_ERR_INVALID_ARG;
+  if (!x || !w || !b || !y || T < 0 || C <= 0 || (C & 3) || out_mode < 0 || out_mode > 2) return SM3_ERR_INVALID_ARG;
   if (out_mode == 1 && ((H & 1) || (W & 1))) return SM3_ERR_INVALID_ARG;
   if (T == 0) return SM3_OK;
   hipStream_t st = (hipStream_t)stream;

@@ -22,7 +22,8 @@ static int by_tile16(const GemmParams& p, int tile, int bk, dim3 grid, hipStream
   return SM3_ERR_INVALID_ARG;
 }
 
-int launch_nt16(const GemmParams& p, int epi, int tile, int bk, dim3 grid, hipStream_t st) {
+int launch_nt16(const GemmParams& p, int epi, int tile, int bk, int io, dim3 grid, hipStream_t st) {
+  if (io) return launch_nt_h16(p, epi, tile, bk, io, grid, st);
   switch (epi) {
     case EPI_NONE: return by_tile16<MODE_NT, EPI_NONE>(p, tile, bk, grid, st);
     case EPI_BIAS: return by_tile16<MODE_NT, EPI_BIAS>(p, tile, bk, grid, st);
@@ -33,13 +34,15 @@ int launch_nt16(const GemmParams& p, int epi, int tile, int bk, dim3 grid, hipSt
   return SM3_ERR_INVALID_ARG;
 }
 
-int launch_nn16(const GemmParams& p, int epi, int tile, int bk, dim3 grid, hipStream_t st) {
+int launch_nn16(const GemmParams& p, int epi, int tile, int bk, int io, dim3 grid, hipStream_t st) {
+  if (io) return launch_nn_h16(p, epi, tile, bk, io, grid, st);
   if (epi == EPI_NONE) return by_tile16<MODE_NN, EPI_NONE>(p, tile, bk, grid, st);
   if (epi == EPI_GELU_BWD) return by_tile16<MODE_NN, EPI_GELU_BWD>(p, tile, bk, grid, st);
   return SM3_ERR_INVALID_ARG;
 }
 
-int launch_tn16(const GemmParams& p, int tile, int bk, dim3 grid, hipStream_t st) {
+int launch_tn16(const GemmParams& p, int tile, int bk, int io, dim3 grid, hipStream_t st) {
+  if (io) return launch_tn_h16(p, tile, bk, io, grid, st);
   switch (tile) {
     case 0: go16<MODE_TN, EPI_NONE, T128x128>(p, bk, grid, st); return SM3_OK;
     case 1: go16<MODE_TN, EPI_NONE, T128x96>(p, bk, grid, st); return SM3_OK;

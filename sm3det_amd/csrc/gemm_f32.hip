@@ -377,6 +377,8 @@ int sm3_gemm_f32(const sm3_gemm_desc* d, void* workspace, size_t workspace_bytes
   if (d->mode == MODE_TN && d->epilogue != EPI_NONE) return SM3_ERR_INVALID_ARG;
   if (d->mode != MODE_NT && d->mode != MODE_NN && d->mode != MODE_TN) return SM3_ERR_INVALID_ARG;
   if (d->compute != 0 && d->compute != 1) return SM3_ERR_INVALID_ARG;
+  if (d->io != 0 && (d->compute != 1 || d->io < 0 || d->io > 15)) return SM3_ERR_INVALID_ARG;
+  if ((d->io & 3) && ((d->lda & 7) || (d->ldb & 7) || (d->M & 1) || (d->N & 1))) return SM3_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   const Cfg c = choose_cfg(d);
   {  // the kernel addresses each operand as block base + 32-bit byte offset (buffer loads): keep the spans below 2^31.
@@ -427,7 +429,8 @@ int sm3_gemm_f32(const sm3_gemm_desc* d, void* workspace, size_t workspace_bytes
       p.csum_stride = d->M;
     }
     dim3 grid(c.ntn * c.ntm, 1, c.groups * c.splits);
-    const int rc = d->compute == 1 ? launch_tn16(p, c.tile, c.bk, grid, st) : launch_tn(p, c.tile, c.bk, 0, grid, st);
+    const int rc = d->compute == 1 ? launch_tn16(p, c.tile, c.bk, d->io, grid, st)
+                                   : launch_tn(p, c.tile, c.bk, 0, grid, st);
     if (rc) return rc;
     if (c.splits > 1 && !c.fixup) {
       launch_splitk_reduce((const float*)workspace, out, mn, c.splits, c.groups, nullptr, 0, 0, st,
@@ -439,8 +442,8 @@ int sm3_gemm_f32(const sm3_gemm_desc* d, void* workspace, size_t workspace_bytes
   dim3 grid(c.ntn * c.ntm, 1, c.splits);
   int rc;
   if (d->compute == 1)
-    rc = d->mode == MODE_NT ? launch_nt16(p, d->epilogue, c.tile, c.bk, grid, st)
-                            : launch_nn16(p, d->epilogue, c.tile, c.bk, grid, st);
+    rc = d->mode == MODE_NT ? launch_nt16(p, d->epilogue, c.tile, c.bk, d->io, grid, st)
+                            : launch_nn16(p, d->epilogue, c.tile, c.bk, d->io, grid, st);
   else
     rc = d->mode == MODE_NT ? launch_nt(p, d->epilogue, c.tile, c.bk, 0, grid, st)
                             : launch_nn(p, d->epilogue, c.tile, c.bk, 0, grid, st);

@@ -161,9 +161,20 @@ constexpr int smem_floats() {
   return 2 * BK * (lda + ldb);
 }
 
-template <int MODE, int EPI, int BK, class TL, int GATHER, int F16 = 0, int CSUM = 0>
+// IO (F16 = 1 only): which tensors live in HBM as fp16 -- the AMP data path (mmcv wrap_fp16_model / autocast: the outputs of
+// nn.Linear are half tensors, mmcv/mmcv/runner/fp16_utils.py:71-149).  Weights, biases, the residual stream and every
+// C-wide gradient stay fp32; the LayerNorm output that feeds the GEMMs and the three 4C-wide tensors of a block (GELU
+// output, GELU', their gradient) are fp16: half the bytes of the launches that move them.
+constexpr int IO_A16 = 1, IO_B16 = 2, IO_C16 = 4, IO_X16 = 8;  // A operand, B operand, C output, aux_in / aux_out
+
+template <int MODE, int EPI, int BK, class TL, int GATHER, int F16 = 0, int CSUM = 0, int IO = 0>
 __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kernel(GemmParams p) {
   constexpr int BM = TL::BM, BN = TL::BN, TI = TL::TI, TJ = TL::TJ, WN = TL::WN, WM = TL::WM;
+  constexpr bool A16 = (IO & IO_A16) != 0, B16 = (IO & IO_B16) != 0, C16 = (IO & IO_C16) != 0, X16 = (IO & IO_X16) != 0;
+  static_assert(IO == 0 || (F16 && !GATHER), "fp16 storage only with fp16 operands");
+  static_assert(!B16 || MODE == MODE_TN, "fp16 B operand: only the weight-gradient form (weights stay fp32)");
+  static_assert(!X16 || EPI == EPI_BIAS_GELU || EPI == EPI_GELU_BWD, "fp16 auxiliary tensor = GELU' only");
+  constexpr int EA = A16 ? 2 : 4, EB = B16 ? 2 : 4;  // bytes per element in HBM
   // A tile is written transposed (k-contiguous source) in NT/NN, directly (k-major source) in TN; B transposed in NT.
   // Leading dim of a transposed tile: the 4-byte scatter writes of one half-wave must hit 32 distinct banks:
   // BK=32 -> 8 k-quads x 4 rows need LD = 1 (mod 8); BK=16 -> 4 k-quads x 8 rows need LD = 2 (mod 8).
@@ -283,8 +294,11 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
   constexpr int T_ROWS = NTHREADS / KQ;
   const int t_kq = tid % KQ, t_r = tid / KQ;
   // direct loader (source k-major) of an operand with R columns: quad index tid + 256 i -> (k row, column quad)
-  constexpr int PA = A_TRANS ? (BM + T_ROWS - 1) / T_ROWS : (BK * (BM / 4) + NTHREADS - 1) / NTHREADS;
-  constexpr int PB = B_TRANS ? (BN + T_ROWS - 1) / T_ROWS : (BK * (BN / 4) + NTHREADS - 1) / NTHREADS;
+  // (direct pieces of an fp16-stored operand: one piece = 4 consecutive k of TWO adjacent columns, four 4-byte loads)
+  constexpr int PA = A_TRANS ? (BM + T_ROWS - 1) / T_ROWS
+                             : ((A16 ? (BK / 4) * (BM / 2) : BK * (BM / 4)) + NTHREADS - 1) / NTHREADS;
+  constexpr int PB = B_TRANS ? (BN + T_ROWS - 1) / T_ROWS
+                             : ((B16 ? (BK / 4) * (BN / 2) : BK * (BN / 4)) + NTHREADS - 1) / NTHREADS;
   constexpr int NP = PA + PB;  // pieces (one 16-byte load per thread each) per k-tile
   constexpr int KP = BK / 2;   // k-pairs = MFMA groups per k-tile
   static_assert(NP <= KP, "piece schedule: one load and one store slot per k-pair");
@@ -345,7 +359,7 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
         }
       } else {
         pa[i] = Ag + (long)r * p.lda + 4 * t_kq + (long)kbase * BK;
-        oa[i] = (unsigned)(((long)(r - row0) * p.lda + 4 * t_kq) * 4);
+        oa[i] = (unsigned)(((long)(r - row0) * p.lda + 4 * t_kq) * EA);
       }
     } else {
       constexpr int QR = BM / 4;
@@ -362,12 +376,20 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
         const int g4 = min(idx / BM, BK / 4 - 1), c = idx % BM;  // surplus units repeat the last k-quad
         ha[i] = ((g4 >> 1) * LDA16 + c) * 4 + 2 * (g4 & 1);
         oa[i] = (unsigned)(((long)(4 * g4) * p.lda + min(m0 + c, p.M - 1)) * 4);
+        if (A16) {
+          // unit = (k-octet, column pair, k-quad parity), parity fastest: the two 8-byte LDS stores of 16 consecutive
+          // lanes then spread over 16 banks (2-way) instead of 8 (column pairs are 32 B apart in the image)
+          const int par = idx & 1, u = idx >> 1;
+          const int g8 = min(u / (BM / 2), BK / 8 - 1), cc = 2 * (u % (BM / 2));
+          ha[i] = (g8 * LDA16 + cc) * 4 + 2 * par;
+          oa[i] = (unsigned)(((long)(8 * g8 + 4 * par) * p.lda + min(m0 + cc, p.M - 2)) * 2);
+        }
       }
     }
   }
-  if (MODE == MODE_TN) a_base = reinterpret_cast<const char*>(Ag + (long)row0 * p.lda);
+  if (MODE == MODE_TN) a_base = reinterpret_cast<const char*>(Ag) + (long)row0 * p.lda * EA;
   else if (GATHER) a_base = reinterpret_cast<const char*>(Ag) - (long)(p.sW + 1) * p.cC * 4;
-  else a_base = reinterpret_cast<const char*>(Ag + (long)row0 * p.lda + (long)kbase * BK);
+  else a_base = reinterpret_cast<const char*>(Ag) + ((long)row0 * p.lda + (long)kbase * BK) * EA;
 #pragma unroll
   for (int i = 0; i < PB; i++) {
     kb[i] = 0;
@@ -406,24 +428,31 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
 #pragma unroll
     for (int i = 0; i < PB; i++) {
       const int idx = tid + NTHREADS * i;
-      const int g4 = min(idx / BN, BK / 4 - 1), c = idx % BN;
-      hb[i] = ((g4 >> 1) * LDB16 + c) * 4 + 2 * (g4 & 1);
-      ob[i] = (unsigned)(((long)(4 * g4) * p.ldb + min(n0 + c, p.N - 1)) * 4);
+      if (B16) {
+        const int par = idx & 1, u = idx >> 1;
+        const int g8 = min(u / (BN / 2), BK / 8 - 1), cc = 2 * (u % (BN / 2));
+        hb[i] = (g8 * LDB16 + cc) * 4 + 2 * par;
+        ob[i] = (unsigned)(((long)(8 * g8 + 4 * par) * p.ldb + min(n0 + cc, p.N - 2)) * 2);
+      } else {
+        const int g4 = min(idx / BN, BK / 4 - 1), c = idx % BN;
+        hb[i] = ((g4 >> 1) * LDB16 + c) * 4 + 2 * (g4 & 1);
+        ob[i] = (unsigned)(((long)(4 * g4) * p.ldb + min(n0 + c, p.N - 1)) * 4);
+      }
     }
   }
   if (MODE == MODE_NT) b_base = reinterpret_cast<const char*>(Bg + (long)n0 * p.ldb + (long)kbase * BK);
   else if (MODE == MODE_NN) b_base = reinterpret_cast<const char*>(Bg + (GATHER ? 0 : (long)kbase * BK * p.ldb));
   else if (GATHER == 2) b_base = reinterpret_cast<const char*>(Bg) - (long)(p.sW + 1) * p.cC * 4;
-  else b_base = reinterpret_cast<const char*>(Bg + (long)row0 * p.ldb);
+  else b_base = reinterpret_cast<const char*>(Bg) + (long)row0 * p.ldb * EB;
   // piece q in [0, NP): q < PA -> A piece q, else B piece q - PA.  tail == false (the bulk of the k-loop): tile kt is a
   // complete tile strictly before the last one, so no clamp and no select is issued; tail == true: the last steps, where
   // kt may be clamped and TN reduction rows past the segment end are zeroed.
-  auto make_rsrc = [](const char* base, long valid_floats) {
+  auto make_rsrc = [](const char* base, long valid_floats, int esize) {
     // readfirstlane: base and extent are block-uniform by construction, this makes them provably so (no waterfall
     // loop).  The extent is the operand's valid span seen from the base: a stray offset reads 0 instead of faulting.
     const unsigned long long u = reinterpret_cast<unsigned long long>(base);
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
-    const long vb = valid_floats > 0 ? valid_floats * 4 : 0;
+    const long vb = valid_floats > 0 ? valid_floats * esize : 0;
     const int nrec = __builtin_amdgcn_readfirstlane((int)(vb < 0x7fffffffl ? vb : 0x7fffffffl));
     return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, nrec,
                                              0x00020000);
@@ -443,7 +472,7 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
     b_valid = MODE == MODE_NT ? (long)(p.N - 1 - n0) * p.ldb + (p.K - (long)kbase * BK)
                               : (long)(p.K - (long)kbase * BK - 1) * p.ldb + p.N;
   }
-  const __amdgpu_buffer_rsrc_t a_rsrc = make_rsrc(a_base, a_valid), b_rsrc = make_rsrc(b_base, b_valid);
+  const __amdgpu_buffer_rsrc_t a_rsrc = make_rsrc(a_base, a_valid, EA), b_rsrc = make_rsrc(b_base, b_valid, EB);
   auto ldg = [&](const __amdgpu_buffer_rsrc_t& rs, long soff, unsigned voff) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, (int)soff, 0);
@@ -452,13 +481,18 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
   auto ldg1 = [&](const __amdgpu_buffer_rsrc_t& rs, long soff, unsigned voff) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, (int)soff, 0));
   };
+  auto ldg2 = [&](const __amdgpu_buffer_rsrc_t& rs, long soff, unsigned voff) {  // 8 bytes = 4 stored halves
+    typedef unsigned u32x2l __attribute__((ext_vector_type(2)));
+    const u32x2l v = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)voff, (int)soff, 0);
+    return f32x4{__builtin_bit_cast(float, v[0]), __builtin_bit_cast(float, v[1]), 0.f, 0.f};
+  };
   auto load_piece = [&](f32x4 (&ra)[PA], f32x4 (&rb)[PB], int q, int kt, bool tail) {
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     if (q < PA) {
       if (MODE == MODE_TN && F16) {
         // rows past the segment end lie beyond the descriptor's extent and read 0: no clamp, no select, bulk or tail
 #pragma unroll
-        for (int kk = 0; kk < 4; kk++) ra[q][kk] = ldg1(a_rsrc, ((long)kt * BK + kk) * p.lda * 4, oa[q]);
+        for (int kk = 0; kk < 4; kk++) ra[q][kk] = ldg1(a_rsrc, ((long)kt * BK + kk) * p.lda * EA, oa[q]);
       } else if (MODE == MODE_TN) {
         if (!tail) {
           ra[q] = ldg(a_rsrc, (long)kt * BK * p.lda * 4, oa[q]);
@@ -477,6 +511,8 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
         const long soff = ((long)(uy * p.sW + ux) * p.cC + c0) * 4;           // scalar
         const unsigned voff = (m9[q] & (1u << tap)) ? oa[q] : 0x7fff0000u;   // 3 VALU per load
         ra[q] = ldg(a_rsrc, soff, voff);
+      } else if (A16) {
+        ra[q] = ldg2(a_rsrc, (long)kt * BK * 2, oa[q]);
       } else {
         ra[q] = ldg(a_rsrc, (long)kt * BK * 4, oa[q]);
       }
@@ -512,7 +548,7 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
           rb[i] = ok ? v : zero4;
         } else if (F16) {
 #pragma unroll
-          for (int kk = 0; kk < 4; kk++) rb[i][kk] = ldg1(b_rsrc, ((long)kt * BK + kk) * p.ldb * 4, ob[i]);
+          for (int kk = 0; kk < 4; kk++) rb[i][kk] = ldg1(b_rsrc, ((long)kt * BK + kk) * p.ldb * EB, ob[i]);
         } else if (!tail) {
           rb[i] = ldg(b_rsrc, (long)kt * BK * p.ldb * 4, ob[i]);
         } else {
@@ -558,8 +594,21 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
     auto pack2 = [](float x, float y) {  // round-to-nearest-even, like a torch .half() cast
       return __builtin_bit_cast(uint32_t, f16x2{(_Float16)x, (_Float16)y});
     };
+    auto bits = [](float x) { return __builtin_bit_cast(uint32_t, x); };
+    // a direct piece of an fp16-stored operand holds w[k] = (column c, column c + 1) at four consecutive k: regroup into
+    // the two columns' k-quads (v_perm_b32: low halves / high halves of two words)
+    auto lo2 = [&](float w0, float w1) { return __builtin_amdgcn_perm(bits(w1), bits(w0), 0x05040100u); };
+    auto hi2 = [&](float w0, float w1) { return __builtin_amdgcn_perm(bits(w1), bits(w0), 0x07060302u); };
     if (q < PA) {
-      if (F16) {
+      if (F16 && A16 && A_TRANS) {
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<u32x2*>(Aw + buf * A_ST16 + ha[q]) = u32x2{bits(ra[q][0]), bits(ra[q][1])};  // already halves
+      } else if (F16 && A16) {
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        uint32_t* d = Aw + buf * A_ST16 + ha[q];
+        *reinterpret_cast<u32x2*>(d) = u32x2{lo2(ra[q][0], ra[q][1]), lo2(ra[q][2], ra[q][3])};
+        *reinterpret_cast<u32x2*>(d + 4) = u32x2{hi2(ra[q][0], ra[q][1]), hi2(ra[q][2], ra[q][3])};
+      } else if (F16) {
         typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
         // every F16 piece is four consecutive k of one row / column -> 8 contiguous bytes
         *reinterpret_cast<u32x2*>(Aw + buf * A_ST16 + ha[q]) = u32x2{pack2(ra[q][0], ra[q][1]), pack2(ra[q][2], ra[q][3])};
@@ -574,7 +623,12 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
       }
     } else {
       const int i = q - PA;
-      if (F16) {
+      if (F16 && B16) {
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        uint32_t* d = Bw + buf * B_ST16 + hb[i];
+        *reinterpret_cast<u32x2*>(d) = u32x2{lo2(rb[i][0], rb[i][1]), lo2(rb[i][2], rb[i][3])};
+        *reinterpret_cast<u32x2*>(d + 4) = u32x2{hi2(rb[i][0], rb[i][1]), hi2(rb[i][2], rb[i][3])};
+      } else if (F16) {
         typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
         *reinterpret_cast<u32x2*>(Bw + buf * B_ST16 + hb[i]) = u32x2{pack2(rb[i][0], rb[i][1]), pack2(rb[i][2], rb[i][3])};
       } else {
@@ -828,7 +882,32 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
       const int row = m0 + wm0 + 32 * i + sr + 8 * it;
       const bool ok = row < m_lim && col < p.N;
       const long ai = ok ? (long)row * p.ld_aux + col : 0;
-      dst[it] = *reinterpret_cast<const f32x4*>(p.aux_in + ai);
+      if (X16) {
+        typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+        const f16x4 h = *reinterpret_cast<const f16x4*>(reinterpret_cast<const _Float16*>(p.aux_in) + ai);
+        dst[it] = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+      } else {
+        dst[it] = *reinterpret_cast<const f32x4*>(p.aux_in + ai);
+      }
+    }
+  };
+  // output stores: fp32, or fp16 (round-to-nearest-even, like a torch .half() cast) where the tensor is stored as half
+  auto st_c = [&](long ci, const f32x4& v) {
+    if (C16) {
+      typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+      *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(Cg) + ci) =
+          f16x4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+    } else {
+      *reinterpret_cast<f32x4*>(Cg + ci) = v;
+    }
+  };
+  auto st_x = [&](long ai, const f32x4& v) {
+    if (X16) {
+      typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+      *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(p.aux_out) + ai) =
+          f16x4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+    } else {
+      *reinterpret_cast<f32x4*>(p.aux_out + ai) = v;
     }
   };
   if (AUX_IN) {
@@ -859,17 +938,17 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
       for (int it = 0; it < 4; it++) {
         const int row = m0 + wm0 + 32 * i + sr + 8 * it;
         if (row >= m_lim || !col_ok) continue;
-        float* cp = Cg + c_base + (long)row * p.ldc + col;
+        const long ci = c_base + (long)row * p.ldc + col;
         const long ai = (long)row * p.ld_aux + col;
         if (EPI == EPI_NONE) {
-          *reinterpret_cast<f32x4*>(cp) = v[it];
+          st_c(ci, v[it]);
         } else if (EPI == EPI_BIAS) {
-          *reinterpret_cast<f32x4*>(cp) = v[it] + bv;
+          st_c(ci, v[it] + bv);
         } else if (EPI == EPI_BIAS_RELU) {
           f32x4 o = v[it] + bv;
 #pragma unroll
           for (int e = 0; e < 4; e++) o[e] = fmaxf(o[e], 0.f);
-          *reinterpret_cast<f32x4*>(cp) = o;
+          st_c(ci, o);
         } else if (EPI == EPI_BIAS_GELU) {
           const f32x4 h = v[it] + bv;
           f32x4 y, dy;
@@ -880,16 +959,16 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
             y[e] = ye;
             dy[e] = de;
           }
-          *reinterpret_cast<f32x4*>(p.aux_out + ai) = dy;
-          *reinterpret_cast<f32x4*>(cp) = y;
+          st_x(ai, dy);
+          st_c(ci, y);
         } else if (EPI == EPI_BIAS_SCALE_RES) {
           const f32x4 y = v[it] + bv;
-          *reinterpret_cast<f32x4*>(p.aux_out + ai) = y;
+          *reinterpret_cast<f32x4*>(p.aux_out + ai) = y;  // y and the residual stream are fp32 in every data path
           const float rsc = p.rowscale ? p.rowscale[row / p.rows_per_scale] : 1.f;
-          *reinterpret_cast<f32x4*>(cp) = pre[t % (AUX_DEPTH + 1)][it] + (gv * rsc) * y;
+          st_c(ci, pre[t % (AUX_DEPTH + 1)][it] + (gv * rsc) * y);
         } else if (EPI == EPI_GELU_BWD) {
           const f32x4 o = v[it] * pre[t % (AUX_DEPTH + 1)][it];
-          *reinterpret_cast<f32x4*>(cp) = o;
+          st_c(ci, o);
           cs[j] += o;
         }
       }
@@ -924,9 +1003,15 @@ int launch_nt(const GemmParams& p, int epi, int tile, int bk, int gather, dim3 g
 int launch_nn(const GemmParams& p, int epi, int tile, int bk, int gather, dim3 grid, hipStream_t st);
 int launch_tn(const GemmParams& p, int tile, int bk, int gather, dim3 grid, hipStream_t st);
 // fp16-operand variants (gemm_f16.hip): k-step 16 | 32, tiles 0 / 1 / 5 (NT, NN), 0 / 1 / 2 (TN)
-int launch_nt16(const GemmParams& p, int epi, int tile, int bk, dim3 grid, hipStream_t st);
-int launch_nn16(const GemmParams& p, int epi, int tile, int bk, dim3 grid, hipStream_t st);
-int launch_tn16(const GemmParams& p, int tile, int bk, dim3 grid, hipStream_t st);
+// io: IO_* bits = which tensors are stored as fp16 (0: all fp32 in HBM, rounded in the loader).  gemm_h16.hip holds the
+// io != 0 instantiations: NT {A16: bias / bias+scale+residual / none; A16|C16|X16: bias+GELU}, NN {A16: none;
+// C16|X16: GELU'}, TN {B16; A16|B16}
+int launch_nt16(const GemmParams& p, int epi, int tile, int bk, int io, dim3 grid, hipStream_t st);
+int launch_nn16(const GemmParams& p, int epi, int tile, int bk, int io, dim3 grid, hipStream_t st);
+int launch_tn16(const GemmParams& p, int tile, int bk, int io, dim3 grid, hipStream_t st);
+int launch_nt_h16(const GemmParams& p, int epi, int tile, int bk, int io, dim3 grid, hipStream_t st);
+int launch_nn_h16(const GemmParams& p, int epi, int tile, int bk, int io, dim3 grid, hipStream_t st);
+int launch_tn_h16(const GemmParams& p, int tile, int bk, int io, dim3 grid, hipStream_t st);
 
 inline void tile_dims(int tile, int& bm, int& bn) {
   static const int d[6][2] = {{128, 128}, {128, 96}, {96, 128}, {128, 192}, {192, 128}, {64, 128}};

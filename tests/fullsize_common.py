@@ -40,8 +40,8 @@ ARCHS = {'tiny': dict(depths=[3, 3, 9, 3], channels=[96, 192, 384, 768]),
          'base': dict(depths=[3, 3, 27, 3], channels=[128, 256, 512, 1024])}
 ARCH_TINY = ARCHS['tiny']
 N_OUT_SAMPLES, N_GRAD_SAMPLES, SMALL_TENSOR = 8192, 512, 768
-FRAGILE_REL_GAP = 1e-2  # tokens whose top-k margin / logit scale is below this are listed in the fixture (fp32 replays may flip
-# only margins < 2e-4, the fp16 data path of the AMP configs only margins < 5e-3: tests/test_fullsize_gpu.py)
+FRAGILE_REL_GAP = 3e-2  # tokens whose top-k margin / logit scale is below this are listed in the fixture (fp32 replays may flip
+# only margins < 2e-4, the fp16 data path of the AMP configs only margins < 2e-2 = its tolerance: tests/test_fullsize_gpu.py)
 
 
 def _gen(tag, seed):

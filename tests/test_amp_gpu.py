@@ -73,6 +73,121 @@ def test_gemm_fp16_epilogues_and_groups():
     assert rel_err(dW, refw) < 1e-4
 
 
+@pytest.mark.parametrize('M,N,K,tiles', [(1000, 384, 96, None), (2050, 96, 384, None), (515, 768, 192, None),
+                                         (4096, 288, 192, None)])
+def test_gemm_fp16_storage_nt_nn_all_io_combinations(M, N, K, tiles):
+    """The AMP DATA PATH: operands / outputs stored as fp16 in HBM (sm3_gemm_desc.io derived from the tensor dtypes).
+    Every supported combination against the fp64 product of the same (half) operands; half outputs within one fp16
+    rounding of it."""
+    from sm3det_amd import _lib_backbone as LB
+    from sm3det_amd import amp
+    A = (_rand(M, K, seed=1) * 0.5).half()
+    W = _rand(N, K, seed=2) * 0.1           # weights stay fp32 (rounded in the loader)
+    bias = _rand(N, seed=3)
+    ref = A.double() @ W.half().double().t() + bias.double()
+    with amp.autocast():
+        # NT, A16 -> fp32 (gate projection / expert FC2)
+        C = torch.full((M, N), float('nan'), device='cuda')
+        LB.gemm(LB.NT, A, W, C, M, N, K, epilogue=LB.EPI_BIAS, bias=bias)
+        assert rel_err(C, ref) < 2e-5
+        # NT, A16 -> GELU (f16) + GELU' (f16)  (FC1)
+        act, dact = torch.zeros(M, N, device='cuda', dtype=torch.half), torch.zeros(M, N, device='cuda', dtype=torch.half)
+        LB.gemm(LB.NT, A, W, act, M, N, K, epilogue=LB.EPI_BIAS_GELU, bias=bias, aux_out=dact)
+        g = torch.nn.functional.gelu(ref)
+        h = ref.clone().requires_grad_(True)
+        torch.nn.functional.gelu(h).sum().backward()
+        assert rel_err(act, g) < 1.5e-3 and rel_err(dact, h.grad) < 1.5e-3   # 2^-11 relative + the A&S polynomial
+        # NT, A16 -> fp32 with layer scale + drop path + residual  (FC2)
+        res, gam = _rand(M, N, seed=4), _rand(N, seed=5)
+        rs = torch.tensor([1.0, 0.0, 1.1, 1.0], device='cuda')[:max(1, (M + 1023) // 1024)].contiguous()
+        y, out = torch.zeros(M, N, device='cuda'), torch.zeros(M, N, device='cuda')
+        LB.gemm(LB.NT, A, W, out, M, N, K, epilogue=LB.EPI_BIAS_SCALE_RES, bias=bias, aux_in=res, aux_out=y, gamma=gam,
+                rowscale=rs, rows_per_scale=1024)
+        rowsc = rs.double()[torch.arange(M, device='cuda') // 1024][:, None]
+        assert rel_err(y, ref) < 2e-5 and rel_err(out, res.double() + gam.double() * rowsc * ref) < 2e-5
+        # NN, A16 -> fp32 (FC1 input gradient): dx = dh @ W   (dh (M, N) half, W (N, K) fp32)
+        dh = (_rand(M, N, seed=6) * 0.3).half()
+        dx = torch.full((M, K), float('nan'), device='cuda')
+        LB.gemm(LB.NN, dh, W, dx, M, K, N)
+        assert rel_err(dx, dh.double() @ W.half().double()) < 2e-5
+        # NN, fp32 dy -> x GELU' (f16) = dh (f16) + bias-gradient column sums (FC2 input gradient)
+        dy = _rand(M, K, seed=7) * 0.2        # (M, K): C-wide gradient, fp32
+        W2 = _rand(K, N, seed=8) * 0.1        # (K, N)
+        gp = (_rand(M, N, seed=9).abs() * 0.5).half()
+        dh2, db = torch.zeros(M, N, device='cuda', dtype=torch.half), torch.zeros(N, device='cuda')
+        LB.gemm(LB.NN, dy, W2, dh2, M, N, K, epilogue=LB.EPI_GELU_BWD, aux_in=gp, colsum_out=db)
+        r2 = (dy.half().double() @ W2.half().double()) * gp.double()
+        assert rel_err(dh2, r2) < 1.5e-3 and rel_err(db, r2.sum(0)) < 1e-4
+
+
+@pytest.mark.parametrize('M,N,K', [(96, 384, 5000), (384, 96, 3001 * 2), (768, 192, 3000), (292, 332, 1112)])
+def test_gemm_fp16_storage_tn(M, N, K):
+    """weight-gradient form with the activation-sized operands stored as fp16: dy (fp32)^T act (f16) and dh (f16)^T x (f16)"""
+    from sm3det_amd import _lib_backbone as LB
+    from sm3det_amd import amp
+    A32, A16 = _rand(K, M, seed=6) * 0.3, (_rand(K, M, seed=6) * 0.3).half()
+    B16 = (_rand(K, N, seed=7) * 0.5).half()
+    with amp.autocast():
+        C = torch.full((M, N), float('nan'), device='cuda')
+        LB.gemm(LB.TN, A32, B16, C, M, N, K)
+        assert rel_err(C, A32.half().double().t() @ B16.double()) < 3e-5
+        C = torch.full((M, N), float('nan'), device='cuda')
+        LB.gemm(LB.TN, A16, B16, C, M, N, K)
+        assert rel_err(C, A16.double().t() @ B16.double()) < 3e-5
+
+
+def test_gemm_fp16_storage_grouped_experts():
+    from sm3det_amd import _lib_backbone as LB
+    from sm3det_amd import amp
+    E, counts = 4, [150, 0, 78, 130]
+    S = sum(counts)
+    offs = torch.tensor(np.concatenate([[0], np.cumsum(counts)]), dtype=torch.int32, device='cuda')
+    C_, Hd = 192, 768
+    X = (_rand(S, C_, seed=20)).half()
+    W1, b1 = _rand(E, Hd, C_, seed=21) * 0.1, _rand(E, Hd, seed=22)
+    hpre = torch.zeros(S, Hd, device='cuda', dtype=torch.half)
+    act = torch.zeros(S, Hd, device='cuda', dtype=torch.half)
+    seg = lambda t, e: t[offs[e]:offs[e + 1]]  # noqa: E731
+    with amp.autocast():
+        LB.gemm(LB.NT, X, W1, act, S, Hd, C_, epilogue=LB.EPI_BIAS_GELU, bias=b1, aux_out=hpre, offsets=offs,
+                num_groups=E)
+        ref = torch.cat([seg(X, e).double() @ W1[e].half().double().t() + b1[e].double() for e in range(E)])
+        assert rel_err(act, torch.nn.functional.gelu(ref)) < 1.5e-3
+        dH = (_rand(S, Hd, seed=23) * 0.2).half()
+        dW = torch.full((E, Hd, C_), float('nan'), device='cuda')
+        LB.gemm(LB.TN, dH, X, dW, Hd, C_, S, offsets=offs, num_groups=E)
+        refw = torch.stack([seg(dH, e).double().t() @ seg(X, e).double() for e in range(E)])
+        assert rel_err(dW, refw) < 3e-5
+        dX = torch.full((S, C_), float('nan'), device='cuda')
+        LB.gemm(LB.NN, dH, W1, dX, S, C_, Hd, offsets=offs, num_groups=E)
+        refx = torch.cat([seg(dH, e).double() @ W1[e].half().double() for e in range(E)])
+        assert rel_err(dX, refx) < 3e-5
+        dY = _rand(S, C_, seed=24) * 0.2
+        dW2 = torch.full((E, C_, Hd), float('nan'), device='cuda')
+        LB.gemm(LB.TN, dY, act, dW2, C_, Hd, S, offsets=offs, num_groups=E)
+        refw2 = torch.stack([seg(dY, e).half().double().t() @ seg(act, e).double() for e in range(E)])
+        assert rel_err(dW2, refw2) < 3e-5
+
+
+def test_layernorm_fp16_output_and_unsupported_io_fails_loudly():
+    from sm3det_amd import _lib_backbone as LB
+    from sm3det_amd import amp
+    from sm3det_amd._lib import SM3Error
+    T, C = 1000, 192
+    x, w, b = _rand(T, C, seed=1) * 3 + 1, _rand(C, seed=2), _rand(C, seed=3)
+    y = torch.zeros(T, C, device='cuda', dtype=torch.half)
+    mean, rstd = torch.zeros(T, device='cuda'), torch.zeros(T, device='cuda')
+    LB.call('layernorm_fwd', x, w, b, 1e-6, y, mean, rstd, T, C, 2, 0, 0)
+    ref = torch.nn.functional.layer_norm(x.double(), (C,), w.double(), b.double(), 1e-6)
+    assert (y.double() - ref).abs().max().item() <= 1e-3 * ref.abs().max().item()
+    assert torch.equal(y, ref.float().half()) or (y.double() - ref.float().half().double()).abs().max() <= 2e-3
+    with amp.autocast():  # fp16 WEIGHTS are not a supported storage form
+        with pytest.raises(SM3Error):
+            LB.gemm(LB.NT, _rand(64, 96).half(), _rand(96, 96).half(), torch.zeros(64, 96, device='cuda'), 64, 96, 96)
+    with pytest.raises(SM3Error):  # half tensors outside autocast
+        LB.gemm(LB.NT, _rand(64, 96).half(), _rand(96, 96), torch.zeros(64, 96, device='cuda'), 64, 96, 96)
+
+
 @pytest.mark.parametrize('name', ['moe_e4k2', 'moe_e8k3'])
 def test_backbone_fp16_enabled_vs_fp32_reference_fixture(name):
     """train-mode forward + backward with injected randomness under wrap_fp16_model, against the REFERENCE module's fp32

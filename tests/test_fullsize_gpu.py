@@ -38,11 +38,14 @@ pytestmark = pytest.mark.gpu
 FWD_TOL, BWD_TOL = 1e-4, 1e-3
 FLIP_MARGIN = 2e-4
 # AMP (configs #3 / #5, `fp16 = dict(loss_scale='dynamic')`): SURVEY.md 8(c) compares the fp16 data path with the fp32
-# reference at 2e-2.  The gate projection then sees fp16-rounded operands, which moves a logit by ~1e-3 of its scale, so
-# tokens whose k-th / (k+1)-th margin is below AMP_FLIP_MARGIN may legitimately route the other way; every such token
-# must be on the fixture's near-tie list (which lists margins up to 1e-2) and the swap must be k-th <-> runner-up.
+# reference at 2e-2.  A router deep in the network then sees inputs that legitimately differ from the fp32 run by up to
+# that tolerance (measured in round 3: a token of the SECOND MoE block flipped at a reference margin of 5e-3 of the logit
+# scale), so a token whose k-th / (k+1)-th margin is below AMP_FLIP_MARGIN = the tolerance itself may route the other
+# way; every such token must be on the fixture's near-tie list (which lists margins up to 3e-2), the swap must be
+# k-th <-> runner-up, and at most 1 % of a block's tokens may flip.
 AMP_TOL = 2e-2
-AMP_FLIP_MARGIN = 5e-3
+AMP_FLIP_MARGIN = 2e-2
+AMP_MAX_FLIP_FRACTION = 1e-2
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -104,6 +107,8 @@ def _run_case(case, amp):
                 f'and is not a near-tie of the reference (margin {frag.get(t, ("> 1e-3",))[0]})'
             # the swap must be k-th <-> runner-up: the new set = reference set minus its k-th plus the runner-up
             assert frag[t][1] in got[t, :k].tolist(), (case, i, j, t)
+        if amp:
+            assert bad.numel() <= AMP_MAX_FLIP_FRACTION * got.shape[0], (case, i, j, int(bad.numel()), got.shape[0])
         if bad.numel() and first_flip_stage is None:
             first_flip_stage = i
         n_flips += int(bad.numel())
