@@ -466,6 +466,12 @@ int sm3_deform_im2col(const float* im, const float* offset, float* col, int chan
 int sm3_deform_col2im(const float* col, const float* offset, float* grad_im, int channels, int height, int width,
                       int kh, int kw, int pad_h, int pad_w, int stride_h, int stride_w, int dil_h, int dil_w, int imgs,
                       int deformable_group, long ld_col, sm3_stream_t stream);
+/* The input-gradient scatter onto an NHWC map (imgs, H, W, C) that the caller zero-filled (a wave = one sampling
+ * position x 64 channels: coalesced 256-byte atomics instead of 64 scattered ones); the caller then adds the map into
+ * the NCHW gradInput with sm3_transpose_add_f32. */
+int sm3_deform_col2im_nhwc(const float* col, const float* offset, float* grad_im_nhwc, int channels, int height,
+                           int width, int kh, int kw, int pad_h, int pad_w, int stride_h, int stride_w, int dil_h,
+                           int dil_w, int imgs, int deformable_group, long ld_col, sm3_stream_t stream);
 int sm3_deform_col2im_coord(const float* col, const float* im, const float* offset, float* grad_offset, int channels,
                             int height, int width, int kh, int kw, int pad_h, int pad_w, int stride_h, int stride_w,
                             int dil_h, int dil_w, int imgs, int deformable_group, long ld_col, sm3_stream_t stream);

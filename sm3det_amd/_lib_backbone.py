@@ -77,6 +77,7 @@ def signatures():
         'sm3_adamw_multi': (I, [P, P, P, P, P, P, I, P, P, F, F, F, F, P, P, P, P, P, F, F, I, P]),
         'sm3_deform_im2col': (I, [P, P, P] + [I] * 13 + [LL, P]),
         'sm3_deform_col2im': (I, [P, P, P] + [I] * 13 + [LL, P]),
+        'sm3_deform_col2im_nhwc': (I, [P, P, P] + [I] * 13 + [LL, P]),
         'sm3_deform_col2im_coord': (I, [P, P, P, P] + [I] * 13 + [LL, P]),
     }
 

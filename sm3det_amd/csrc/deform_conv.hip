@@ -165,6 +165,64 @@ __global__ __launch_bounds__(256) void deform_col2im_kernel(long npos, const flo
   }
 }
 
+// The same scatter onto an NHWC gradient map (imgs, H, W, C), zero-filled by the caller: a wave owns one sampling position
+// (b, deformable group, tap, h_out, w_out) and its 64 lanes are 64 CHANNELS, so each of the <= 4 target pixels receives
+// ONE coalesced 256-byte atomic instead of 64 scattered 4-byte ones on 64 different planes (the NCHW form above spends
+// 8 ms of the 10.6 ms backward of (2,256,128,128) in 302 M scattered atomics).  The column matrix is (C*taps, positions)
+// with positions contiguous, so a workgroup first turns a [64 channels] x [64 positions] tile of one tap through LDS.
+// grid = (position tiles, channel tiles of the group, deformable groups x taps).
+__global__ __launch_bounds__(256) void deform_col2im_nhwc_kernel(const float* __restrict__ col,
+                                                                const float* __restrict__ off, DcnGeom g,
+                                                                float* __restrict__ grad_nhwc) {
+  __shared__ float tile[64][65];
+  const int taps = g.kh * g.kw;
+  const int tap = blockIdx.z % taps, dgi = blockIdx.z / taps;
+  const int cpdg = g.channels / g.dg;
+  const long per_row = (long)g.imgs * g.ho * g.wo;
+  const long p0 = (long)blockIdx.x * 64;
+  const int c0 = dgi * cpdg + blockIdx.y * 64, c_lim = (dgi + 1) * cpdg;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    const int c = wave + 4 * i;
+    const long p = p0 + lane;
+    tile[c][lane] = (c0 + c < c_lim && p < per_row) ? col[((long)(c0 + c) * taps + tap) * g.ld_col + p] : 0.f;
+  }
+  __syncthreads();
+  const int i = tap / g.kw, j = tap % g.kw;
+  const int ch = c0 + lane;
+  for (int q = 0; q < 16; q++) {
+    const int pl = __builtin_amdgcn_readfirstlane(wave * 16 + q);
+    const long p = p0 + pl;
+    if (p >= per_row) break;
+    const int w_out = (int)(p % g.wo);
+    const int h_out = (int)((p / g.wo) % g.ho);
+    const int b = (int)(p / g.wo / g.ho);
+    const float* op = off + ((long)b * g.dg + dgi) * 2 * taps * g.ho * g.wo;
+    const float offset_h = op[((long)(2 * tap) * g.ho + h_out) * g.wo + w_out];
+    const float offset_w = op[((long)(2 * tap + 1) * g.ho + h_out) * g.wo + w_out];
+    const float cur_inv_h = (h_out * g.stride_h - g.pad_h) + i * g.dil_h + offset_h;
+    const float cur_inv_w = (w_out * g.stride_w - g.pad_w) + j * g.dil_w + offset_w;
+    if (!(fabsf(cur_inv_h) < 1e9f && fabsf(cur_inv_w) < 1e9f)) continue;
+    const float fh = floorf(cur_inv_h), fw = floorf(cur_inv_w);
+    const int y0 = (int)fh, x0 = (int)fw;
+    const float top = tile[lane][pl];
+    if (ch >= c_lim) continue;
+#pragma unroll
+    for (int a = 0; a < 2; a++) {
+      const int y = y0 + a;
+      if (y < 0 || y >= g.height || (a == 1 && cur_inv_h == fh)) continue;
+#pragma unroll
+      for (int c = 0; c < 2; c++) {
+        const int x = x0 + c;
+        if (x < 0 || x >= g.width || (c == 1 && cur_inv_w == fw)) continue;
+        const float wgt = gradient_weight(cur_inv_h, cur_inv_w, y, x, g.height, g.width);
+        atomicAdd(grad_nhwc + (((long)b * g.height + y) * g.width + x) * g.channels + ch, wgt * top);
+      }
+    }
+  }
+}
+
 // one thread per offset element (b, c_off, h, w): gathers over the channels of its deformable group
 __global__ __launch_bounds__(256) void deform_col2im_coord_kernel(long n, const float* __restrict__ col,
                                                                  const float* __restrict__ im,
@@ -255,6 +313,23 @@ int sm3_deform_col2im(const float* col, const float* offset, float* grad_im, int
   const int cpdg = channels / deformable_group;
   dim3 grid((unsigned)((npos + 255) / 256), (unsigned)((cpdg + C2I_CHUNK - 1) / C2I_CHUNK));
   deform_col2im_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(npos, col, offset, g, grad_im);
+  return launch_status();
+}
+
+int sm3_deform_col2im_nhwc(const float* col, const float* offset, float* grad_im_nhwc, int channels, int height,
+                           int width, int kh, int kw, int pad_h, int pad_w, int stride_h, int stride_w, int dil_h,
+                           int dil_w, int imgs, int deformable_group, long ld_col, sm3_stream_t stream) {
+  DcnGeom g;
+  if (!col || !offset || !grad_im_nhwc ||
+      !make_geom(g, channels, height, width, kh, kw, pad_h, pad_w, stride_h, stride_w, dil_h, dil_w, imgs,
+                 deformable_group, ld_col))
+    return SM3_ERR_INVALID_ARG;
+  const long per_row = (long)g.ho * g.wo * imgs;
+  const int cpdg = channels / deformable_group;
+  const long zt = (long)deformable_group * kh * kw;
+  if (zt > 65535 || (cpdg + 63) / 64 > 65535) return SM3_ERR_UNSUPPORTED;
+  dim3 grid((unsigned)((per_row + 63) / 64), (unsigned)((cpdg + 63) / 64), (unsigned)zt);
+  deform_col2im_nhwc_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(col, offset, g, grad_im_nhwc);
   return launch_status();
 }
 

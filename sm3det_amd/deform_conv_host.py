@@ -15,6 +15,7 @@ up to 32 floats so that it feeds the GEMM kernels without a copy; the tiny re-la
 import torch
 import torch.nn.functional as F
 
+from . import _lib
 from . import _lib_backbone as LB
 from ._lib import SM3Error, require_gpu
 
@@ -154,7 +155,12 @@ def deform_conv_backward_input(input, offset, gradOutput, gradInput, gradOffset,
             col = colp if Kp == Kg else colp[:, :Kg].contiguous()
             col = col.view(nIn * kH * kW, ld)
             LB.call('deform_col2im_coord', col, input[sl], offset[sl], gradOffset[sl], *geom, ld)
-            LB.call('deform_col2im', col, offset[sl], gradInput[sl], *geom, ld)
+            # scatter on an NHWC scratch map (coalesced channel-vector atomics), then gradInput (NCHW) += scratch^T
+            scratch = torch.zeros(step, H, W, nIn, device=input.device)
+            LB.call('deform_col2im_nhwc', col, offset[sl], scratch, *geom, ld)
+            gi = gradInput[sl]
+            _lib.check(_lib.lib().sm3_transpose_add_f32(scratch.data_ptr(), gi.data_ptr(), step, H * W, nIn,
+                                                        _lib.stream_ptr()), 'transpose_add_f32')
 
 
 def deform_conv_backward_parameters(input, offset, gradOutput, gradWeight, columns, ones, kW, kH, dW, dH, padW, padH,

@@ -290,7 +290,8 @@ class OrientedStandardRoIHead(nn.Module):
                 lab = torch.cat([gl, lab])
             idx, is_pos, valid, n_pos, n_neg = self.bbox_sampler.sample_fixed(gt_inds, generator)
             sel = boxes[idx]
-            unit = sel.new_tensor([0.0, 0.0, 1.0, 1.0, 0.0])
+            unit = sel.new_zeros(5)  # (built with fill kernels: a host-to-device copy cannot sit inside a hipGraph capture)
+            unit[2:4] = 1.0
             sel = torch.where(valid[:, None], sel, unit)  # unused slots: a harmless unit box (their rows carry no weight)
             gsel = g[(gt_inds[idx] - 1).clamp(min=0)] if k > 0 else sel.new_zeros(S, 5)
             rois.append(torch.cat([sel.new_full((S, 1), float(i)), sel], 1))

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 def _rpn_head(c, num):
     from sm3det_amd.rpn_head import OrientedRPNHead
     return OrientedRPNHead(
-        in_channels=32, feat_channels=32, version='le90',
+        in_channels=128, feat_channels=128, version='le90',
         anchor_generator=dict(type='AnchorGenerator', scales=[c['scale']], ratios=[0.5, 1.0, 2.0], strides=list(c['strides'])),
         bbox_coder=dict(type='MidpointOffsetCoder', angle_range='le90', target_means=list(LC.RPN_MEANS),
                         target_stds=list(LC.RPN_STDS)),
@@ -65,7 +65,7 @@ def test_rpn_forward_train_runs_heads_loss_and_fixed_size_proposals():
     c = LC.rpn_case(2, extent=256, strides=(4, 8, 16, 32), ks=(6, 0))  # one image without any ground truth
     head = _rpn_head(c, 64)
     head.init_weights()
-    feats = [torch.randn(2, 32, h, w, device='cuda').contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    feats = [torch.randn(2, 128, h, w, device='cuda').contiguous(memory_format=torch.channels_last).requires_grad_(True)
              for h, w in c['sizes']]
     metas = [dict(img_shape=(256, 256, 3)) for _ in range(2)]
     cfg = dict(nms_pre=200, max_per_img=100, nms=dict(type='nms', iou_threshold=0.8), min_bbox_size=0)
