@@ -38,3 +38,9 @@ cd $R
 timeout 900 python bench.py --no-cpu-baseline > $O/c3_bench.json 2> $O/c3_bench.err
 echo "[$(( $(date +%s) - t0 )) s] bench rc=$? $(head -c 200 $O/c3_bench.json)" >> $S
 grep -c "capture failed" $O/c3_bench.err >> $S
+timeout 900 python -m pytest tests/test_fullsize_gpu.py -m gpu -q -rf -k amp > $O/c3_pytest_b.log 2>&1
+echo "[$(( $(date +%s) - t0 )) s] fullsize amp rc=$? $(tail -1 $O/c3_pytest_b.log)" >> $S
+for C in SM3Det_convnext_t SM3Det_convnext_b; do
+  timeout 600 python bench.py --config $C --no-ops --no-cpu-baseline > $O/c3_bench_$C.json 2> $O/c3_bench_$C.err
+  echo "[$(( $(date +%s) - t0 )) s] bench $C $(head -c 230 $O/c3_bench_$C.json)" >> $S
+done

@@ -483,8 +483,13 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
   };
   auto ldg2 = [&](const __amdgpu_buffer_rsrc_t& rs, long soff, unsigned voff) {  // 8 bytes = 4 stored halves
     typedef unsigned u32x2l __attribute__((ext_vector_type(2)));
-    const u32x2l v = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)voff, (int)soff, 0);
-    return f32x4{__builtin_bit_cast(float, v[0]), __builtin_bit_cast(float, v[1]), 0.f, 0.f};
+    // bit_cast, not an implicit conversion: whatever 64-bit type the builtin returns (a scalar would be SPLAT into a
+    // 2-vector by a plain assignment, which silently narrows the load to one dword)
+    const u32x2l v = __builtin_bit_cast(u32x2l, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)voff, (int)soff, 0));
+    // (through scalar temporaries: hipcc 7.2 evaluates __builtin_bit_cast applied DIRECTLY to a vector-element
+    // expression `v[1]` as element 0 -- the load was narrowed to one dword and both words of the piece were the same)
+    const unsigned w0 = v[0], w1 = v[1];
+    return f32x4{__builtin_bit_cast(float, w0), __builtin_bit_cast(float, w1), 0.f, 0.f};
   };
   auto load_piece = [&](f32x4 (&ra)[PA], f32x4 (&rb)[PB], int q, int kt, bool tail) {
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
