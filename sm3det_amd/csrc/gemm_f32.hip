@@ -379,7 +379,7 @@ int sm3_gemm_f32(const sm3_gemm_desc* d, void* workspace, size_t workspace_bytes
   if (d->compute != 0 && d->compute != 1) return SM3_ERR_INVALID_ARG;
   if (d->io != 0 && (d->compute != 1 || d->io < 0 || d->io > 15)) return SM3_ERR_INVALID_ARG;
   // fp16-stored operands: 8-byte loads of k-quads (lda % 4, checked above) / 4-byte loads of column pairs (even dims)
-  if ((d->io & 3) && ((d->lda & 1) || (d->ldb & 1) || (d->M & 1) || (d->N & 1))) return SM3_ERR_UNSUPPORTED;
+  if (d->mode == MODE_TN && (((d->io & 1) && (d->M & 1)) || ((d->io & 2) && (d->N & 1)))) return SM3_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   const Cfg c = choose_cfg(d);
   {  // the kernel addresses each operand as block base + 32-bit byte offset (buffer loads): keep the spans below 2^31.

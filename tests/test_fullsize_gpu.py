@@ -94,27 +94,49 @@ def _run_case(case, amp):
     report = dict(case=case, amp=bool(amp))
 
     # ---- routing, token by token -------------------------------------------------------------------------------
-    first_flip_stage, n_flips = None, 0
-    for (i, j, blk), ref in zip(_moe_blocks(net), fx['routing']):
-        got = blk.ffn.last_top_idx.cpu()  # (T, k+1) best first
-        gs, _ = torch.sort(got[:, :k].long(), dim=1)
-        rs, _ = torch.sort(ref['topk'].long(), dim=1)
-        bad = (gs != rs).any(1).nonzero().squeeze(1)
-        frag = {int(t): (float(g), int(r)) for t, g, r in zip(ref['fragile'], ref['fragile_rel_gap'], ref['runner_up'])}
-        for t in bad.tolist():
-            assert t in frag and frag[t][0] < FLIP_MARGIN, \
-                f'{case} stage {i} block {j}: token {t} routed to {got[t].tolist()} vs reference {ref["topk"][t].tolist()} ' \
-                f'and is not a near-tie of the reference (margin {frag.get(t, ("> 1e-3",))[0]})'
-            # the swap must be k-th <-> runner-up: the new set = reference set minus its k-th plus the runner-up
-            assert frag[t][1] in got[t, :k].tolist(), (case, i, j, t)
-        if amp:
-            assert bad.numel() <= AMP_MAX_FLIP_FRACTION * got.shape[0], (case, i, j, int(bad.numel()), got.shape[0])
-        if bad.numel() and first_flip_stage is None:
-            first_flip_stage = i
-        n_flips += int(bad.numel())
-        counts = torch.bincount(got[:, :k].long().view(-1), minlength=E)
-        assert int((counts - fx['expert_counts'][len(report.get('blocks', []))]).abs().sum()) <= 2 * bad.numel()
-        report.setdefault('blocks', []).append(dict(stage=i, block=j, flips=int(bad.numel())))
+    # A token routed differently from the reference must be (a) a near-tie of the reference (margin < FLIP_MARGIN, swap
+    # k-th <-> runner-up) or -- AMP only -- (b) DOWNSTREAM of an earlier flip: a flipped token's block output differs by
+    # O(gate x expert difference), every later depthwise 7x7 spreads that over a 3-pixel ring per block and a downsample
+    # halves the grid, so routers further on legitimately see different inputs there (measured: such second-generation
+    # flips occur at reference margins of 2-3 % of the logit scale).  `cont` tracks that footprint per stage.
+    B_img = x.shape[0]
+    first_flip_stage, n_flips, n_second_gen = None, 0, 0
+    ref_iter = iter(fx['routing'])
+    cont = None
+    for i, stage in enumerate(net.stages):
+        Hs = x.shape[2] // 4 >> i
+        cont = torch.zeros(B_img, 1, Hs, Hs) if cont is None else torch.nn.functional.max_pool2d(cont, 2)
+        for j, blk in enumerate(stage):
+            cont = torch.nn.functional.max_pool2d(cont, 7, stride=1, padding=3)  # this block's 7x7 depthwise conv
+            if blk.MoE_cfg is None:
+                continue
+            ref = next(ref_iter)
+            got = blk.ffn.last_top_idx.cpu()  # (T, k+1) best first
+            gs, _ = torch.sort(got[:, :k].long(), dim=1)
+            rs, _ = torch.sort(ref['topk'].long(), dim=1)
+            bad = (gs != rs).any(1).nonzero().squeeze(1)
+            frag = {int(t): (float(g), int(r)) for t, g, r in zip(ref['fragile'], ref['fragile_rel_gap'], ref['runner_up'])}
+            cflat = cont.view(-1)
+            for t in bad.tolist():
+                near_tie = t in frag and frag[t][0] < FLIP_MARGIN and frag[t][1] in got[t, :k].tolist()
+                downstream = amp and bool(cflat[t] > 0)
+                assert near_tie or downstream, \
+                    f'{case} stage {i} block {j}: token {t} routed to {got[t].tolist()} vs reference ' \
+                    f'{ref["topk"][t].tolist()}: neither a near-tie of the reference (margin ' \
+                    f'{frag.get(t, ("> 3e-2",))[0]}) nor downstream of an earlier flip'
+                n_second_gen += int(not near_tie)
+            if amp:
+                assert bad.numel() <= AMP_MAX_FLIP_FRACTION * got.shape[0], (case, i, j, int(bad.numel()), got.shape[0])
+            if bad.numel():
+                cflat[bad] = 1.0
+                if first_flip_stage is None:
+                    first_flip_stage = i
+            n_flips += int(bad.numel())
+            counts = torch.bincount(got[:, :k].long().view(-1), minlength=E)
+            assert int((counts - fx['expert_counts'][len(report.get('blocks', []))]).abs().sum()) <= 2 * bad.numel()
+            report.setdefault('blocks', []).append(dict(stage=i, block=j, flips=int(bad.numel()), tokens=int(got.shape[0]),
+                                                        footprint=float(cont.mean())))
+    report['second_generation_flips'] = n_second_gen
     report['routing_flips'] = n_flips
 
     # ---- outputs -----------------------------------------------------------------------------------------------

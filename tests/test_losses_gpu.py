@@ -150,9 +150,9 @@ def test_roi_head_forward_train_samples_match_oracle_assignment_and_loss():
     g = torch.Generator().manual_seed(9)
     feats = [torch.randn(2, 32, 64 >> i, 64 >> i, generator=g).cuda().contiguous(memory_format=torch.channels_last)
              .requires_grad_(True) for i in range(4)]
-    B, P = 2, 120
+    B, P = 2, 200
     props = torch.zeros(B, P, 6)
-    counts = torch.tensor([110, 85])
+    counts = torch.tensor([190, 170])
     for i in range(B):  # proposals: jittered copies of the gts + far-away boxes; rows past `counts` hold junk
         src = c['gts'][i][torch.randint(0, c['gts'][i].shape[0], (P,), generator=g)]
         props[i, :, :5] = src + torch.randn(P, 5, generator=g) * torch.tensor([5.0, 5.0, 3.0, 2.0, 0.1])
