@@ -472,6 +472,13 @@ int sm3_deform_col2im(const float* col, const float* offset, float* grad_im, int
 int sm3_deform_col2im_nhwc(const float* col, const float* offset, float* grad_im_nhwc, int channels, int height,
                            int width, int kh, int kw, int pad_h, int pad_w, int stride_h, int stride_w, int dil_h,
                            int dil_w, int imgs, int deformable_group, long ld_col, sm3_stream_t stream);
+/* deformable_col2im + deformable_col2im_coord in ONE pass over the columns, NHWC on both sides: im_nhwc (imgs,H,W,C) is the
+ * input transposed by the caller, grad_im_nhwc (imgs,H,W,C) zero-filled by the caller receives the input gradient
+ * (coalesced channel-vector atomics), grad_offset (imgs, dg*2*kh*kw, Ho, Wo) is fully written. */
+int sm3_deform_bwd_input_fused(const float* col, const float* im_nhwc, const float* offset, float* grad_im_nhwc,
+                               float* grad_offset, int channels, int height, int width, int kh, int kw, int pad_h,
+                               int pad_w, int stride_h, int stride_w, int dil_h, int dil_w, int imgs,
+                               int deformable_group, long ld_col, sm3_stream_t stream);
 int sm3_deform_col2im_coord(const float* col, const float* im, const float* offset, float* grad_offset, int channels,
                             int height, int width, int kh, int kw, int pad_h, int pad_w, int stride_h, int stride_w,
                             int dil_h, int dil_w, int imgs, int deformable_group, long ld_col, sm3_stream_t stream);

@@ -78,6 +78,7 @@ def signatures():
         'sm3_deform_im2col': (I, [P, P, P] + [I] * 13 + [LL, P]),
         'sm3_deform_col2im': (I, [P, P, P] + [I] * 13 + [LL, P]),
         'sm3_deform_col2im_nhwc': (I, [P, P, P] + [I] * 13 + [LL, P]),
+        'sm3_deform_bwd_input_fused': (I, [P, P, P, P, P] + [I] * 13 + [LL, P]),
         'sm3_deform_col2im_coord': (I, [P, P, P, P] + [I] * 13 + [LL, P]),
     }
 

@@ -223,6 +223,109 @@ __global__ __launch_bounds__(256) void deform_col2im_nhwc_kernel(const float* __
   }
 }
 
+// Input gradient AND offset gradient in one pass over the column matrix (the two reference kernels
+// deformable_col2im / deformable_col2im_coord read the same columns and evaluate the same sampling geometry).  NHWC on
+// both sides: a wave owns a sampling position (b, deformable group, tap, h_out, w_out), its lanes are 64 channels.
+//   * d im: <= 4 coalesced 256-byte atomics per position and channel chunk (as deform_col2im_nhwc_kernel);
+//   * d offset: val_h / val_w = sum_c col_c * coordinate_weight_c -- the four corner pixels are the same for every
+//     channel, so a lane reads its channel of the four NHWC corner vectors (coalesced) and accumulates both directions;
+//     the 64 lanes are folded with shuffles once all channel chunks are done.  (The reference-shaped kernel above runs
+//     one thread per (offset channel, position) over all channels with four scattered plane reads per channel: 1.19 ms
+//     at (2,256,128,128), the largest part of the backward once the scatter was coalesced.)
+// grid = (position tiles of 64, 1, deformable groups x taps); grad_nhwc zero-filled by the caller; grad_off fully written.
+__global__ __launch_bounds__(256) void deform_bwd_input_fused_kernel(const float* __restrict__ col,
+                                                                    const float* __restrict__ im_nhwc,
+                                                                    const float* __restrict__ off, DcnGeom g,
+                                                                    float* __restrict__ grad_nhwc,
+                                                                    float* __restrict__ grad_off) {
+  __shared__ float tile[64][65];
+  const int taps = g.kh * g.kw;
+  const int tap = blockIdx.z % taps, dgi = blockIdx.z / taps;
+  const int cpdg = g.channels / g.dg;
+  const long per_row = (long)g.imgs * g.ho * g.wo;
+  const long p0 = (long)blockIdx.x * 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = tap / g.kw, j = tap % g.kw;
+  float acc_h[16], acc_w[16];
+#pragma unroll
+  for (int q = 0; q < 16; q++) acc_h[q] = acc_w[q] = 0.f;
+  for (int cb = 0; cb < cpdg; cb += 64) {
+    const int c0 = dgi * cpdg + cb, c_lim = (dgi + 1) * cpdg;
+    __syncthreads();  // previous chunk's tile fully consumed
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int c = wave + 4 * r;
+      const long p = p0 + lane;
+      tile[c][lane] = (c0 + c < c_lim && p < per_row) ? col[((long)(c0 + c) * taps + tap) * g.ld_col + p] : 0.f;
+    }
+    __syncthreads();
+    const int ch = c0 + lane;
+    const bool ch_ok = ch < c_lim;
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+      const int pl = __builtin_amdgcn_readfirstlane(wave * 16 + q);
+      const long p = p0 + pl;
+      if (p >= per_row) continue;
+      const int w_out = (int)(p % g.wo);
+      const int h_out = (int)((p / g.wo) % g.ho);
+      const int b = (int)(p / g.wo / g.ho);
+      const float* op = off + ((long)b * g.dg + dgi) * 2 * taps * g.ho * g.wo;
+      const float offset_h = op[((long)(2 * tap) * g.ho + h_out) * g.wo + w_out];
+      const float offset_w = op[((long)(2 * tap + 1) * g.ho + h_out) * g.wo + w_out];
+      const float ah = (h_out * g.stride_h - g.pad_h) + i * g.dil_h + offset_h;
+      const float aw = (w_out * g.stride_w - g.pad_w) + j * g.dil_w + offset_w;
+      if (!(fabsf(ah) < 1e9f && fabsf(aw) < 1e9f)) continue;
+      const float fh = floorf(ah), fw = floorf(aw);
+      const int hl = (int)fh, wl = (int)fw;
+      const float top = tile[lane][pl];
+      if (!ch_ok) continue;
+      // the coordinate weight's validity test (get_coordinate_weight: a point outside (-1, H) x (-1, W) contributes 0)
+      const bool inside = !(ah <= -1.f || aw <= -1.f || ah >= g.height || aw >= g.width);
+      float im4[4];
+#pragma unroll
+      for (int a = 0; a < 2; a++) {
+        const int y = hl + a;
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+          const int xx = wl + c;
+          const bool pix_ok = y >= 0 && y < g.height && xx >= 0 && xx < g.width;
+          const long pix = (((long)b * g.height + (pix_ok ? y : 0)) * g.width + (pix_ok ? xx : 0)) * g.channels + ch;
+          im4[2 * a + c] = (inside && pix_ok) ? im_nhwc[pix] : 0.f;
+          // d im: every integer pixel within distance < 1 of the sampling point (floor + 1 only if non-integral)
+          const bool hit = pix_ok && !(a == 1 && ah == fh) && !(c == 1 && aw == fw);
+          if (hit) {
+            const float wgt = gradient_weight(ah, aw, y, xx, g.height, g.width);
+            atomicAdd(grad_nhwc + pix, wgt * top);
+          }
+        }
+      }
+      // get_coordinate_weight (deform_conv.cpp:65-112), corners (hl,wl) (hl,wh) (hh,wl) (hh,wh)
+      const float cwh = -1.f * (wl + 1 - aw) * im4[0] + -1.f * (aw - wl) * im4[1] + (wl + 1 - aw) * im4[2] + (aw - wl) * im4[3];
+      const float cww = -1.f * (hl + 1 - ah) * im4[0] + (hl + 1 - ah) * im4[1] + -1.f * (ah - hl) * im4[2] + (ah - hl) * im4[3];
+      acc_h[q] += cwh * top;
+      acc_w[q] += cww * top;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 16; q++) {
+    float vh = acc_h[q], vw = acc_w[q];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      vh += __shfl_xor(vh, o, 64);
+      vw += __shfl_xor(vw, o, 64);
+    }
+    const long p = p0 + wave * 16 + q;
+    if (lane == 0 && p < per_row) {
+      const int w_out = (int)(p % g.wo);
+      const int h_out = (int)((p / g.wo) % g.ho);
+      const int b = (int)(p / g.wo / g.ho);
+      float* gp = grad_off + ((long)b * g.dg + dgi) * 2 * taps * g.ho * g.wo;
+      gp[((long)(2 * tap) * g.ho + h_out) * g.wo + w_out] = vh;
+      gp[((long)(2 * tap + 1) * g.ho + h_out) * g.wo + w_out] = vw;
+    }
+  }
+}
+
 // one thread per offset element (b, c_off, h, w): gathers over the channels of its deformable group
 __global__ __launch_bounds__(256) void deform_col2im_coord_kernel(long n, const float* __restrict__ col,
                                                                  const float* __restrict__ im,
@@ -330,6 +433,24 @@ int sm3_deform_col2im_nhwc(const float* col, const float* offset, float* grad_im
   if (zt > 65535 || (cpdg + 63) / 64 > 65535) return SM3_ERR_UNSUPPORTED;
   dim3 grid((unsigned)((per_row + 63) / 64), (unsigned)((cpdg + 63) / 64), (unsigned)zt);
   deform_col2im_nhwc_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(col, offset, g, grad_im_nhwc);
+  return launch_status();
+}
+
+int sm3_deform_bwd_input_fused(const float* col, const float* im_nhwc, const float* offset, float* grad_im_nhwc,
+                               float* grad_offset, int channels, int height, int width, int kh, int kw, int pad_h,
+                               int pad_w, int stride_h, int stride_w, int dil_h, int dil_w, int imgs,
+                               int deformable_group, long ld_col, sm3_stream_t stream) {
+  DcnGeom g;
+  if (!col || !im_nhwc || !offset || !grad_im_nhwc || !grad_offset ||
+      !make_geom(g, channels, height, width, kh, kw, pad_h, pad_w, stride_h, stride_w, dil_h, dil_w, imgs,
+                 deformable_group, ld_col))
+    return SM3_ERR_INVALID_ARG;
+  const long per_row = (long)g.ho * g.wo * imgs;
+  const long zt = (long)deformable_group * kh * kw;
+  if (zt > 65535) return SM3_ERR_UNSUPPORTED;
+  dim3 grid((unsigned)((per_row + 63) / 64), 1, (unsigned)zt);
+  deform_bwd_input_fused_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(col, im_nhwc, offset, g, grad_im_nhwc,
+                                                                       grad_offset);
   return launch_status();
 }
 

@@ -154,10 +154,14 @@ def deform_conv_backward_input(input, offset, gradOutput, gradInput, gradOffset,
                 LB.gemm(LB.TN, wg[g], go[g], colp[g], Kp, ld, Mg, lda=Kp, ldb=ld, splits=1)
             col = colp if Kp == Kg else colp[:, :Kg].contiguous()
             col = col.view(nIn * kH * kW, ld)
-            LB.call('deform_col2im_coord', col, input[sl], offset[sl], gradOffset[sl], *geom, ld)
-            # scatter on an NHWC scratch map (coalesced channel-vector atomics), then gradInput (NCHW) += scratch^T
+            # both gradients in one pass over the columns, NHWC on both sides: the input is transposed once, the input
+            # gradient is scattered on an NHWC scratch map (coalesced channel-vector atomics) and added into gradInput
+            inp = input[sl]
+            im_nhwc = torch.empty(step, H, W, nIn, device=input.device)
+            _lib.check(_lib.lib().sm3_transpose_f32(inp.data_ptr(), im_nhwc.data_ptr(), step, nIn, H * W,
+                                                    _lib.stream_ptr()), 'transpose_f32')
             scratch = torch.zeros(step, H, W, nIn, device=input.device)
-            LB.call('deform_col2im_nhwc', col, offset[sl], scratch, *geom, ld)
+            LB.call('deform_bwd_input_fused', col, im_nhwc, offset[sl], scratch, gradOffset[sl], *geom, ld)
             gi = gradInput[sl]
             _lib.check(_lib.lib().sm3_transpose_add_f32(scratch.data_ptr(), gi.data_ptr(), step, H * W, nIn,
                                                         _lib.stream_ptr()), 'transpose_add_f32')
