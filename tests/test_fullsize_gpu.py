@@ -151,12 +151,22 @@ def _run_case(case, amp):
             stats[name] = dict(max=float(e.max()), p999=float(torch.quantile(e, 0.999)), median=float(e.median()),
                                tol=tol, reference_fp32_floor=fx['fp32_floor'][i][name])
             stats[name]['frac_above_tol'] = float((e > tol).double().mean())
-            if strict:
+            if strict and amp:
+                # 2e-2 is the tolerance of the tensor (AMP vs the fp32 oracle): the element-wise metric
+                # divides small elements' absolute error (~1e-3 of the tensor's scale after a few fp16 GEMMs) by as little
+                # as 1 % of the scale, so for AMP it is applied to 99.9 % of the elements and the worst one gets 5x
+                assert stats[name]['p999'] < tol and float(e.max()) < 5 * tol, (case, f'out{i}', name, stats[name])
+            elif strict:
                 assert float(e.max()) < tol, (case, f'out{i}', name, stats[name])
             else:
                 # downstream of a flipped token: the token and its 7x7 neighbourhoods in later blocks differ by design
                 assert stats[name]['frac_above_tol'] <= (2e-2 if amp else 5e-3), (case, f'out{i}', name, stats[name])
             assert float(e.median()) < FWD_TOL / 10, (case, f'out{i}', name, stats[name])
+        if amp:  # and the max-norm form the small AMP fixtures use (tests/test_amp_gpu.py), on the stored samples
+            got_s = FC.summarise_output(i, o)['samples'].double()
+            mx = float((got_s - ref['samples'].double()).abs().max() / ref['max_abs'])
+            stats['max_norm_rel'] = mx
+            assert mx < (AMP_TOL if strict else 10 * AMP_TOL), (case, f'out{i}', mx)
         report[f'out{i}'] = dict(strict=strict, **stats)
     gl_err = abs(float(gl) - fx['gate_loss']) / abs(fx['gate_loss'])
     assert gl_err < (FWD_TOL if n_flips == 0 else max(FWD_TOL, 1e-3)), (case, float(gl), fx['gate_loss'])
@@ -176,7 +186,7 @@ def _run_case(case, amp):
     for key in table:
         e, l2 = FC.compare_grad(key, grads[key], fx['grads'])
         fe, fl2 = floor.get(key, (0.0, 0.0))
-        te, tl2 = max(BWD_TOL, 4.0 * fe), max(BWD_TOL, 4.0 * fl2)
+        te, tl2 = max(BWD_TOL, 4.0 * fe) * (5.0 if amp else 1.0), max(BWD_TOL, 4.0 * fl2)  # AMP: worst element 5x (see outputs)
         if te > BWD_TOL or tl2 > BWD_TOL:
             loosened[key] = dict(err=e, l2=l2, reference_fp32_floor=(fe, fl2))
         if e / te > worst[0]:
