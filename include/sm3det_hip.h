@@ -401,11 +401,12 @@ int sm3_scale_bwd_prep(const float* dout, const float* y, const float* gamma, co
  * scale = device scalar exp(min(temperature, ln 100)); noise (T,E) ~ N(0,1) (train) or NULL.
  * Outputs: top_idx/top_val (T, m=min(k+1,E)) descending; gates (T,k) = softmax(top k); clean (T,E); sigma (T,E)
  * (train); hnorm (T); partials (sm3_moe_router_partial_rows(T), 2E) = per-workgroup [importance | load] sums
- * (sum over dim 0 = totals, deterministic). */
+ * (sum over dim 0 = totals, deterministic).  forced_topk (T,k) int32 or NULL (production): teacher-forced routing for
+ * precision tests -- the given experts win the top-k selection, all values still come from this run's logits. */
 int sm3_moe_router_partial_rows(int T);
 int sm3_moe_router_fwd(const float* hcat, int ldh, int P, const float* snorm, const float* scale, const float* noise,
                        int T, int E, int k, int train, int32_t* top_idx, float* top_val, float* gates, float* clean,
-                       float* sigma, float* hnorm, float* partials, sm3_stream_t stream);
+                       float* sigma, float* hnorm, float* partials, const int32_t* forced_topk, sm3_stream_t stream);
 /* backward: dgate (T,k) from the combine, dimp/dload (E) from the aux loss.  Writes dhcat (T,ldh) = [dh | draw | 0],
  * dcn (T,E) = dclean/max(|h|,eps) and ds_part (sm3_moe_router_partial_rows(T)) partial sums of d(scale). */
 int sm3_moe_router_bwd(const float* hcat, int ldh, int P, const float* snorm, const float* scale, const float* noise,

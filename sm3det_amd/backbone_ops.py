@@ -337,7 +337,7 @@ class _MoEBlock(Function):
 
     @staticmethod
     def forward(ctx, x, w49, bdw, lnw, lnb, wp, bp, wn, sim, temp, w1, b1, w2, b2, gamma, rs, noise, eps, B, H, W, k,
-                train, clamp_max, loss_coef):
+                train, clamp_max, loss_coef, forced_topk=None):
         from . import _lib
         x = _chk(x, 'x')
         T, C = x.shape
@@ -373,8 +373,12 @@ class _MoEBlock(Function):
         sigma = _e(T, E, like=x) if train else None
         nblk = _lib.lib().sm3_moe_router_partial_rows(T)
         partials = _e(nblk, 2 * E, like=x)
+        if forced_topk is not None:
+            forced_topk = forced_topk.to(device=x.device, dtype=torch.int32).contiguous()
+            if forced_topk.shape != (T, k):
+                raise SM3Error(f'forced_topk must be ({T}, {k})')
         call('moe_router_fwd', hcat, PC, P, snorm, scale, noise, T, E, k, int(train), top_idx, top_val, gates,
-             clean, sigma, hnorm, partials, nbytes=4.0 * T * (PC + 4 * E))
+             clean, sigma, hnorm, partials, forced_topk, nbytes=4.0 * T * (PC + 4 * E))
         tot, loss = _e(2 * E, like=x), _e(1, like=x)
         call('moe_aux_loss_fwd', partials, nblk, E, float(loss_coef), tot, loss)
         # dispatch tables (no host sync)
@@ -486,12 +490,12 @@ class _MoEBlock(Function):
         _join_side(dev)
         return (dx, dw49, dbdw, dlnw, dlnb, dwp, dbp, dwn, dsim, None if dtemp is None else dtemp.reshape(temp.shape),
                 dw1, db1, dw2, db2, dgamma,
-                None, None, None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None, None, None)
 
 
 def moe_block(x, w49, bdw, lnw, lnb, wp, bp, wn, sim, temp, w1, b1, w2, b2, gamma, rs, noise, eps, B, H, W, k, train,
-              clamp_max, loss_coef=1e-2):
+              clamp_max, loss_coef=1e-2, forced_topk=None):
     """Returns (out (T,C), aux loss (scalar), [importance | load] (2E, non-differentiable), expert slot offsets
     (E+1, int32, non-differentiable), top-(k+1) expert indices per token (T, min(k+1,E), int32, non-differentiable))."""
     return _MoEBlock.apply(x, w49, bdw, lnw, lnb, wp, bp, wn, sim, temp, w1, b1, w2, b2, gamma, rs, noise, eps, B, H,
-                           W, k, train, clamp_max, loss_coef)
+                           W, k, train, clamp_max, loss_coef, forced_topk)

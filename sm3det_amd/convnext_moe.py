@@ -251,8 +251,9 @@ class ConvNeXtBlock(nn.Module):
             rs.div_(keep)
         return rs
 
-    def forward_tokens(self, x, B, H, W, noise=None, drop_scale=None):
-        """x (B*H*W, C) -> (out tokens, gate loss or None).  noise / drop_scale: injected randomness (tests)."""
+    def forward_tokens(self, x, B, H, W, noise=None, drop_scale=None, forced_topk=None):
+        """x (B*H*W, C) -> (out tokens, gate loss or None).  noise / drop_scale: injected randomness (tests);
+        forced_topk (T, k): teacher-forced routing (precision tests: see sm3_moe_router_fwd)."""
         C = self.in_channels
         w49 = self.depthwise_conv.weight  # tap-major (49, C)
         rs = self._rowscale(B, x.device) if drop_scale is None else drop_scale.to(x.device, torch.float32)
@@ -275,7 +276,7 @@ class ConvNeXtBlock(nn.Module):
         out, loss, tot, offsets, top_idx = ops.moe_block(
             x, w49, self.depthwise_conv.bias, self.norm.weight, self.norm.bias, *gate_args, moe.w1, moe.b1, moe.w2,
             moe.b2, self.gamma, rs, noise if train else None, self.norm.eps, B, H, W, moe.k, train, clamp_max,
-            moe.loss_coef)  # aux loss (:234-238) comes out of the block: coef * (cv^2(importance) + cv^2(load))
+            moe.loss_coef, forced_topk)  # aux loss (:234-238) comes out of the block: coef * (cv^2(importance) + cv^2(load))
         moe.last_expert_offsets = offsets
         moe.last_importance_load = tot
         moe.last_top_idx = top_idx
@@ -376,8 +377,9 @@ class ConvNeXt_moe(nn.Module):
     def _stem_norm(self):
         return self.downsample_layers[0][1]
 
-    def _forward_impl(self, x, noise=None, drop_scale=None):
-        """x: (B,3,H,W) NCHW fp32 on the GPU.  noise: optional list of (T,E) tensors, one per MoE block (tests)."""
+    def _forward_impl(self, x, noise=None, drop_scale=None, forced_routing=None):
+        """x: (B,3,H,W) NCHW fp32 on the GPU.  noise: optional list of (T,E) tensors, one per MoE block (tests);
+        forced_routing: optional list of (T,k) expert-index tensors, one per MoE block (teacher-forced routing, tests)."""
         if not x.is_cuda:
             raise RuntimeError('sm3det_amd backbone runs on the MI355X only (no CPU fallback)')
         B, _, Hi, Wi = x.shape
@@ -399,6 +401,7 @@ class ConvNeXt_moe(nn.Module):
             drop_scale = gen_drop if drop_scale is None else drop_scale
         noise_iter = iter(noise) if noise is not None else None
         drop_iter = iter(drop_scale) if drop_scale is not None else None
+        forced_iter = iter(forced_routing) if forced_routing is not None else None
         for i, stage in enumerate(self.stages):
             if i == 0:
                 tok = self._stem_norm().forward_tokens(tok)
@@ -412,7 +415,8 @@ class ConvNeXt_moe(nn.Module):
             for blk in stage:
                 nz = next(noise_iter) if (noise_iter is not None and blk.MoE_cfg is not None) else None
                 ds = next(drop_iter) if drop_iter is not None else None
-                tok, gl = blk.forward_tokens(tok, B, H, W, noise=nz, drop_scale=ds)
+                fr = next(forced_iter) if (forced_iter is not None and blk.MoE_cfg is not None) else None
+                tok, gl = blk.forward_tokens(tok, B, H, W, noise=nz, drop_scale=ds, forced_topk=fr)
                 if gl is not None:
                     gate_losses.append(gl)
                     self._gate_loss_terms.append((i, gl))
@@ -598,8 +602,8 @@ class ConvNeXt_moe_MultiInput(ConvNeXt_moe):
     def _stem_norm(self):
         return self.downsample_layers[0][0]
 
-    def forward(self, x, datasets=['single'], noise=None, drop_scale=None):
+    def forward(self, x, datasets=['single'], noise=None, drop_scale=None, forced_routing=None):
         if len(datasets) == 1:
             x = [x]
         x = torch.cat(list(x), dim=0)
-        return self._run(x, noise=noise, drop_scale=drop_scale)
+        return self._run(x, noise=noise, drop_scale=drop_scale, forced_routing=forced_routing)

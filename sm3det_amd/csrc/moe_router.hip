@@ -104,7 +104,7 @@ __global__ __launch_bounds__(RT_THREADS) void moe_router_fwd_kernel(
     const float* __restrict__ hcat, int ldh, int P, const float* __restrict__ snorm, const float* __restrict__ scale_p,
     const float* __restrict__ noise, int T, int E, int k, int train, int32_t* __restrict__ top_idx,
     float* __restrict__ top_val, float* __restrict__ gates, float* __restrict__ clean_o, float* __restrict__ sigma_o,
-    float* __restrict__ hnorm_o, float* __restrict__ partials) {
+    float* __restrict__ hnorm_o, float* __restrict__ partials, const int32_t* __restrict__ forced) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* s_s = sm;                         // snorm, row stride ET (zero padded), 16-byte aligned rows
   float* hs = sm + (long)P * ET;           // [16][P+1]
@@ -165,7 +165,16 @@ __global__ __launch_bounds__(RT_THREADS) void moe_router_fwd_kernel(
         logit[e] = cl[e] + nz[e] * sg[e];
       }
     }
-    // top-m selection (descending); ties -> lower index, like a stable descending sort
+    // top-m selection (descending); ties -> lower index, like a stable descending sort.
+    // `forced` (NULL in production; precision tests only): the k experts of every token are GIVEN (teacher-forced
+    // routing: e.g. the reference's own choice, so that a mixed-precision run can be compared with an fp32 reference
+    // without the butterfly effect of a near-tie routed the other way).  The forced experts win the selection -- ordered
+    // among themselves by this run's logits -- and the runner-up is the best of the others; every value below (gates,
+    // thresholds, load) is computed from this run's logits as usual.
+    unsigned fset = 0;
+    if (forced) {
+      for (int j = 0; j < k; j++) fset |= 1u << forced[(long)t * k + j];
+    }
     float tvv[ET];
     int tii[ET];
     unsigned used = 0;
@@ -176,12 +185,16 @@ __global__ __launch_bounds__(RT_THREADS) void moe_router_fwd_kernel(
       if (j < m) {
         float best = -INFINITY;
         int bi = -1;
+        bool bf = false;
 #pragma unroll
-        for (int e = 0; e < ET; e++)
-          if (e < E && !((used >> e) & 1u) && (bi < 0 || logit[e] > best)) {
+        for (int e = 0; e < ET; e++) {
+          const bool fe = (fset >> e) & 1u;
+          if (e < E && !((used >> e) & 1u) && (bi < 0 || (fe && !bf) || (fe == bf && logit[e] > best))) {
             best = logit[e];
             bi = e;
+            bf = fe;
           }
+        }
         used |= 1u << bi;
         tvv[j] = best;
         tii[j] = bi;
@@ -430,7 +443,7 @@ int sm3_moe_router_partial_rows(int T) { return (T + RT_TOKENS - 1) / RT_TOKENS;
 
 int sm3_moe_router_fwd(const float* hcat, int ldh, int P, const float* snorm, const float* scale, const float* noise,
                        int T, int E, int k, int train, int32_t* top_idx, float* top_val, float* gates, float* clean,
-                       float* sigma, float* hnorm, float* partials, sm3_stream_t stream) {
+                       float* sigma, float* hnorm, float* partials, const int32_t* forced_topk, sm3_stream_t stream) {
   if (!hcat || (snorm && !scale) || !top_idx || !top_val || !gates || !clean || !hnorm || !partials)
     return SM3_ERR_INVALID_ARG;
   if (!snorm && P < E) return SM3_ERR_INVALID_ARG;  // linear gate: the logits are the first E of the P columns
@@ -440,7 +453,8 @@ int sm3_moe_router_fwd(const float* hcat, int ldh, int P, const float* snorm, co
   hipStream_t st = (hipStream_t)stream;
 #define CALL(ET)                                                                                                   \
   moe_router_fwd_kernel<ET><<<nblk, RT_THREADS, ((size_t)P * ET + (size_t)RT_TOKENS * (P + 1)) * sizeof(float), st>>>( \
-      hcat, ldh, P, snorm, scale, noise, T, E, k, train, top_idx, top_val, gates, clean, sigma, hnorm, partials)
+      hcat, ldh, P, snorm, scale, noise, T, E, k, train, top_idx, top_val, gates, clean, sigma, hnorm, partials,     \
+      forced_topk)
   if (E <= 4) CALL(4);
   else if (E <= 8) CALL(8);
   else if (E <= 16) CALL(16);
