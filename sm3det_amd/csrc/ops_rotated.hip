@@ -525,12 +525,20 @@ __global__ __launch_bounds__(SWEEP_THREADS) void nms_sweep_lds_kernel(const uint
     if (tid < 64) {
       const int lane = tid;
       const int i = blk * 64 + lane;
-      uint64_t removed = remv[blk];
+      // The 64-step dependency chain (box b survives unless an earlier survivor of this block suppresses it) runs on the
+      // SCALAR unit: `removed` / `kept` are wave-uniform, row b of the diagonal block comes out of lane b with
+      // v_readlane (compile-time lane).  A __shfl of a 64-bit value per step is two dependent ds_bpermute round trips
+      // (~150 cycles): 64 of them were 4 us of the 6.4 us a step took.
+      const uint64_t r0 = remv[blk];
+      uint64_t removed = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(r0 >> 32)) << 32) |
+                         __builtin_amdgcn_readfirstlane((uint32_t)r0);
       const int nvalid = min(64, n - blk * 64);
+      const uint32_t dlo = (uint32_t)dcur, dhi = (uint32_t)(dcur >> 32);
       uint64_t kept = 0;
-      for (int b = 0; b < nvalid; b++) {
-        const uint64_t wb = __shfl(dcur, b, 64);
-        if (!((removed >> b) & 1ull)) {
+#pragma unroll
+      for (int b = 0; b < 64; b++) {
+        const uint64_t wb = ((uint64_t)__builtin_amdgcn_readlane(dhi, b) << 32) | __builtin_amdgcn_readlane(dlo, b);
+        if (b < nvalid && !((removed >> b) & 1ull)) {
           kept |= (1ull << b);
           removed |= wb;
         }
