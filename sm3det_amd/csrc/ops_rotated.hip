@@ -501,7 +501,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void nms_sweep_lds_kernel(const uint
   const int tid = threadIdx.x;
   for (int c = tid; c < nblk; c += SWEEP_THREADS) remv[c] = 0;
   if (tid == 0) s_count = 0;
-  auto fetch = [&](int blk, uint64_t (&w)[SWEEP_PREF], uint64_t& diag) {
+  auto fetch = [&](int blk, uint64_t (&w)[SWEEP_PREF], uint64_t& diag, int64_t& ord) {
     const int ncols = nblk - (blk + 1);
     const uint64_t* mrow = mask + (size_t)blk * 64 * nblk + (blk + 1);
 #pragma unroll
@@ -515,29 +515,35 @@ __global__ __launch_bounds__(SWEEP_THREADS) void nms_sweep_lds_kernel(const uint
       w[j] = v;
     }
     diag = 0;
-    if (tid < 64 && blk * 64 + tid < n) diag = mask[(size_t)(blk * 64 + tid) * nblk + blk];
+    ord = 0;
+    if (tid < 64 && blk * 64 + tid < n) {
+      diag = mask[(size_t)(blk * 64 + tid) * nblk + blk];
+      ord = order[blk * 64 + tid];  // the kept boxes' original indices: loaded ahead, not inside the serial step
+    }
   };
   uint64_t cur[SWEEP_PREF], nxt[SWEEP_PREF], dcur, dnxt = 0;
-  fetch(0, cur, dcur);
+  int64_t ocur, onxt = 0;
+  fetch(0, cur, dcur, ocur);
   __syncthreads();
   for (int blk = 0; blk < nblk; blk++) {
-    if (blk + 1 < nblk) fetch(blk + 1, nxt, dnxt);  // in flight during the serial scan below
+    if (blk + 1 < nblk) fetch(blk + 1, nxt, dnxt, onxt);  // in flight during the serial scan below
     if (tid < 64) {
       const int lane = tid;
-      const int i = blk * 64 + lane;
       // The 64-step dependency chain (box b survives unless an earlier survivor of this block suppresses it) runs on the
       // SCALAR unit: `removed` / `kept` are wave-uniform, row b of the diagonal block comes out of lane b with
       // v_readlane (compile-time lane).  A __shfl of a 64-bit value per step is two dependent ds_bpermute round trips
       // (~150 cycles): 64 of them were 4 us of the 6.4 us a step took.
       const uint64_t r0 = remv[blk];
-      uint64_t removed = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(r0 >> 32)) << 32) |
-                         __builtin_amdgcn_readfirstlane((uint32_t)r0);
+      // (the builtins return int: without the uint32_t casts a set bit 31 of the low word sign-extends into the high one)
+      uint64_t removed = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(r0 >> 32)) << 32) |
+                         (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)r0);
       const int nvalid = min(64, n - blk * 64);
       const uint32_t dlo = (uint32_t)dcur, dhi = (uint32_t)(dcur >> 32);
       uint64_t kept = 0;
 #pragma unroll
       for (int b = 0; b < 64; b++) {
-        const uint64_t wb = ((uint64_t)__builtin_amdgcn_readlane(dhi, b) << 32) | __builtin_amdgcn_readlane(dlo, b);
+        const uint64_t wb = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(dhi, b) << 32) |
+                            (uint64_t)(uint32_t)__builtin_amdgcn_readlane(dlo, b);
         if (b < nvalid && !((removed >> b) & 1ull)) {
           kept |= (1ull << b);
           removed |= wb;
@@ -546,7 +552,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void nms_sweep_lds_kernel(const uint
       const int base = s_count;
       if ((kept >> lane) & 1ull) {
         const int pos = __popcll(kept & ((1ull << lane) - 1ull));
-        keep[base + pos] = order[i];
+        keep[base + pos] = ocur;
       }
       if (lane == 0) {
         s_kept = kept;
@@ -578,6 +584,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void nms_sweep_lds_kernel(const uint
 #pragma unroll
     for (int j = 0; j < SWEEP_PREF; j++) cur[j] = nxt[j];
     dcur = dnxt;
+    ocur = onxt;
   }
   if (tid == 0) *num_keep = s_count;
 }
