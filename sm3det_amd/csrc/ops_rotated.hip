@@ -489,7 +489,8 @@ __global__ __launch_bounds__(SWEEP_THREADS) void nms_sweep_kernel(const uint64_t
 // 4.8 MB move (rocprofv3, round 3).  Here (i) remv[] lives in LDS (ds_or_b64, no L2 round trip), and (ii) while block
 // `blk` is being resolved every thread already holds the words of block row `blk + 1` in registers -- they do not depend
 // on which boxes survive, only their USE does -- so a step costs the 64-box serial scan plus one LDS phase.
-// Rows past PREF * 1024 words (N > 16 384) are read after the barrier as before.  Needs nblk * 8 bytes of LDS.
+// Columns past 16 * PREF = 256 of a block row (N > 16 448) are read after the barrier as before.  Needs nblk * 8 bytes
+// of LDS.
 constexpr int SWEEP_PREF = 16;
 __global__ __launch_bounds__(SWEEP_THREADS) void nms_sweep_lds_kernel(const uint64_t* __restrict__ mask,
                                                                      const int64_t* __restrict__ order, int n,
@@ -501,18 +502,18 @@ __global__ __launch_bounds__(SWEEP_THREADS) void nms_sweep_lds_kernel(const uint
   const int tid = threadIdx.x;
   for (int c = tid; c < nblk; c += SWEEP_THREADS) remv[c] = 0;
   if (tid == 0) s_count = 0;
+  // thread -> (row b of the block, column lane cl): columns cl, cl + 16, ... of row b (16 threads read 128 contiguous bytes;
+  // no index division -- a flat index / ncols per word cost ~1300 VALU instructions per thread and step, which with
+  // 4 waves per SIMD WAS the step time after the memory round trips were gone: 3.9 us)
+  const int rb_ = tid >> 4, cl = tid & 15;
   auto fetch = [&](int blk, uint64_t (&w)[SWEEP_PREF], uint64_t& diag, int64_t& ord) {
     const int ncols = nblk - (blk + 1);
-    const uint64_t* mrow = mask + (size_t)blk * 64 * nblk + (blk + 1);
+    const uint64_t* mrow = mask + ((size_t)blk * 64 + rb_) * nblk + (blk + 1);
+    const bool row_ok = blk * 64 + rb_ < n;
 #pragma unroll
     for (int j = 0; j < SWEEP_PREF; j++) {
-      const int idx = tid + j * SWEEP_THREADS;
-      uint64_t v = 0;
-      if (idx < 64 * ncols) {
-        const int b = idx / ncols, c = idx - b * ncols;
-        if (blk * 64 + b < n) v = mrow[(size_t)b * nblk + c];
-      }
-      w[j] = v;
+      const int c = cl + 16 * j;
+      w[j] = (row_ok && c < ncols) ? mrow[c] : 0ull;
     }
     diag = 0;
     ord = 0;
@@ -562,20 +563,14 @@ __global__ __launch_bounds__(SWEEP_THREADS) void nms_sweep_lds_kernel(const uint
     __syncthreads();
     const uint64_t kept = s_kept;
     const int ncols = nblk - (blk + 1);
+    if ((kept >> rb_) & 1ull) {
 #pragma unroll
-    for (int j = 0; j < SWEEP_PREF; j++) {
-      const int idx = tid + j * SWEEP_THREADS;
-      if (cur[j] != 0) {  // idx < 64 * ncols by construction
-        const int b = idx / ncols, c = idx - b * ncols;
-        if ((kept >> b) & 1ull) atomicOr((unsigned long long*)(remv + blk + 1 + c), (unsigned long long)cur[j]);
-      }
-    }
-    if (64 * ncols > SWEEP_PREF * SWEEP_THREADS) {  // very long rows: the part that was not prefetched
-      const uint64_t* mrow = mask + (size_t)blk * 64 * nblk + (blk + 1);
-      for (int idx = tid + SWEEP_PREF * SWEEP_THREADS; idx < 64 * ncols; idx += SWEEP_THREADS) {
-        const int b = idx / ncols, c = idx - b * ncols;
-        if (((kept >> b) & 1ull) && blk * 64 + b < n) {
-          const uint64_t w = mrow[(size_t)b * nblk + c];
+      for (int j = 0; j < SWEEP_PREF; j++)
+        if (cur[j] != 0) atomicOr((unsigned long long*)(remv + blk + 1 + cl + 16 * j), (unsigned long long)cur[j]);
+      if (ncols > 16 * SWEEP_PREF && blk * 64 + rb_ < n) {  // very long rows (N > 16 448): the part that was not prefetched
+        const uint64_t* mrow = mask + ((size_t)blk * 64 + rb_) * nblk + (blk + 1);
+        for (int c = cl + 16 * SWEEP_PREF; c < ncols; c += 16) {
+          const uint64_t w = mrow[c];
           if (w) atomicOr((unsigned long long*)(remv + blk + 1 + c), (unsigned long long)w);
         }
       }
