@@ -805,30 +805,37 @@ def main():
         g_n = sum(v['launches'] for v in gem)
         achieved = g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
         g_by = sum(v['bytes'] for v in gem)
-        traffic = None  # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside bench.py)
-        try:
-            with open(os.path.join(ROOT, 'profiles', 'r02', 'pmc_traffic.json')) as f:
-                traffic = round(json.load(f)['gemm_family']['hbm_bytes_per_launch'])
-        except Exception:
-            pass
+        # HBM bytes per launch from the committed PMC passes of this command (rocprofv3 cannot run inside bench.py); the
+        # passes exist for the headline workload (fp32 and AMP), other configs report null
+        traffic = traffic_file = None
+        if args.config == DEFAULT_CONFIG or (args.amp and args.config == 'SM3Det_convnext_t'):  # the same backbone
+            for rnd in ('r03', 'r02'):
+                cand = os.path.join('profiles', rnd, 'pmc_traffic_amp.json' if args.amp else 'pmc_traffic.json')
+                try:
+                    with open(os.path.join(ROOT, cand)) as f:
+                        traffic = round(json.load(f)['gemm_family']['hbm_bytes_per_launch'])
+                    traffic_file = cand
+                    break
+                except Exception:
+                    continue
         roofline = dict(bound='mfma', kernel='gemm_f32_kernel (NT/NN/TN, fp32 v_mfma_f32_32x32x2_f32)',
                         achieved=round(achieved, 2), peak=MI355X_FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
                         frac=round(achieved / MI355X_FP32_MFMA_PEAK_TFLOPS, 4), traffic=traffic,
-                        traffic_source='profiles/r02/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, '
-                                       'FETCH x2 + WRITE, per launch incl. the slice-reduce pass of the TN launches; '
-                                       'scripts/collect_artifacts.sh)',
+                        traffic_source=None if traffic_file is None else
+                        f'{traffic_file} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, FETCH x2 + WRITE, '
+                        'per launch incl. the slice-reduce pass of the TN launches; scripts/collect_artifacts.sh)',
                         algorithmic_bytes_per_launch=round(g_by / max(g_n, 1)),
                         launches_per_step=g_n, avg_launch_us=round(g_ms / max(g_n, 1) * 1e3, 2),
                         algorithmic_gflop_per_step=round(g_fl / 1e9, 1),
                         gemm_ms_per_step=round(g_ms, 3),
                         other_kernels_ms_per_step=round(sum(v['ms'] for n, v in kernels.items()
                                                             if not n.startswith('gemm_f')), 3))
-        if args.amp:  # fp16 operands: 16x the matrix rate -> the family streams its fp32 operands: HBM-bound
+        if args.amp:  # fp16 operands: 16x the matrix rate -> the family streams its operands: HBM-bound
             gbs = g_by / (g_ms * 1e-3) / 1e9 if g_ms > 0 else 0.0
-            roofline.update(bound='hbm', kernel='gemm_f32_kernel<.., F16> (fp16 operands rounded in the loader, '
-                            'v_mfma_f32_32x32x16_f16, fp32 tensors in HBM)', achieved=round(gbs, 1),
-                            peak=MI355X_HBM_PEAK_GBS, unit='GB/s', frac=round(gbs / MI355X_HBM_PEAK_GBS, 4),
-                            traffic=None, traffic_source=None, mfma_tflops=round(achieved, 1))
+            roofline.update(bound='hbm', kernel='gemm_f32_kernel<.., F16, IO> (v_mfma_f32_32x32x16_f16; activations stored '
+                            'fp16 in HBM, weights / residual stream / C-wide gradients fp32 and rounded in the loader)',
+                            achieved=round(gbs, 1), peak=MI355X_HBM_PEAK_GBS, unit='GB/s',
+                            frac=round(gbs / MI355X_HBM_PEAK_GBS, 4), mfma_tflops=round(achieved, 1))
 
     result = None
     if rank == 0:

@@ -36,6 +36,7 @@ def _hipcc():
 # run time with SM3DET_HIP_LIB=<path> (sm3det_amd/_lib.py).  Measurement aids, never loaded by default.
 VARIANTS = {
     'gelu_exact': ['-DSM3_GELU_EXACT=1'],  # GELU epilogues through ocml erff/expf instead of the A&S 7.1.26 polynomial
+    'f16_occ2': ['-DSM3_F16_OCC=2'],       # fp16-operand GEMMs at two workgroups per CU (round-2 occupancy)
 }
 
 

@@ -9,7 +9,8 @@ namespace sm3gemm {
 template <int MODE, int EPI, class TL>
 static void go16(const GemmParams& p, int bk, dim3 grid, hipStream_t st) {
   if (bk == 16) gemm_f32_kernel<MODE, EPI, 16, TL, 0, 1><<<grid, NTHREADS, 0, st>>>(p);
-  else gemm_f32_kernel<MODE, EPI, 32, TL, 0, 1><<<grid, NTHREADS, 0, st>>>(p);
+  else if (bk == 32) gemm_f32_kernel<MODE, EPI, 32, TL, 0, 1><<<grid, NTHREADS, 0, st>>>(p);
+  else gemm_f32_kernel<MODE, EPI, 64, TL, 0, 1><<<grid, NTHREADS, 0, st>>>(p);
 }
 
 template <int MODE, int EPI>

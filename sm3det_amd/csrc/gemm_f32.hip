@@ -234,7 +234,7 @@ inline double quant_cost(long blocks) {
 //  * TN: (128x128, 128x96, 96x128) x slices 1..192 reduced by the second pass (never the in-kernel fix-up: on 64 KB slabs
 //    it measured slower); cost = quantisation x waste x handicap + the slab round trip, 60*G/K of the GEMM's own time per
 //    slice.  Since the k-loop lost its vector-ALU work the 96-wide tiles are as fast per FLOP as 128x128.
-// d->tuning (benchmarking aid, 0 in production): bits 0-3 tile+1, 4-7 k-step (1 = 16, 2 = 32), 8-15 slices,
+// d->tuning (benchmarking aid, 0 in production): bits 0-3 tile+1, 4-7 k-step (1 = 16, 2 = 32, 3 = 64: fp16 only), 8-15 slices,
 // bit 16: TN slices summed by the in-kernel fix-up instead of the second pass (so a literal 256 in the slices field
 // reads as `automatic + fix-up`: scripts/gemm_sweep2.py)
 Cfg choose_cfg(const sm3_gemm_desc* d) {
@@ -253,8 +253,8 @@ Cfg choose_cfg(const sm3_gemm_desc* d) {
     static const double handicap[3] = {1.0, 1.04, 1.02};
     int bk = d->K >= 1024 ? 32 : 16;
     if (t_bk) bk = t_bk == 1 ? 16 : 32;
-    if (d->compute == 1) bk = t_bk == 1 ? 16 : 32;  // fp16 operands
-    if (d->K % bk) bk = 16;
+    if (d->compute == 1) bk = t_bk == 1 ? 16 : (t_bk == 3 ? 64 : 32);  // fp16 operands
+    if (d->K % bk) bk = (bk == 64 && d->K % 32 == 0) ? 32 : 16;
     const int kt = d->K / bk;
     double best = 0;
     int best_s = 1;
@@ -329,7 +329,7 @@ Cfg choose_cfg(const sm3_gemm_desc* d) {
   if (t_bk) c.bk = t_bk == 1 ? 16 : 32;
   if (c.tile >= 3) c.bk = 16;
   if (d->compute == 1) {
-    c.bk = t_bk == 1 ? 16 : 32;
+    c.bk = t_bk == 1 ? 16 : (t_bk == 3 ? 64 : 32);
     if (c.tile > 2) c.tile = 0;
   }
   tile_dims(c.tile, c.bm, c.bn);

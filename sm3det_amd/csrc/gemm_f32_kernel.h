@@ -104,8 +104,15 @@ using T192x128 = Tile<2, 2, 3, 2>;
 using T64x128 = Tile<2, 2, 1, 2>;
 
 // resident workgroups per CU the launch bounds ask for (VGPR budget 512 / waves-per-SIMD)
-template <class TL, int BK>
+#ifndef SM3_F16_OCC
+#define SM3_F16_OCC 3  // A/B builds: python -m sm3det_amd.build --variant f16_occ2
+#endif
+template <class TL, int BK, int F16 = 0>
 constexpr int occupancy() {
+  // F16: the fp16 LDS image of a k-step-32 tile is 34 KB (the fp32 image 66 KB), so three workgroups fit a CU and the
+  // loop -- bound by load latency, not by the matrix pipe -- gets a third wave per SIMD to hide it; k-step 64 (68 KB,
+  // twice the MFMAs per barrier) runs two
+  if (F16) return BK == 64 ? 2 : SM3_F16_OCC;
   // 128x128 at k-step 16 needs ~150 VGPRs to keep its LDS read bases out of the loop: 3 waves per SIMD without spills
   // instead of 4 with scratch reloads and address arithmetic between the MFMAs
   return (TL::TI * TL::TJ >= 6 || BK == 32) ? 2 : (TL::TI * TL::TJ >= 3 ? 3 : 4);
@@ -152,15 +159,6 @@ __device__ __forceinline__ void gelu_erf_both(float h, float& y, float& dy) {
   dy = fmaf(h, pdf, cdf);
 }
 
-// LDS bytes of one instantiation
-template <int MODE, int BK, class TL>
-constexpr int smem_floats() {
-  constexpr int PADT = (BK == 32) ? 1 : 2;
-  constexpr int lda = (MODE != MODE_TN) ? TL::BM + PADT : TL::BM + 4;
-  constexpr int ldb = (MODE == MODE_NT) ? TL::BN + PADT : TL::BN + 4;
-  return 2 * BK * (lda + ldb);
-}
-
 // IO (F16 = 1 only): which tensors live in HBM as fp16 -- the AMP data path (mmcv wrap_fp16_model / autocast: the outputs of
 // nn.Linear are half tensors, mmcv/mmcv/runner/fp16_utils.py:71-149).  Weights, biases, the residual stream and every
 // C-wide gradient stay fp32; the LayerNorm output that feeds the GEMMs and the three 4C-wide tensors of a block (GELU
@@ -168,7 +166,7 @@ constexpr int smem_floats() {
 constexpr int IO_A16 = 1, IO_B16 = 2, IO_C16 = 4, IO_X16 = 8;  // A operand, B operand, C output, aux_in / aux_out
 
 template <int MODE, int EPI, int BK, class TL, int GATHER, int F16 = 0, int CSUM = 0, int IO = 0>
-__global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kernel(GemmParams p) {
+__global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32_kernel(GemmParams p) {
   constexpr int BM = TL::BM, BN = TL::BN, TI = TL::TI, TJ = TL::TJ, WN = TL::WN, WM = TL::WM;
   constexpr bool A16 = (IO & IO_A16) != 0, B16 = (IO & IO_B16) != 0, C16 = (IO & IO_C16) != 0, X16 = (IO & IO_X16) != 0;
   static_assert(IO == 0 || (F16 && !GATHER), "fp16 storage only with fp16 operands");
@@ -184,8 +182,6 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
   constexpr int LDA_S = A_TRANS ? BM + PADT : BM + 4;
   constexpr int LDB_S = B_TRANS ? BN + PADT : BN + 4;
   constexpr int A_STAGE = BK * LDA_S, B_STAGE = BK * LDB_S;
-  __shared__ __attribute__((aligned(16))) float smem[2 * (A_STAGE + B_STAGE)];
-  float* As = smem;                // [2][BK][LDA_S]
   // F16: the LDS image holds fp16, converted once when a piece is stored.  The 8 consecutive k of one row (one MFMA
   // fragment of a lane) are 16 contiguous bytes: element (k, r) lives in half ((k / 8) * LD16 + r) * 8 + (k & 7), so a
   // fragment is ONE conflict-free ds_read_b128 with no conversion or permute between it and the MFMA (the fp32 image
@@ -193,9 +189,15 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
   // stores of a k-step-32 tile on distinct banks.
   constexpr int LDA16 = BM + 4, LDB16 = BN + 4;                          // rows per k-octet
   constexpr int A_ST16 = (BK / 8) * LDA16 * 4, B_ST16 = (BK / 8) * LDB16 * 4;  // dwords per stage
+  // the allocation is the image of the instantiation's own precision (round 2 gave F16 the fp32 size, which capped it at
+  // two workgroups per CU); never below the epilogue's per-wave staging patches (4 x 32 x 36 floats)
+  static_assert(!(F16 && CSUM), "the column-sum by-product folds through an fp32-sized scratch");
+  constexpr int SMEM_IMAGE = F16 ? 2 * (A_ST16 + B_ST16) : 2 * (A_STAGE + B_STAGE);
+  constexpr int SMEM_WORDS = SMEM_IMAGE > 4 * 32 * 36 ? SMEM_IMAGE : 4 * 32 * 36;
+  __shared__ __attribute__((aligned(16))) float smem[SMEM_WORDS];
+  float* As = smem;                // [2][BK][LDA_S]
   uint32_t* Aw = reinterpret_cast<uint32_t*>(smem);  // [2][BK/8][LDA16][4 dwords], then B
   uint32_t* Bw = Aw + 2 * A_ST16;
-  static_assert(!F16 || 2 * (A_ST16 + B_ST16) <= 2 * (A_STAGE + B_STAGE), "F16 image fits the fp32 allocation");
   float* Bs = smem + 2 * A_STAGE;  // [2][BK][LDB_S]
 
   const int tid = threadIdx.x;
@@ -731,24 +733,31 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
     const uint32_t* b_w = Bw + buf * B_ST16 + (wn0 + l31) * 4;
 #pragma unroll
     for (int q = 0; q < NP; q++) load_piece(na, nb, q, kt_load, tail);
-#pragma unroll
-    for (int ks = 0; ks < BK / 16; ks++) {
-      f16x8 a[TI], b[TJ];
+    // fragments of sub-step ks + 1 are requested before the MFMAs of sub-step ks (one LDS round trip per step instead of
+    // one per sub-step); the LDS writes of tile kt + 1 go out after the first sub-step's reads
+    constexpr int KS = BK / 16;
+    f16x8 a[2][TI], b[2][TJ];
+    auto frag = [&](int ks, f16x8 (&fa)[TI], f16x8 (&fb)[TJ]) {
 #pragma unroll
       for (int i = 0; i < TI; i++)
-        a[i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(a_w + ((2 * ks + lh) * LDA16 + 32 * i) * 4));
+        fa[i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(a_w + ((2 * ks + lh) * LDA16 + 32 * i) * 4));
 #pragma unroll
       for (int j = 0; j < TJ; j++)
-        b[j] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(b_w + ((2 * ks + lh) * LDB16 + 32 * j) * 4));
+        fb[j] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(b_w + ((2 * ks + lh) * LDB16 + 32 * j) * 4));
+    };
+    frag(0, a[0], b[0]);
 #pragma unroll
-      for (int i = 0; i < TI; i++)
-#pragma unroll
-        for (int j = 0; j < TJ; j++)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[j], a[i], acc[i][j], 0, 0, 0);
+    for (int ks = 0; ks < KS; ks++) {
+      if (ks + 1 < KS) frag(ks + 1, a[(ks + 1) & 1], b[(ks + 1) & 1]);
       if (ks == 0) {
 #pragma unroll
         for (int q = 0; q < NP; q++) store_piece(ca, cb, q, buf ^ 1, live);
       }
+#pragma unroll
+      for (int i = 0; i < TI; i++)
+#pragma unroll
+        for (int j = 0; j < TJ; j++)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[ks & 1][j], a[ks & 1][i], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
   };
@@ -1007,7 +1016,7 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK>())) void gemm_f32_kern
 int launch_nt(const GemmParams& p, int epi, int tile, int bk, int gather, dim3 grid, hipStream_t st);
 int launch_nn(const GemmParams& p, int epi, int tile, int bk, int gather, dim3 grid, hipStream_t st);
 int launch_tn(const GemmParams& p, int tile, int bk, int gather, dim3 grid, hipStream_t st);
-// fp16-operand variants (gemm_f16.hip): k-step 16 | 32, tiles 0 / 1 / 5 (NT, NN), 0 / 1 / 2 (TN)
+// fp16-operand variants (gemm_f16.hip): k-step 16 | 32 | 64, tiles 0 / 1 / 5 (NT, NN), 0 / 1 / 2 (TN)
 // io: IO_* bits = which tensors are stored as fp16 (0: all fp32 in HBM, rounded in the loader).  gemm_h16.hip holds the
 // io != 0 instantiations: NT {A16: bias / bias+scale+residual / none; A16|C16|X16: bias+GELU}, NN {A16: none;
 // C16|X16: GELU'}, TN {B16; A16|B16}

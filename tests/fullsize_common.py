@@ -187,3 +187,17 @@ def compare_grad(key, g, packed):
     e = elementwise_err(vals, rv, ref['max_abs'])
     l2 = abs(got['l2'] - ref['l2']) / (ref['l2'] + 1e-30)
     return float(e.max()), l2
+
+
+def compare_grad_maxnorm(key, g, packed):
+    """-> (max |a - ref| over the stored elements / the tensor's largest |ref|, relative error of the projection of `a`
+    on the reference direction over the stored elements): the max-norm form the AMP tests use (tests/test_amp_gpu.py);
+    the projection catches a wrong overall scale, which random rounding noise does not produce"""
+    ref = packed['table'][key]
+    _, vals = summarise_grad(key, g)
+    rv = packed['values'][ref['off']:ref['off'] + ref['n']].double()
+    vals = vals.detach().double().cpu().reshape(-1)
+    mx = float((vals - rv).abs().max() / (ref['max_abs'] + 1e-30))
+    den = float((rv * rv).sum())  # 0 for the parameters of a block whose only sample was dropped (drop path)
+    proj = float(abs((vals * rv).sum() / den - 1.0)) if den > 0 else 0.0
+    return mx, proj
