@@ -2,7 +2,7 @@
 AMP data path stores as fp16 in fp16 (gemm_h16.hip); prints per shape the default configuration's time and every
 alternative, best first, plus the step total of the defaults and of the per-shape best.
 
-    python scripts/gemm_sweep_amp.py [--default-only]  > gpurun_out/gemm_sweep_amp.txt
+    python scripts/gemm_sweep_amp.py [--default-only] [--cold]  > gpurun_out/gemm_sweep_amp.txt
 """
 import json
 import os
@@ -17,6 +17,8 @@ from sm3det_amd import amp  # noqa: E402
 import numpy as np  # noqa: E402
 
 BK = {None: 0, 16: 1, 32: 2, 64: 3}
+# --cold: six rotating argument sets per shape, so that no launch finds its operands in the 256 MB MALL / the L2s
+ROT = 6 if '--cold' in sys.argv else 1
 
 
 def tune(tile=None, bk=None, splits=0):
@@ -33,6 +35,9 @@ def candidates(mode):
     for t in tiles:
         for bk in (32, 64):
             out.append(dict(tile=t, bk=bk))
+            if '--splits' in sys.argv:
+                for sp in ((2, 3, 4, 6, 8) if mode != 'tn' else (1, 2, 4, 8, 16, 32, 64)):
+                    out.append(dict(tile=t, bk=bk, splits=sp))
     return out
 
 
@@ -49,38 +54,41 @@ def main():
                 c = (frac * rows).astype(np.int64)
                 c[-1] += rows - c.sum()
                 offs = torch.tensor(np.concatenate([[0], np.cumsum(c)]), dtype=torch.int32, device=dev)
-            bias = torch.randn(G, N, device=dev)
-            gamma = torch.randn(N, device=dev)
-            cs = torch.empty(G, N, device=dev)
-            kw = dict(offsets=offs, num_groups=G)
-            if mode == 'nt':
-                A, B = torch.randn(M, K, device=dev).to(h), torch.randn(G, N, K, device=dev) * 0.05
-                if epi == LB.EPI_BIAS_GELU:  # FC1: act and GELU' stored as halves
-                    C = torch.empty(M, N, device=dev, dtype=h)
-                    kw.update(epilogue=epi, bias=bias, aux_out=torch.empty(M, N, device=dev, dtype=h))
-                elif epi == LB.EPI_BIAS_SCALE_RES:
-                    C = torch.empty(M, N, device=dev)
-                    kw.update(epilogue=epi, bias=bias, aux_in=torch.randn(M, N, device=dev), aux_out=torch.empty(M, N, device=dev),
-                              gamma=gamma)
+            sets = []
+            for _rep in range(ROT):
+                bias = torch.randn(G, N, device=dev)
+                gamma = torch.randn(N, device=dev)
+                cs = torch.empty(G, N, device=dev)
+                kw = dict(offsets=offs, num_groups=G)
+                if mode == 'nt':
+                    A, B = torch.randn(M, K, device=dev).to(h), torch.randn(G, N, K, device=dev) * 0.05
+                    if epi == LB.EPI_BIAS_GELU:  # FC1: act and GELU' stored as halves
+                        C = torch.empty(M, N, device=dev, dtype=h)
+                        kw.update(epilogue=epi, bias=bias, aux_out=torch.empty(M, N, device=dev, dtype=h))
+                    elif epi == LB.EPI_BIAS_SCALE_RES:
+                        C = torch.empty(M, N, device=dev)
+                        kw.update(epilogue=epi, bias=bias, aux_in=torch.randn(M, N, device=dev), aux_out=torch.empty(M, N, device=dev),
+                                  gamma=gamma)
+                    else:
+                        C = torch.empty(M, N, device=dev)
+                        kw.update(epilogue=epi, bias=bias)
+                elif mode == 'nn':
+                    B = torch.randn(G, K, N, device=dev) * 0.05
+                    if epi == LB.EPI_GELU_BWD:  # dy (fp32) . W2 x GELU' (half) -> dh (half)
+                        A = torch.randn(M, K, device=dev)
+                        C = torch.empty(M, N, device=dev, dtype=h)
+                        kw.update(epilogue=epi, aux_in=torch.randn(M, N, device=dev).to(h), colsum_out=cs)
+                    else:                       # dh (half) . W1 -> fp32
+                        A = torch.randn(M, K, device=dev).to(h)
+                        C = torch.empty(M, N, device=dev)
                 else:
-                    C = torch.empty(M, N, device=dev)
-                    kw.update(epilogue=epi, bias=bias)
-            elif mode == 'nn':
-                B = torch.randn(G, K, N, device=dev) * 0.05
-                if epi == LB.EPI_GELU_BWD:  # dy (fp32) . W2 x GELU' (half) -> dh (half)
-                    A = torch.randn(M, K, device=dev)
-                    C = torch.empty(M, N, device=dev, dtype=h)
-                    kw.update(epilogue=epi, aux_in=torch.randn(M, N, device=dev).to(h), colsum_out=cs)
-                else:                       # dh (half) . W1 -> fp32
-                    A = torch.randn(M, K, device=dev).to(h)
-                    C = torch.empty(M, N, device=dev)
-            else:
-                # weight gradients: dh^T x (both halves) when the output is 4C x C, dy^T act (fp32, half) when C x 4C
-                A = torch.randn(K, M, device=dev)
-                if M > N:
-                    A = A.to(h)
-                B = torch.randn(K, N, device=dev).to(h)
-                C = torch.empty(G, M, N, device=dev)
+                    # weight gradients: dh^T x (both halves) when the output is 4C x C, dy^T act (fp32, half) when C x 4C
+                    A = torch.randn(K, M, device=dev)
+                    if M > N:
+                        A = A.to(h)
+                    B = torch.randn(K, N, device=dev).to(h)
+                    C = torch.empty(G, M, N, device=dev)
+                sets.append((A, B, C, dict(kw)))
             md = dict(nt=LB.NT, nn=LB.NN, tn=LB.TN)[mode]
             cands = candidates(mode)
             best_t = [float('inf')] * len(cands)
@@ -91,11 +99,13 @@ def main():
                         continue
                     LB.TUNING = tune(**cand)
                     try:
-                        for _ in range(2):
+                        for r_ in range(2):
+                            A, B, C, kw = sets[r_ % ROT]
                             LB.gemm(md, A, B, C, M, N, K, **kw)
                         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                         e0.record()
-                        for _ in range(6):
+                        for r_ in range(6):
+                            A, B, C, kw = sets[(r_ + 2) % ROT]
                             LB.gemm(md, A, B, C, M, N, K, **kw)
                         e1.record()
                         torch.cuda.synchronize()
@@ -110,7 +120,7 @@ def main():
             tot_def += d_us * cnt
             tot_best += res[0][0] * cnt
             print(f'{mode} {M}x{N}x{K} g{G} e{epi} x{cnt}: default {d_us:.1f} us ({fl / d_us / 1e6:.0f} TF)  best {res[0][0]:.1f} us '
-                  f'{res[0][1]}   ' + '  '.join(f'{t:.1f}:{c.get("tile", "-")}/{c.get("bk", "-")}' for t, c in res[1:]), flush=True)
+                  f'{res[0][1]}   ' + '  '.join(f'{t:.1f}:{c.get("tile", "-")}/{c.get("bk", "-")}/{c.get("splits", "-")}' for t, c in res[1:12]), flush=True)
             if errs:
                 print('      errors:', errs)
             print('JSON ' + json.dumps(dict(mode=mode, M=M, N=N, K=K, G=G, epi=epi, count=cnt, default_us=d_us,

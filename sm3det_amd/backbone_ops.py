@@ -100,10 +100,10 @@ def _tn(dy, x, M, N, rows, **kw):
 
 
 def _tn_bias(dy, x, M, N, rows, db, **kw):
-    """dW = dy^T x and db = column sums of dy in one launch: the fp32 TN kernel sums the rows of its A operand while it
-    loads them (no separate column-sum kernel, no zero-fill, dy is read once).  The fp16-operand mode keeps the
-    separate kernel."""
-    if LB.COMPUTE == 0:
+    """dW = dy^T x and db = column sums of dy in one launch: the TN kernel sums the rows of its A operand while it
+    loads them (no separate column-sum kernel, no zero-fill, dy is read once).  Only an fp16-STORED dy keeps the
+    separate kernel (the C-wide gradients of the AMP data path are fp32)."""
+    if dy.dtype == torch.float32:
         return _tn(dy, x, M, N, rows, colsum_out=db, **kw)
     colsum(dy, rows, M, db, offsets=kw.get('offsets'), num_groups=kw.get('num_groups', 1))
     return _tn(dy, x, M, N, rows, **kw)

@@ -37,6 +37,9 @@ def _hipcc():
 VARIANTS = {
     'gelu_exact': ['-DSM3_GELU_EXACT=1'],  # GELU epilogues through ocml erff/expf instead of the A&S 7.1.26 polynomial
     'f16_occ2': ['-DSM3_F16_OCC=2'],       # fp16-operand GEMMs at two workgroups per CU (round-2 occupancy)
+    # phase ablations of the fp16-operand GEMM loop (results are WRONG by construction: timing only)
+    'abl_noload': ['-DSM3_ABL_NOLOAD=1'], 'abl_nostore': ['-DSM3_ABL_NOSTORE=1'], 'abl_nomfma': ['-DSM3_ABL_NOMFMA=1'],
+    'abl_noepi': ['-DSM3_ABL_NOEPI=1'], 'abl_loop_only_mfma': ['-DSM3_ABL_NOLOAD=1', '-DSM3_ABL_NOSTORE=1', '-DSM3_ABL_NOEPI=1'],
 }
 
 

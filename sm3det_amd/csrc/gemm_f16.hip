@@ -42,12 +42,21 @@ int launch_nn16(const GemmParams& p, int epi, int tile, int bk, int io, dim3 gri
   return SM3_ERR_INVALID_ARG;
 }
 
+template <class TL>
+static void go16_tn(const GemmParams& p, int bk, dim3 grid, hipStream_t st) {
+  if (!p.csum) return go16<MODE_TN, EPI_NONE, TL>(p, bk, grid, st);
+  // + column sums of the (fp32) A operand: the bias gradient next to the weight gradient, as in the fp32 form
+  if (bk == 16) gemm_f32_kernel<MODE_TN, EPI_NONE, 16, TL, 0, 1, 1><<<grid, NTHREADS, 0, st>>>(p);
+  else if (bk == 32) gemm_f32_kernel<MODE_TN, EPI_NONE, 32, TL, 0, 1, 1><<<grid, NTHREADS, 0, st>>>(p);
+  else gemm_f32_kernel<MODE_TN, EPI_NONE, 64, TL, 0, 1, 1><<<grid, NTHREADS, 0, st>>>(p);
+}
+
 int launch_tn16(const GemmParams& p, int tile, int bk, int io, dim3 grid, hipStream_t st) {
   if (io) return launch_tn_h16(p, tile, bk, io, grid, st);
   switch (tile) {
-    case 0: go16<MODE_TN, EPI_NONE, T128x128>(p, bk, grid, st); return SM3_OK;
-    case 1: go16<MODE_TN, EPI_NONE, T128x96>(p, bk, grid, st); return SM3_OK;
-    case 2: go16<MODE_TN, EPI_NONE, T96x128>(p, bk, grid, st); return SM3_OK;
+    case 0: go16_tn<T128x128>(p, bk, grid, st); return SM3_OK;
+    case 1: go16_tn<T128x96>(p, bk, grid, st); return SM3_OK;
+    case 2: go16_tn<T96x128>(p, bk, grid, st); return SM3_OK;
   }
   return SM3_ERR_INVALID_ARG;
 }

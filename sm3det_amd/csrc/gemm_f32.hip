@@ -250,10 +250,19 @@ Cfg choose_cfg(const sm3_gemm_desc* d) {
     // CUs left with fewer than two workgroups x 10 % per extra slice (fix-up traffic); refitted on
     // profiles/r02/gemm_sweep_r02b.txt (regret 0.3 % of the summed NT/NN time of the training step)
     static const int cand[3] = {0, 1, 5};
-    static const double handicap[3] = {1.0, 1.04, 1.02};
+    static const double handicap32[3] = {1.0, 1.04, 1.02};
+    // fp16 operands: the loop is bound by operand delivery, not by the matrix pipe, so the tile with the most reuse wins
+    // unless CU-round quantisation costs more than 15 % (cold-operand sweep, profiles/r03/amp_gemm/gemm_sweep_amp_cold.txt)
+    static const double handicap16[3] = {1.0, 1.04, 1.15};
+    const double* handicap = d->compute == 1 ? handicap16 : handicap32;
     int bk = d->K >= 1024 ? 32 : 16;
     if (t_bk) bk = t_bk == 1 ? 16 : 32;
-    if (d->compute == 1) bk = t_bk == 1 ? 16 : (t_bk == 3 ? 64 : 32);  // fp16 operands
+    if (d->compute == 1) {
+      // k-step 64 (two workgroups per CU, half the barriers, 128 contiguous bytes per fp16 row and step) pays on the long
+      // reductions and on the stage-0 FC2 shape (N <= 128 columns, an M-long stream of fp16 rows); same sweep
+      bk = (d->K >= 3072 || (d->mode == MODE_NT && d->N <= 128 && d->K >= 384 && d->M >= 65536)) ? 64 : 32;
+      if (t_bk) bk = t_bk == 1 ? 16 : (t_bk == 3 ? 64 : 32);
+    }
     if (d->K % bk) bk = (bk == 64 && d->K % 32 == 0) ? 32 : 16;
     const int kt = d->K / bk;
     double best = 0;
@@ -302,7 +311,8 @@ Cfg choose_cfg(const sm3_gemm_desc* d) {
   }
   // ---- TN
   static const int cand[3] = {0, 1, 2};
-  static const double handicap[3] = {1.0, 0.97, 0.97};
+  static const double handicap32[3] = {1.0, 0.97, 0.97}, handicap16[3] = {1.0, 1.1, 1.1};  // fp16: see above
+  const double* handicap = d->compute == 1 ? handicap16 : handicap32;
   const int rows = d->K / G > 0 ? d->K / G : 1;
   const double pen = d->K > 0 ? 60.0 * G / d->K : 0.0;
   double best = 0;
@@ -417,7 +427,8 @@ int sm3_gemm_f32(const sm3_gemm_desc* d, void* workspace, size_t workspace_bytes
     float* out = d->C;
     const long mn1 = (long)d->M * d->N;
     const bool cs = d->colsum_out != nullptr;  // bias gradient = column sums of A, a by-product of the A loader
-    if (cs && (d->compute != 0 || c.fixup)) return SM3_ERR_UNSUPPORTED;
+    // (an fp16-STORED A operand has no fp32 values to add: the caller keeps the separate column-sum kernel there)
+    if (cs && (c.fixup || (d->io & 1))) return SM3_ERR_UNSUPPORTED;
     const long mn = mn1 + (cs ? d->M : 0);
     if (c.splits > 1 && !c.fixup) {  // raw slices to the workspace, separate reduce pass
       p.C = (float*)workspace;

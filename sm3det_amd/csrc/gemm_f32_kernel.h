@@ -191,9 +191,10 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
   constexpr int A_ST16 = (BK / 8) * LDA16 * 4, B_ST16 = (BK / 8) * LDB16 * 4;  // dwords per stage
   // the allocation is the image of the instantiation's own precision (round 2 gave F16 the fp32 size, which capped it at
   // two workgroups per CU); never below the epilogue's per-wave staging patches (4 x 32 x 36 floats)
-  static_assert(!(F16 && CSUM), "the column-sum by-product folds through an fp32-sized scratch");
+  static_assert(!(CSUM && A16), "the column-sum by-product adds the fp32 values of the A pieces");
   constexpr int SMEM_IMAGE = F16 ? 2 * (A_ST16 + B_ST16) : 2 * (A_STAGE + B_STAGE);
   constexpr int SMEM_WORDS = SMEM_IMAGE > 4 * 32 * 36 ? SMEM_IMAGE : 4 * 32 * 36;
+  static_assert(!(F16 && CSUM) || (BK / 4) * BM <= SMEM_WORDS, "column-sum scratch of the fp16-operand TN form");
   __shared__ __attribute__((aligned(16))) float smem[SMEM_WORDS];
   float* As = smem;                // [2][BK][LDA_S]
   uint32_t* Aw = reinterpret_cast<uint32_t*>(smem);  // [2][BK/8][LDA16][4 dwords], then B
@@ -731,8 +732,10 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     const uint32_t* a_w = Aw + buf * A_ST16 + (wm0 + l31) * 4;
     const uint32_t* b_w = Bw + buf * B_ST16 + (wn0 + l31) * 4;
+#ifndef SM3_ABL_NOLOAD  // ablation builds (sm3det_amd/build.py VARIANTS): measurement aids, never the default library
 #pragma unroll
     for (int q = 0; q < NP; q++) load_piece(na, nb, q, kt_load, tail);
+#endif
     // fragments of sub-step ks + 1 are requested before the MFMAs of sub-step ks (one LDS round trip per step instead of
     // one per sub-step); the LDS writes of tile kt + 1 go out after the first sub-step's reads
     constexpr int KS = BK / 16;
@@ -749,15 +752,24 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
 #pragma unroll
     for (int ks = 0; ks < KS; ks++) {
       if (ks + 1 < KS) frag(ks + 1, a[(ks + 1) & 1], b[(ks + 1) & 1]);
+#ifndef SM3_ABL_NOSTORE
       if (ks == 0) {
 #pragma unroll
         for (int q = 0; q < NP; q++) store_piece(ca, cb, q, buf ^ 1, live);
       }
+#endif
+#ifdef SM3_ABL_NOMFMA
+#pragma unroll
+      for (int i = 0; i < TI; i++) asm volatile("" ::"v"(a[ks & 1][i]));
+#pragma unroll
+      for (int j = 0; j < TJ; j++) asm volatile("" ::"v"(b[ks & 1][j]));
+#else
 #pragma unroll
       for (int i = 0; i < TI; i++)
 #pragma unroll
         for (int j = 0; j < TJ; j++)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[ks & 1][j], a[ks & 1][i], acc[i][j], 0, 0, 0);
+#endif
     }
     __syncthreads();
   };
@@ -785,7 +797,22 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
     }
   }
 
-  if (CSUM && do_cs) {  // fold the k rows of the tile through LDS (free after the loop)
+  if (CSUM && do_cs && F16) {  // an F16 piece = four k of ONE column (unit idx = k-quad * BM + column): [BK / 4][BM]
+    float* red = smem;
+#pragma unroll
+    for (int i = 0; i < PA; i++) {
+      const int idx = tid + NTHREADS * i;
+      if (idx < (BK / 4) * BM) red[idx] = (csa[i][0] + csa[i][1]) + (csa[i][2] + csa[i][3]);
+    }
+    __syncthreads();
+    if (tid < BM && m0 + tid < p.M) {
+      float t = 0.f;
+#pragma unroll
+      for (int g4 = 0; g4 < BK / 4; g4++) t += red[g4 * BM + tid];
+      p.csum[(long)blockIdx.z * p.csum_stride + m0 + tid] = t;
+    }
+    __syncthreads();  // the epilogue stages through the same memory
+  } else if (CSUM && do_cs) {  // fold the k rows of the tile through LDS (free after the loop)
     constexpr int QRc = BM / 4;
     float* red = smem;  // [BK][BM + 4]
 #pragma unroll
@@ -803,6 +830,19 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
     __syncthreads();  // the epilogue stages through the same memory
   }
 
+#ifdef SM3_ABL_NOEPI
+  if (F16) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < TI; i++)
+#pragma unroll
+      for (int j = 0; j < TJ; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) t += acc[i][j][r];
+    if (t == 12345.678f) p.C[tid] = t;
+    return;
+  }
+#endif
   // ---- split-K fix-up: publish this slice, the last arriver of the tile sums all slices in order ------------
   if (p.splits > 1 && p.fixup) {
     constexpr int NF = TI * TJ * 4;  // float4 fragments per thread

@@ -47,12 +47,22 @@ int launch_nn_h16(const GemmParams& p, int epi, int tile, int bk, int io, dim3 g
   return SM3_ERR_UNSUPPORTED;
 }
 
+template <class TL, int IO>
+static void goh_tn(const GemmParams& p, int bk, dim3 grid, hipStream_t st) {
+  if (IO & IO_A16 || !p.csum) return goh<MODE_TN, EPI_NONE, TL, IO>(p, bk, grid, st);
+  // + column sums of the fp32 A operand (dy): the FC2 / gate bias gradient as a by-product
+  constexpr int IOC = IO & ~IO_A16;
+  if (bk == 16) gemm_f32_kernel<MODE_TN, EPI_NONE, 16, TL, 0, 1, 1, IOC><<<grid, NTHREADS, 0, st>>>(p);
+  else if (bk == 32) gemm_f32_kernel<MODE_TN, EPI_NONE, 32, TL, 0, 1, 1, IOC><<<grid, NTHREADS, 0, st>>>(p);
+  else gemm_f32_kernel<MODE_TN, EPI_NONE, 64, TL, 0, 1, 1, IOC><<<grid, NTHREADS, 0, st>>>(p);
+}
+
 template <int IO>
 static int tn_by_tile_h(const GemmParams& p, int tile, int bk, dim3 grid, hipStream_t st) {
   switch (tile) {
-    case 0: goh<MODE_TN, EPI_NONE, T128x128, IO>(p, bk, grid, st); return SM3_OK;
-    case 1: goh<MODE_TN, EPI_NONE, T128x96, IO>(p, bk, grid, st); return SM3_OK;
-    case 2: goh<MODE_TN, EPI_NONE, T96x128, IO>(p, bk, grid, st); return SM3_OK;
+    case 0: goh_tn<T128x128, IO>(p, bk, grid, st); return SM3_OK;
+    case 1: goh_tn<T128x96, IO>(p, bk, grid, st); return SM3_OK;
+    case 2: goh_tn<T96x128, IO>(p, bk, grid, st); return SM3_OK;
   }
   return SM3_ERR_INVALID_ARG;
 }

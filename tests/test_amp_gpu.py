@@ -134,6 +134,21 @@ def test_gemm_fp16_storage_tn(M, N, K):
         C = torch.full((M, N), float('nan'), device='cuda')
         LB.gemm(LB.TN, A16, B16, C, M, N, K)
         assert rel_err(C, A16.double().t() @ B16.double()) < 3e-5
+        # bias gradient as a by-product: the column sums of the fp32 A operand (exact fp32 values, not the fp16-rounded
+        # ones the product uses), with an fp16-stored and with an fp32 B operand; k-steps 32 and 64, every TN tile
+        for B in (B16, B16.float()):
+            for tune in (0, (2 << 4) | 1, (3 << 4) | 2, (3 << 4) | 3, (1 << 4) | 1):
+                C = torch.full((M, N), float('nan'), device='cuda')
+                cs = torch.full((M,), float('nan'), device='cuda')
+                LB.TUNING = tune
+                try:
+                    LB.gemm(LB.TN, A32, B, C, M, N, K, colsum_out=cs)
+                finally:
+                    LB.TUNING = 0
+                assert rel_err(C, A32.half().double().t() @ B.half().double()) < 3e-5, tune
+                assert rel_err(cs, A32.double().sum(0)) < 1e-5, tune
+        with pytest.raises(Exception):  # an fp16-STORED A has no fp32 values to add: refused, never silently wrong
+            LB.gemm(LB.TN, A16, B16, C, M, N, K, colsum_out=cs)
 
 
 def test_gemm_fp16_storage_grouped_experts():
