@@ -786,13 +786,23 @@ def main():
     from sm3det_amd import backbone_ops as _bops
     overlap_was = _bops.OVERLAP_WGRAD
     _bops.OVERLAP_WGRAD = False
-    if rank == 0:
-        LB.PROFILE = []
-    step()
-    torch.cuda.synchronize()
+    # Three such steps, the one with the smallest summed bracket time is reported: a bracket also holds the host's launch
+    # latency whenever the stream runs dry between e0 and the kernel, which a busy host inflates (observed once: 113 us
+    # per GEMM launch instead of 103, with an unchanged 19.95 ms graph-replayed step).
+    prof = None
+    for _ in range(3):
+        if rank == 0:
+            LB.PROFILE = []
+        step()
+        torch.cuda.synchronize()
+        if rank == 0:
+            cand, LB.PROFILE = LB.PROFILE, None
+            tot = sum(e0.elapsed_time(e1) for _n, _f, _b, e0, e1 in cand)
+            if prof is None or tot < prof[0]:
+                prof = (tot, cand)
     _bops.OVERLAP_WGRAD = overlap_was
     if rank == 0:
-        prof, LB.PROFILE = LB.PROFILE, None
+        prof = prof[1]
         for name, flops, nbytes, e0, e1 in prof:
             k = kernels.setdefault(name, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
             k['launches'] += 1

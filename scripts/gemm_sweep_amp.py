@@ -19,6 +19,7 @@ import numpy as np  # noqa: E402
 BK = {None: 0, 16: 1, 32: 2, 64: 3}
 # --cold: six rotating argument sets per shape, so that no launch finds its operands in the 256 MB MALL / the L2s
 ROT = 6 if '--cold' in sys.argv else 1
+FP32 = '--fp32' in sys.argv  # the same sweep over the fp32 GEMM family (all tensors fp32, no autocast)
 
 
 def tune(tile=None, bk=None, splits=0):
@@ -29,11 +30,13 @@ def candidates(mode):
     out = [dict()]
     if '--default-only' in sys.argv:
         return out
-    tiles = (0, 1, 2) if mode == 'tn' else (0, 1, 5)
-    for bk in (32, 64, 16):
+    tiles = ((0, 1, 2, 3, 4) if FP32 else (0, 1, 2)) if mode == 'tn' else ((0, 1, 3, 5) if FP32 else (0, 1, 5))
+    for bk in ((32, 16) if FP32 else (32, 64, 16)):
         out.append(dict(bk=bk))
     for t in tiles:
-        for bk in (32, 64):
+        for bk in ((16, 32) if FP32 else (32, 64)):
+            if FP32 and t in (3, 4) and bk == 32:
+                continue
             out.append(dict(tile=t, bk=bk))
             if '--splits' in sys.argv:
                 for sp in ((2, 3, 4, 6, 8) if mode != 'tn' else (1, 2, 4, 8, 16, 32, 64)):
@@ -43,9 +46,10 @@ def candidates(mode):
 
 def main():
     dev = torch.device('cuda')
-    h = torch.float16
+    h = torch.float32 if FP32 else torch.float16
     tot_def = tot_best = 0.0
-    with amp.autocast():
+    import contextlib
+    with (contextlib.nullcontext() if FP32 else amp.autocast()):
         for mode, M, N, K, G, epi, cnt in SHAPES:
             rows = K if mode == 'tn' else M
             offs = None
