@@ -125,3 +125,62 @@ def test_roi_align_rotated_vs_ref(aligned, clockwise, ratio):
     g = O.roi_align_rotated_backward(go, rois, x.shape, 7, 7, 0.25, ratio, aligned, clockwise)
     # the reference accumulates in (n,c,ph,pw) index order, and so does the oracle: bit-exact
     assert np.array_equal(g, gin.numpy()), np.abs(g - gin.numpy()).max()
+
+
+@pytest.mark.parametrize('seed', [7, 8, 9])
+def test_circumscribed_circle_pretest_is_conservative(seed):
+    """The GPU kernels skip the polygon clipping for pairs whose circumscribed circles are apart AND whose boxes are not
+    thin (ops_rotated.hip `may_intersect`) and write IoU = +0.0 for them.  Property pinned here against the oracle
+    (bit-exact with the compiled reference): every pair the pre-test rejects -- evaluated in fp32 exactly as the kernel
+    does -- has IoU == 0.0 in the reference arithmetic, on random, near-touching, far-away and thin / degenerate boxes.
+    (Thin boxes matter: below ~1e-7 of the coordinates an edge vector collapses to zero in fp32 and the reference reports
+    IoU = 1 / inf / negative for boxes that are far apart; the shortcut must leave those to the full computation.)"""
+    f = np.float32
+    rng = np.random.default_rng(seed)
+    n = 150000
+    b1 = np.stack([rng.uniform(0, 512, n), rng.uniform(0, 512, n), rng.uniform(0.5, 160, n), rng.uniform(0.5, 160, n),
+                   rng.uniform(-np.pi, np.pi, n)], 1).astype(f)
+    b2 = b1.copy()
+    b2[:, 2:4] = rng.uniform(0.5, 160, (n, 2)).astype(f)
+    b2[:, 4] = rng.uniform(-np.pi, np.pi, n).astype(f)
+    # a third of the pairs get one thin side, log-uniform from 1e-10 to 1 (the collapse happens around 1e-5 here)
+    thin = rng.random(n) < 0.33
+    side = rng.integers(0, 2, n)
+    which = rng.integers(0, 2, n)
+    t = (10.0 ** rng.uniform(-10, 0, n)).astype(f)
+    for bx, sel in ((b1, thin & (which == 0)), (b2, thin & (which == 1))):
+        bx[sel & (side == 0), 2] = t[sel & (side == 0)]
+        bx[sel & (side == 1), 3] = t[sel & (side == 1)]
+    b2[:300, 2] = 0
+    b1[300:600, 3] = 0
+    # second box at a distance around the sum of the circumscribed radii (the interesting band), any direction
+    r1 = 0.5 * np.sqrt(b1[:, 2].astype(np.float64) ** 2 + b1[:, 3].astype(np.float64) ** 2)
+    r2 = 0.5 * np.sqrt(b2[:, 2].astype(np.float64) ** 2 + b2[:, 3].astype(np.float64) ** 2)
+    dist = (r1 + r2) * rng.choice([0.2, 0.9, 0.99, 1.0, 1.004, 1.006, 1.02, 1.5, 4.0, 20.0], n)
+    ang = rng.uniform(0, 2 * np.pi, n)
+    b2[:, 0] = (b1[:, 0] + dist * np.cos(ang)).astype(f)
+    b2[:, 1] = (b1[:, 1] + dist * np.sin(ang)).astype(f)
+    far = slice(n - 4000, n)  # far-away coordinates: cancellation in the centre shift
+    b1[far, :2] += f(3e5)
+    b2[far, :2] += f(3e5)
+
+    def pretest(a, b):  # ops_rotated.hip: circum_radius / min_extent / may_intersect, fp32, same operation order
+        ra = f(0.5) * np.sqrt(a[:, 2] * a[:, 2] + a[:, 3] * a[:, 3], dtype=f)
+        rb = f(0.5) * np.sqrt(b[:, 2] * b[:, 2] + b[:, 3] * b[:, 3], dtype=f)
+        ea, eb = np.minimum(np.abs(a[:, 2]), np.abs(a[:, 3])), np.minimum(np.abs(b[:, 2]), np.abs(b[:, 3]))
+        dx, dy, rs = a[:, 0] - b[:, 0], a[:, 1] - b[:, 1], ra + rb
+        apart = dx * dx + dy * dy > rs * rs * f(1.01) + f(1e-12)
+        solid = np.minimum(ea, eb) >= f(1e-3) * (np.abs(dx) + np.abs(dy) + rs)
+        return ~(apart & solid)
+
+    keep = pretest(b1, b2)
+    iou = O.box_iou_rotated(b1, b2, 0, True)
+    assert 0.2 < keep.mean() < 0.9  # both outcomes well represented
+    assert (iou[~keep] == 0.0).all(), (np.abs(iou[~keep]).max(), int((iou[~keep] != 0).sum()))
+    assert (iou[keep] > 0).any()
+    # the reference does report intersections for far-apart thin boxes: the reason for the `solid` clause
+    ra = 0.5 * np.sqrt(b1[:, 2] ** 2 + b1[:, 3] ** 2) + 0.5 * np.sqrt(b2[:, 2] ** 2 + b2[:, 3] ** 2)
+    apart = (b1[:, 0] - b2[:, 0]) ** 2 + (b1[:, 1] - b2[:, 1]) ** 2 > 1.02 * ra ** 2
+    assert (iou[apart] != 0).any()
+    iof = O.box_iou_rotated(b1, b2, 1, True)
+    assert (iof[~keep] == 0.0).all()
