@@ -245,34 +245,42 @@ __device__ __forceinline__ bool may_intersect(float x1, float y1, float r1, floa
   return !(apart && solid);
 }
 
-// One wave owns IOU_CHUNK consecutive pairs: 16 rounds of 64 cheap pre-tests write the zeros directly and collect the
-// surviving pairs in an LDS list; the list is then clipped 64 pairs at a time with all lanes busy.  On spread-out boxes
-// (2000 x 512 uniform in 1024^2: 3 % of the pairs survive) that is one clipping pass per wave instead of sixteen.
-constexpr int IOU_ROUNDS = 16, IOU_CHUNK = 64 * IOU_ROUNDS;
+// One wave owns 64 * ROUNDS consecutive pairs: ROUNDS rounds of 64 cheap pre-tests (unrolled: the box loads of all rounds
+// are in flight together) write the zeros directly and collect the surviving pairs in an LDS list; the list is then
+// clipped 64 pairs at a time with all lanes busy.  On spread-out boxes (2000 x 512 uniform in 1024^2: 3 % of the pairs
+// survive) that is one clipping pass per 64 * ROUNDS pairs instead of ROUNDS.  ROUNDS is chosen on the host so that
+// small problems still spread over the chip (1 round = the plain one-pair-per-lane form with the zero shortcut).
+template <int ROUNDS>
 __global__ __launch_bounds__(256) void box_iou_rotated_kernel(const float* __restrict__ boxes1,
                                                               const float* __restrict__ boxes2,
                                                               float* __restrict__ ious, int n1, int n2,
                                                               int mode_flag, int aligned) {
-  __shared__ unsigned short cand[4][IOU_CHUNK];
+  constexpr int CHUNK = 64 * ROUNDS;
+  __shared__ unsigned short cand[4][CHUNK];
   const long total = aligned ? (long)n1 : (long)n1 * n2;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const long nchunks = (total + IOU_CHUNK - 1) / IOU_CHUNK;
+  const long nchunks = (total + CHUNK - 1) / CHUNK;
   for (long ch = (long)blockIdx.x * 4 + wv; ch < nchunks; ch += (long)gridDim.x * 4) {
-    const long base = ch * IOU_CHUNK;
-    int cnt = 0;
-    for (int r = 0; r < IOU_ROUNDS; r++) {
+    const long base = ch * CHUNK;
+    bool ok[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; r++) {
       const long idx = base + r * 64 + lane;
-      bool ok = idx < total;
-      if (ok) {
+      ok[r] = idx < total;
+      if (ok[r]) {
         const long i = aligned ? idx : idx / n2;
         const long j = aligned ? idx : idx - i * n2;
         const float* a = boxes1 + 5 * i;
         const float* b = boxes2 + 5 * j;
-        ok = may_intersect(a[0], a[1], circum_radius(a), min_extent(a), b[0], b[1], circum_radius(b), min_extent(b));
-        if (!ok) ious[idx] = 0.f;
+        ok[r] = may_intersect(a[0], a[1], circum_radius(a), min_extent(a), b[0], b[1], circum_radius(b), min_extent(b));
+        if (!ok[r]) ious[idx] = 0.f;
       }
-      const unsigned long long bal = __ballot(ok);
-      if (ok) cand[wv][cnt + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)(r * 64 + lane);
+    }
+    int cnt = 0;
+#pragma unroll
+    for (int r = 0; r < ROUNDS; r++) {
+      const unsigned long long bal = __ballot(ok[r]);
+      if (ok[r]) cand[wv][cnt + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)(r * 64 + lane);
       cnt += __popcll(bal);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the list is read by other lanes of this wave
@@ -555,21 +563,23 @@ __global__ __launch_bounds__(SWEEP_THREADS) void nms_sweep_kernel(const uint64_t
 // on which boxes survive, only their USE does -- so a step costs the 64-box serial scan plus one LDS phase.
 // Columns past 16 * PREF = 256 of a block row (N > 16 448) are read after the barrier as before.  Needs nblk * 8 bytes
 // of LDS.
-constexpr int SWEEP_PREF = 16;
+constexpr int SWEEP_PREF = 10;  // words per thread and block row held in registers: rows of up to 160 column blocks (N <= 10 304)
 __global__ __launch_bounds__(SWEEP_THREADS) void nms_sweep_lds_kernel(const uint64_t* __restrict__ mask,
                                                                      const int64_t* __restrict__ order, int n,
                                                                      int nblk, int64_t* __restrict__ keep,
                                                                      int32_t* __restrict__ num_keep) {
-  extern __shared__ __attribute__((aligned(16))) uint64_t remv[];  // [nblk]
+  extern __shared__ __attribute__((aligned(16))) uint64_t remv[];  // [nblk + 3]: the loop runs whole triples of steps
   __shared__ uint64_t s_kept;
   __shared__ int s_count;
   const int tid = threadIdx.x;
-  for (int c = tid; c < nblk; c += SWEEP_THREADS) remv[c] = 0;
+  for (int c = tid; c < nblk + 3; c += SWEEP_THREADS) remv[c] = 0;
   if (tid == 0) s_count = 0;
   // thread -> (row b of the block, column lane cl): columns cl, cl + 16, ... of row b (16 threads read 128 contiguous bytes;
   // no index division -- a flat index / ncols per word cost ~1300 VALU instructions per thread and step, which with
   // 4 waves per SIMD WAS the step time after the memory round trips were gone: 3.9 us)
   const int rb_ = tid >> 4, cl = tid & 15;
+  // block row `blk` of the mask (right of the diagonal), its diagonal word and the boxes' original indices.  Everything is
+  // predicated per lane, nothing branches: blocks past the end load nothing and decide nothing.
   auto fetch = [&](int blk, uint64_t (&w)[SWEEP_PREF], uint64_t& diag, int64_t& ord) {
     const int ncols = nblk - (blk + 1);
     const uint64_t* mrow = mask + ((size_t)blk * 64 + rb_) * nblk + (blk + 1);
@@ -586,12 +596,12 @@ __global__ __launch_bounds__(SWEEP_THREADS) void nms_sweep_lds_kernel(const uint
       ord = order[blk * 64 + tid];  // the kept boxes' original indices: loaded ahead, not inside the serial step
     }
   };
-  uint64_t cur[SWEEP_PREF], nxt[SWEEP_PREF], dcur, dnxt = 0;
-  int64_t ocur, onxt = 0;
-  fetch(0, cur, dcur, ocur);
-  __syncthreads();
-  for (int blk = 0; blk < nblk; blk++) {
-    if (blk + 1 < nblk) fetch(blk + 1, nxt, dnxt, onxt);  // in flight during the serial scan below
+  // One step decides one 64-box block.  Its data was requested TWO steps earlier (three rotating register sets).
+  auto step = [&](int blk, const uint64_t (&cur)[SWEEP_PREF], uint64_t dcur, int64_t ocur, uint64_t (&pw)[SWEEP_PREF],
+                  uint64_t& pd, int64_t& po) {
+    // refill the set the PREVIOUS step consumed with the block two steps on: the requests go out while wave 0 runs the
+    // serial scan below (the other 15 waves would only wait at the barrier)
+    fetch(blk + 2, pw, pd, po);
     if (tid < 64) {
       const int lane = tid;
       // The 64-step dependency chain (box b survives unless an earlier survivor of this block suppresses it) runs on the
@@ -602,18 +612,22 @@ __global__ __launch_bounds__(SWEEP_THREADS) void nms_sweep_lds_kernel(const uint
       // (the builtins return int: without the uint32_t casts a set bit 31 of the low word sign-extends into the high one)
       uint64_t removed = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(r0 >> 32)) << 32) |
                          (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)r0);
-      const int nvalid = min(64, n - blk * 64);
+      const int nvalid = min(64, n - blk * 64);  // <= 0 for the padding steps past the last block
+      const uint64_t valid = nvalid >= 64 ? ~0ull : (nvalid > 0 ? (1ull << nvalid) - 1ull : 0ull);
       const uint32_t dlo = (uint32_t)dcur, dhi = (uint32_t)(dcur >> 32);
-      uint64_t kept = 0;
+      // Boxes beyond the end count as removed, so the loop body is three scalar operations on the chain (bit test, select,
+      // or) plus the two lane reads: a single wave issues one instruction per four cycles, and the 13 instructions per
+      // box this loop had before WERE the step (2.9 us per 64-box block whatever the row length).  Row b of the diagonal
+      // block only carries bits above b, so bit b of `removed` is final once box b - 1 is decided: the survivors are
+      // read off the final word.
+      removed |= ~valid;
 #pragma unroll
       for (int b = 0; b < 64; b++) {
         const uint64_t wb = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(dhi, b) << 32) |
                             (uint64_t)(uint32_t)__builtin_amdgcn_readlane(dlo, b);
-        if (b < nvalid && !((removed >> b) & 1ull)) {
-          kept |= (1ull << b);
-          removed |= wb;
-        }
+        removed |= ((removed >> b) & 1ull) ? 0ull : wb;
       }
+      const uint64_t kept = ~removed & valid;
       const int base = s_count;
       if ((kept >> lane) & 1ull) {
         const int pos = __popcll(kept & ((1ull << lane) - 1ull));
@@ -631,7 +645,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void nms_sweep_lds_kernel(const uint
 #pragma unroll
       for (int j = 0; j < SWEEP_PREF; j++)
         if (cur[j] != 0) atomicOr((unsigned long long*)(remv + blk + 1 + cl + 16 * j), (unsigned long long)cur[j]);
-      if (ncols > 16 * SWEEP_PREF && blk * 64 + rb_ < n) {  // very long rows (N > 16 448): the part that was not prefetched
+      if (ncols > 16 * SWEEP_PREF && blk * 64 + rb_ < n) {  // longer rows: the part that was not prefetched
         const uint64_t* mrow = mask + ((size_t)blk * 64 + rb_) * nblk + (blk + 1);
         for (int c = cl + 16 * SWEEP_PREF; c < ncols; c += 16) {
           const uint64_t w = mrow[c];
@@ -640,10 +654,16 @@ __global__ __launch_bounds__(SWEEP_THREADS) void nms_sweep_lds_kernel(const uint
       }
     }
     __syncthreads();
-#pragma unroll
-    for (int j = 0; j < SWEEP_PREF; j++) cur[j] = nxt[j];
-    dcur = dnxt;
-    ocur = onxt;
+  };
+  uint64_t w0[SWEEP_PREF], w1[SWEEP_PREF], w2[SWEEP_PREF], d0, d1, d2 = 0;
+  int64_t o0, o1, o2 = 0;
+  fetch(0, w0, d0, o0);
+  fetch(1, w1, d1, o1);
+  __syncthreads();
+  for (int blk = 0; blk < nblk; blk += 3) {  // three steps per iteration, no branch between them (see fetch)
+    step(blk, w0, d0, o0, w2, d2, o2);
+    step(blk + 1, w1, d1, o1, w0, d0, o0);
+    step(blk + 2, w2, d2, o2, w1, d1, o1);
   }
   if (tid == 0) *num_keep = s_count;
 }
@@ -1052,10 +1072,14 @@ int sm3_box_iou_rotated(const float* boxes1, const float* boxes2, float* ious, i
   const long total = aligned ? (long)n1 : (long)n1 * n2;
   if (total == 0) return SM3_OK;
   if (!boxes1 || !boxes2 || !ious) return SM3_ERR_INVALID_ARG;
-  long blocks = ((total + IOU_CHUNK - 1) / IOU_CHUNK + 3) / 4;  // four waves per workgroup, one chunk of pairs per wave
+  // pairs per wave: enough waves to cover the 1024 SIMDs a few times over before the chunks grow
+  const int rounds = total >= 64l * 16 * 4096 ? 16 : (total >= 64l * 4 * 2048 ? 4 : 1);
+  long blocks = ((total + 64 * rounds - 1) / (64 * rounds) + 3) / 4;  // four waves per workgroup, one chunk per wave
   if (blocks > 256 * 32) blocks = 256 * 32;
-  box_iou_rotated_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(boxes1, boxes2, ious, n1, n2, mode_flag,
-                                                                     aligned);
+  hipStream_t st = (hipStream_t)stream;
+  if (rounds == 16) box_iou_rotated_kernel<16><<<(int)blocks, 256, 0, st>>>(boxes1, boxes2, ious, n1, n2, mode_flag, aligned);
+  else if (rounds == 4) box_iou_rotated_kernel<4><<<(int)blocks, 256, 0, st>>>(boxes1, boxes2, ious, n1, n2, mode_flag, aligned);
+  else box_iou_rotated_kernel<1><<<(int)blocks, 256, 0, st>>>(boxes1, boxes2, ious, n1, n2, mode_flag, aligned);
   return launch_status();
 }
 
@@ -1105,7 +1129,7 @@ static int nms_common(bool rotated, const float* boxes, int stride, const float*
   else
     nms_mask_kernel<<<(int)ntiles, 64, 0, st>>>(boxes, order, n, nblk, thr, (float)offset, mask);
   if ((size_t)nblk * 8 <= 96 * 1024)  // removal vector in LDS, next block row prefetched (N <= 786 432)
-    nms_sweep_lds_kernel<<<1, SWEEP_THREADS, (size_t)nblk * 8, st>>>(mask, order, n, nblk, keep, num_keep);
+    nms_sweep_lds_kernel<<<1, SWEEP_THREADS, (size_t)(nblk + 3) * 8, st>>>(mask, order, n, nblk, keep, num_keep);
   else
     nms_sweep_kernel<<<1, SWEEP_THREADS, 0, st>>>(mask, order, n, nblk, (uint64_t*)(w + o_remv), keep, num_keep);
   return launch_status();
