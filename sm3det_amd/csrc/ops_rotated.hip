@@ -403,7 +403,8 @@ __device__ __forceinline__ void tri_decode(int t, int nblk, int& rb, int& cb) {
 __global__ __launch_bounds__(256) void nms_rotated_mask_kernel(const float* __restrict__ dets, int stride,
                                                               const int64_t* __restrict__ order, int n,
                                                               int nblk, float thr, int multi_label,
-                                                              uint64_t* __restrict__ mask) {
+                                                              uint64_t* __restrict__ mask,
+                                                              uint64_t* __restrict__ diagt) {
   int rb, cb;
   tri_decode(blockIdx.x, nblk, rb, cb);
   // per box: x, y, w, h, angle, label, circumscribed radius, smallest extent
@@ -455,11 +456,18 @@ __global__ __launch_bounds__(256) void nms_rotated_mask_kernel(const float* __re
   }
   __syncthreads();
   if (wv == 0 && ri < n) mask[(size_t)ri * nblk + cb] = rowword[lane];
+  if (wv == 1 && rb == cb) {  // the diagonal tile transposed, for the sweep's parallel intra-block resolution
+    uint64_t t = 0;
+#pragma unroll 8
+    for (int r = 0; r < 64; r++) t |= ((rowword[r] >> lane) & 1ull) << r;
+    diagt[(size_t)rb * 64 + lane] = t;
+  }
 }
 
 __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ boxes,
                                                      const int64_t* __restrict__ order, int n, int nblk,
-                                                     float thr, float offset, uint64_t* __restrict__ mask) {
+                                                     float thr, float offset, uint64_t* __restrict__ mask,
+                                                     uint64_t* __restrict__ diagt) {
   int rb, cb;
   tri_decode(blockIdx.x, nblk, rb, cb);
   __shared__ float cbox[64 * 5];
@@ -476,26 +484,37 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
   }
   __syncthreads();
   const int ri = rb * 64 + lane;
-  if (ri >= n) return;
-  const float* d = boxes + order[ri] * 4;
-  const float ix1 = d[0], iy1 = d[1], ix2 = d[2], iy2 = d[3];
-  const float iarea = (ix2 - ix1 + offset) * (iy2 - iy1 + offset);
-  const int ncol = min(64, n - cb * 64);
   uint64_t word = 0;
-  const int cstart = (rb == cb) ? lane + 1 : 0;
-  for (int c = cstart; c < ncol; c++) {
-    float xx1 = fmaxf(ix1, cbox[c * 5 + 0]);
-    float yy1 = fmaxf(iy1, cbox[c * 5 + 1]);
-    float xx2 = fminf(ix2, cbox[c * 5 + 2]);
-    float yy2 = fminf(iy2, cbox[c * 5 + 3]);
-    float w = fmaxf(0.f, xx2 - xx1 + offset);
-    float h = fmaxf(0.f, yy2 - yy1 + offset);
-    float inter = w * h;
-    float ovr = inter / (iarea + cbox[c * 5 + 4] - inter);  // division form, cpu/nms.cpp:46
-    if (ovr > thr) word |= (1ull << c);
+  if (ri < n) {
+    const float* d = boxes + order[ri] * 4;
+    const float ix1 = d[0], iy1 = d[1], ix2 = d[2], iy2 = d[3];
+    const float iarea = (ix2 - ix1 + offset) * (iy2 - iy1 + offset);
+    const int ncol = min(64, n - cb * 64);
+    const int cstart = (rb == cb) ? lane + 1 : 0;
+    for (int c = cstart; c < ncol; c++) {
+      float xx1 = fmaxf(ix1, cbox[c * 5 + 0]);
+      float yy1 = fmaxf(iy1, cbox[c * 5 + 1]);
+      float xx2 = fminf(ix2, cbox[c * 5 + 2]);
+      float yy2 = fminf(iy2, cbox[c * 5 + 3]);
+      float w = fmaxf(0.f, xx2 - xx1 + offset);
+      float h = fmaxf(0.f, yy2 - yy1 + offset);
+      float inter = w * h;
+      float ovr = inter / (iarea + cbox[c * 5 + 4] - inter);  // division form, cpu/nms.cpp:46
+      if (ovr > thr) word |= (1ull << c);
+    }
+    mask[(size_t)ri * nblk + cb] = word;
   }
-  mask[(size_t)ri * nblk + cb] = word;
+  if (rb == cb) {  // the diagonal tile transposed (all 64 lanes vote), for the sweep's parallel intra-block resolution
+    uint64_t t = 0;
+#pragma unroll 8
+    for (int c = 0; c < 64; c++) {
+      const uint64_t col = __ballot((word >> c) & 1ull);
+      if (lane == c) t = col;
+    }
+    diagt[(size_t)rb * 64 + lane] = t;
+  }
 }
+
 
 constexpr int SWEEP_THREADS = 1024;
 __global__ __launch_bounds__(SWEEP_THREADS) void nms_sweep_kernel(const uint64_t* __restrict__ mask,
@@ -563,112 +582,141 @@ __global__ __launch_bounds__(SWEEP_THREADS) void nms_sweep_kernel(const uint64_t
 // on which boxes survive, only their USE does -- so a step costs the 64-box serial scan plus one LDS phase.
 // Columns past 16 * PREF = 256 of a block row (N > 16 448) are read after the barrier as before.  Needs nblk * 8 bytes
 // of LDS.
-constexpr int SWEEP_PREF = 10;  // words per thread and block row held in registers: rows of up to 160 column blocks (N <= 10 304)
+constexpr int SWEEP_CH = 3;  // 64-column chunks per row held in registers: rows of up to 192 column blocks (N <= 12 352)
 __global__ __launch_bounds__(SWEEP_THREADS) void nms_sweep_lds_kernel(const uint64_t* __restrict__ mask,
+                                                                     const uint64_t* __restrict__ diagt,
                                                                      const int64_t* __restrict__ order, int n,
                                                                      int nblk, int64_t* __restrict__ keep,
                                                                      int32_t* __restrict__ num_keep) {
-  extern __shared__ __attribute__((aligned(16))) uint64_t remv[];  // [nblk + 3]: the loop runs whole triples of steps
-  __shared__ uint64_t s_kept;
+  extern __shared__ __attribute__((aligned(16))) uint64_t remv[];  // [nblk + 4]: the loop runs whole triples of steps
+  __shared__ uint64_t s_kept[2];
   __shared__ int s_count;
   const int tid = threadIdx.x;
-  for (int c = tid; c < nblk + 3; c += SWEEP_THREADS) remv[c] = 0;
+  for (int c = tid; c < nblk + 4; c += SWEEP_THREADS) remv[c] = 0;
+  if (tid < 2) s_kept[tid] = 0;
   if (tid == 0) s_count = 0;
-  // thread -> (row b of the block, column lane cl): columns cl, cl + 16, ... of row b (16 threads read 128 contiguous bytes;
-  // no index division -- a flat index / ncols per word cost ~1300 VALU instructions per thread and step, which with
-  // 4 waves per SIMD WAS the step time after the memory round trips were gone: 3.9 us)
-  const int rb_ = tid >> 4, cl = tid & 15;
-  // block row `blk` of the mask (right of the diagonal), its diagonal word and the boxes' original indices.  Everything is
-  // predicated per lane, nothing branches: blocks past the end load nothing and decide nothing.
-  auto fetch = [&](int blk, uint64_t (&w)[SWEEP_PREF], uint64_t& diag, int64_t& ord) {
+  // wave w owns rows 4w .. 4w + 3 of a block, lane = column (64 contiguous words = 512 bytes per row and load).  A thread
+  // ORs its four rows in registers and issues ONE conflict-free LDS update per 64-column chunk: 48 wave-level ds_or_b64 per
+  // block.  (Before: thread = (row, column lane), 160 wave-level updates with 4 lanes per address -- the LDS pipe, not the
+  // scan, set the 2.2 us per block; a flat index / ncols mapping before that cost ~1300 VALU instructions per thread.)
+  const int wv = tid >> 6, lane = tid & 63;
+  // block row `blk` of the mask (right of the diagonal); for wave 0 also the TRANSPOSED diagonal word of box (blk, lane)
+  // (bit b' set <=> box b' of this block suppresses it), the first word right of the diagonal and the box's original index.  Everything is predicated per lane, nothing branches: blocks past the end load
+  // nothing and decide nothing.
+  auto fetch = [&](int blk, uint64_t (&w)[4][SWEEP_CH], uint64_t& diag, uint64_t& diag1, int64_t& ord) {
     const int ncols = nblk - (blk + 1);
-    const uint64_t* mrow = mask + ((size_t)blk * 64 + rb_) * nblk + (blk + 1);
-    const bool row_ok = blk * 64 + rb_ < n;
 #pragma unroll
-    for (int j = 0; j < SWEEP_PREF; j++) {
-      const int c = cl + 16 * j;
-      w[j] = (row_ok && c < ncols) ? mrow[c] : 0ull;
+    for (int r = 0; r < 4; r++) {
+      const int row = blk * 64 + 4 * wv + r;
+      const uint64_t* mrow = mask + (size_t)row * nblk + (blk + 1);
+#pragma unroll
+      for (int j = 0; j < SWEEP_CH; j++) {
+        const int c = lane + 64 * j;
+        w[r][j] = (row < n && c < ncols) ? mrow[c] : 0ull;
+      }
     }
     diag = 0;
+    diag1 = 0;
     ord = 0;
     if (tid < 64 && blk * 64 + tid < n) {
-      diag = mask[(size_t)(blk * 64 + tid) * nblk + blk];
+      diag = diagt[(size_t)blk * 64 + tid];
+      if (ncols > 0) diag1 = mask[(size_t)(blk * 64 + tid) * nblk + blk + 1];
       ord = order[blk * 64 + tid];  // the kept boxes' original indices: loaded ahead, not inside the serial step
     }
   };
-  // One step decides one 64-box block.  Its data was requested TWO steps earlier (three rotating register sets).
-  auto step = [&](int blk, const uint64_t (&cur)[SWEEP_PREF], uint64_t dcur, int64_t ocur, uint64_t (&pw)[SWEEP_PREF],
-                  uint64_t& pd, int64_t& po) {
-    // refill the set the PREVIOUS step consumed with the block two steps on: the requests go out while wave 0 runs the
-    // serial scan below (the other 15 waves would only wait at the barrier)
-    fetch(blk + 2, pw, pd, po);
+  // Step `blk`, ONE barrier:
+  //   * wave 0 decides the 64 boxes of block blk (the serial scan) and ORs the first word right of the diagonal of every
+  //     survivor into remv[blk + 1] itself, so that the next scan does not depend on anybody else;
+  //   * meanwhile all 16 waves OR the rows of the survivors of block blk - 1 (decided in the previous step, `s_kept`
+  //     double-buffered) into remv[blk ..]: OR is idempotent, so re-applying the word wave 0 already added is harmless, and
+  //     remv[c] is complete for blocks <= c - 2 at the barrier before step c, which is all the scan of block c needs on
+  //     top of wave 0's own contribution for block c - 1.
+  auto step = [&](int blk, uint64_t dcur, uint64_t d1cur, int64_t ocur, uint64_t (&pw)[4][SWEEP_CH], uint64_t& pd,
+                  uint64_t& pd1, int64_t& po) {
+    // `pw` holds the rows of block blk - 1 (blk = 0: nothing, s_kept is 0)
+    const uint64_t kprev = s_kept[(blk + 1) & 1];
+    const unsigned k4 = (unsigned)(kprev >> (4 * wv)) & 15u;  // this wave's four rows
+    const int pblk = blk - 1;
+    const int pcols = nblk - blk;  // columns right of the diagonal of block blk - 1
+    if (k4) {
+#pragma unroll
+      for (int j = 0; j < SWEEP_CH; j++) {
+        uint64_t v = 0;
+#pragma unroll
+        for (int r = 0; r < 4; r++) v |= ((k4 >> r) & 1u) ? pw[r][j] : 0ull;
+        if (v != 0) atomicOr((unsigned long long*)(remv + blk + lane + 64 * j), (unsigned long long)v);
+      }
+      if (pcols > 64 * SWEEP_CH) {  // longer rows: the part that was not prefetched
+        for (int c = lane + 64 * SWEEP_CH; c < pcols; c += 64) {
+          uint64_t v = 0;
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int row = pblk * 64 + 4 * wv + r;
+            if (((k4 >> r) & 1u) && row < n) v |= mask[(size_t)row * nblk + blk + c];
+          }
+          if (v != 0) atomicOr((unsigned long long*)(remv + blk + c), (unsigned long long)v);
+        }
+      }
+    }
+    // the set is consumed: refill it with the block two steps on (in flight during the scans of this and the next step)
+    fetch(blk + 2, pw, pd, pd1, po);
     if (tid < 64) {
-      const int lane = tid;
-      // The 64-step dependency chain (box b survives unless an earlier survivor of this block suppresses it) runs on the
-      // SCALAR unit: `removed` / `kept` are wave-uniform, row b of the diagonal block comes out of lane b with
-      // v_readlane (compile-time lane).  A __shfl of a 64-bit value per step is two dependent ds_bpermute round trips
-      // (~150 cycles): 64 of them were 4 us of the 6.4 us a step took.
-      const uint64_t r0 = remv[blk];
+      const uint64_t r0 = remv[blk];  // after this wave's own ORs above and of the previous step: LDS is in order per wave
       // (the builtins return int: without the uint32_t casts a set bit 31 of the low word sign-extends into the high one)
-      uint64_t removed = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(r0 >> 32)) << 32) |
-                         (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)r0);
+      const uint64_t removed = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(r0 >> 32)) << 32) |
+                               (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)r0);
       const int nvalid = min(64, n - blk * 64);  // <= 0 for the padding steps past the last block
       const uint64_t valid = nvalid >= 64 ? ~0ull : (nvalid > 0 ? (1ull << nvalid) - 1ull : 0ull);
-      const uint32_t dlo = (uint32_t)dcur, dhi = (uint32_t)(dcur >> 32);
-      // Boxes beyond the end count as removed, so the loop body is three scalar operations on the chain (bit test, select,
-      // or) plus the two lane reads: a single wave issues one instruction per four cycles, and the 13 instructions per
-      // box this loop had before WERE the step (2.9 us per 64-box block whatever the row length).  Row b of the diagonal
-      // block only carries bits above b, so bit b of `removed` is final once box b - 1 is decided: the survivors are
-      // read off the final word.
-      removed |= ~valid;
-#pragma unroll
-      for (int b = 0; b < 64; b++) {
-        const uint64_t wb = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(dhi, b) << 32) |
-                            (uint64_t)(uint32_t)__builtin_amdgcn_readlane(dlo, b);
-        removed |= ((removed >> b) & 1ull) ? 0ull : wb;
+      // Greedy order inside the block (box b survives unless an earlier SURVIVOR of this block suppresses it) as a parallel
+      // fixed point: K <- { b in S : no b' in K suppresses b }, S = the boxes earlier blocks left alive, starting from
+      // K = S.  Suppression only runs from lower to higher indices, so after t rounds the first t boxes are final
+      // (induction on the index): at most 64 rounds, and a round that changes nothing has reached the unique solution of
+      // the recursion = the sequential result.  A round is one AND, one compare and one ballot over the transposed
+      // diagonal words; the number of rounds is the longest suppression chain + 1 (2-4 on detection boxes).  The
+      // sequential scan this replaces cost 64 x 8 scalar-unit instructions at one issue per ~10 cycles = 2.2 us per block
+      // whatever the data -- it, not the memory traffic, was the sweep.
+      const uint64_t S = valid & ~removed;
+      const bool in_s = (S >> lane) & 1ull;
+      uint64_t kept = S;
+      for (int round = 0; round < 66; round++) {
+        const uint64_t nk = __ballot(in_s && (dcur & kept) == 0ull);
+        if (nk == kept) break;
+        kept = nk;
       }
-      const uint64_t kept = ~removed & valid;
       const int base = s_count;
       if ((kept >> lane) & 1ull) {
         const int pos = __popcll(kept & ((1ull << lane) - 1ull));
         keep[base + pos] = ocur;
+        if (d1cur) atomicOr((unsigned long long*)(remv + blk + 1), (unsigned long long)d1cur);
       }
       if (lane == 0) {
-        s_kept = kept;
+        s_kept[blk & 1] = kept;
         s_count = base + __popcll(kept);
       }
     }
     __syncthreads();
-    const uint64_t kept = s_kept;
-    const int ncols = nblk - (blk + 1);
-    if ((kept >> rb_) & 1ull) {
-#pragma unroll
-      for (int j = 0; j < SWEEP_PREF; j++)
-        if (cur[j] != 0) atomicOr((unsigned long long*)(remv + blk + 1 + cl + 16 * j), (unsigned long long)cur[j]);
-      if (ncols > 16 * SWEEP_PREF && blk * 64 + rb_ < n) {  // longer rows: the part that was not prefetched
-        const uint64_t* mrow = mask + ((size_t)blk * 64 + rb_) * nblk + (blk + 1);
-        for (int c = cl + 16 * SWEEP_PREF; c < ncols; c += 16) {
-          const uint64_t w = mrow[c];
-          if (w) atomicOr((unsigned long long*)(remv + blk + 1 + c), (unsigned long long)w);
-        }
-      }
-    }
-    __syncthreads();
   };
-  uint64_t w0[SWEEP_PREF], w1[SWEEP_PREF], w2[SWEEP_PREF], d0, d1, d2 = 0;
+  // three register sets in rotation: {rows of the block being applied, the block being scanned, the block after it}
+  uint64_t w0[4][SWEEP_CH], w1[4][SWEEP_CH], w2[4][SWEEP_CH], d0, d1, d2 = 0, e0, e1, e2 = 0;
   int64_t o0, o1, o2 = 0;
-  fetch(0, w0, d0, o0);
-  fetch(1, w1, d1, o1);
+#pragma unroll
+  for (int r = 0; r < 4; r++)
+#pragma unroll
+    for (int j = 0; j < SWEEP_CH; j++) w2[r][j] = 0;
+  fetch(0, w0, d0, e0, o0);
+  fetch(1, w1, d1, e1, o1);
   __syncthreads();
-  for (int blk = 0; blk < nblk; blk += 3) {  // three steps per iteration, no branch between them (see fetch)
-    step(blk, w0, d0, o0, w2, d2, o2);
-    step(blk + 1, w1, d1, o1, w0, d0, o0);
-    step(blk + 2, w2, d2, o2, w1, d1, o1);
+  // whole triples of steps, no branch between them (see fetch): the steps past the last block apply and decide nothing
+  for (int blk = 0; blk < nblk; blk += 3) {
+    step(blk, d0, e0, o0, w2, d2, e2, o2);
+    step(blk + 1, d1, e1, o1, w0, d0, e0, o0);
+    step(blk + 2, d2, e2, o2, w1, d1, e1, o1);
   }
   if (tid == 0) *num_keep = s_count;
 }
 
-size_t nms_ws_layout(int n, size_t* off_order, size_t* off_mask, size_t* off_remv, size_t* off_sort) {
+size_t nms_ws_layout(int n, size_t* off_order, size_t* off_mask, size_t* off_remv, size_t* off_sort,
+                     size_t* off_diagt) {
   const int nblk = (n + 63) / 64;
   size_t o = 0;
   *off_order = o;
@@ -679,6 +727,8 @@ size_t nms_ws_layout(int n, size_t* off_order, size_t* off_mask, size_t* off_rem
   o += align_up((size_t)nblk * 8, 256);
   *off_sort = o;
   o += align_up((size_t)next_pow2(n > 0 ? n : 1) * 8, 256);
+  *off_diagt = o;  // the diagonal 64x64 tiles transposed: word (blk, c) = which boxes of block blk suppress its box c
+  o += align_up((size_t)nblk * 64 * 8, 256);
   return o;
 }
 
@@ -1095,8 +1145,8 @@ int sm3_argsort_desc_f32(const float* scores, int n, int64_t* order, void* works
 }
 
 size_t sm3_nms_workspace_bytes(int n) {
-  size_t a, b, c, d;
-  return nms_ws_layout(n > 0 ? n : 1, &a, &b, &c, &d);
+  size_t a, b, c, d, e;
+  return nms_ws_layout(n > 0 ? n : 1, &a, &b, &c, &d, &e);
 }
 size_t sm3_nms_rotated_workspace_bytes(int n) { return sm3_nms_workspace_bytes(n); }
 
@@ -1111,8 +1161,8 @@ static int nms_common(bool rotated, const float* boxes, int stride, const float*
   if (!boxes || !keep || !ws) return SM3_ERR_INVALID_ARG;
   if (rotated && (stride < 5 || (multi_label && stride < 6))) return SM3_ERR_INVALID_ARG;
   if (!rotated && offset != 0 && offset != 1) return SM3_ERR_INVALID_ARG;
-  size_t o_order, o_mask, o_remv, o_sort;
-  size_t need = nms_ws_layout(n, &o_order, &o_mask, &o_remv, &o_sort);
+  size_t o_order, o_mask, o_remv, o_sort, o_diagt;
+  size_t need = nms_ws_layout(n, &o_order, &o_mask, &o_remv, &o_sort, &o_diagt);
   if (ws_bytes < need) return SM3_ERR_WORKSPACE;
   char* w = (char*)ws;
   const int nblk = (n + 63) / 64;
@@ -1123,13 +1173,14 @@ static int nms_common(bool rotated, const float* boxes, int stride, const float*
     order = (const int64_t*)(w + o_order);
   }
   uint64_t* mask = (uint64_t*)(w + o_mask);
+  uint64_t* diagt = (uint64_t*)(w + o_diagt);
   const long ntiles = (long)nblk * (nblk + 1) / 2;
   if (rotated)
-    nms_rotated_mask_kernel<<<(int)ntiles, 256, 0, st>>>(boxes, stride, order, n, nblk, thr, multi_label, mask);
+    nms_rotated_mask_kernel<<<(int)ntiles, 256, 0, st>>>(boxes, stride, order, n, nblk, thr, multi_label, mask, diagt);
   else
-    nms_mask_kernel<<<(int)ntiles, 64, 0, st>>>(boxes, order, n, nblk, thr, (float)offset, mask);
+    nms_mask_kernel<<<(int)ntiles, 64, 0, st>>>(boxes, order, n, nblk, thr, (float)offset, mask, diagt);
   if ((size_t)nblk * 8 <= 96 * 1024)  // removal vector in LDS, next block row prefetched (N <= 786 432)
-    nms_sweep_lds_kernel<<<1, SWEEP_THREADS, (size_t)(nblk + 3) * 8, st>>>(mask, order, n, nblk, keep, num_keep);
+    nms_sweep_lds_kernel<<<1, SWEEP_THREADS, (size_t)(nblk + 4) * 8, st>>>(mask, diagt, order, n, nblk, keep, num_keep);
   else
     nms_sweep_kernel<<<1, SWEEP_THREADS, 0, st>>>(mask, order, n, nblk, (uint64_t*)(w + o_remv), keep, num_keep);
   return launch_status();

@@ -170,6 +170,28 @@ def test_nms_vs_oracle(n, thr, offset, cluster):
     assert np.array_equal(keep.cpu().numpy(), exp), (len(exp), keep.numel())
 
 
+@pytest.mark.parametrize('n,step', [(64, 6.0), (200, 6.0), (1000, 6.5), (130, 2.0)])
+def test_nms_chains_of_dependent_boxes_vs_oracle(n, step):
+    """Longest possible suppression chains: a row of 10-px boxes shifted by `step` px in score order -- box i overlaps
+    i + 1 (and, for the small step, several more) above the threshold, so whether box i survives depends on the fate of
+    every earlier box: the greedy order inside a 64-box block then needs as many rounds of the sweep's parallel fixed
+    point as the chain is long (ops_rotated.hip nms_sweep_lds_kernel), and the chains cross block boundaries."""
+    ops, O = _ops(), _oracle()
+    x = (np.arange(n) * step).astype(np.float32)
+    hb = np.stack([x, np.zeros(n, np.float32), x + 10, np.full(n, 10, np.float32)], 1)
+    s = np.linspace(1.0, 0.1, n).astype(np.float32)  # strictly decreasing: score order = position order
+    _, keep = ops.nms(dev(hb), dev(s), iou_threshold=0.2, offset=0)
+    exp = O.nms(hb, s, 0.2, 0)
+    assert np.array_equal(keep.cpu().numpy(), exp), (len(exp), keep.numel())
+    assert 1 < len(exp) < n
+    rb = np.stack([x + 5, np.full(n, 5, np.float32), np.full(n, 10, np.float32), np.full(n, 10, np.float32),
+                   np.full(n, 0.3, np.float32)], 1)
+    _, keep = ops.nms_rotated(dev(rb), dev(s), 0.2)
+    exp = O.nms_rotated(rb, s, 0.2)
+    assert np.array_equal(keep.cpu().numpy(), exp), (len(exp), keep.numel())
+    assert 1 < len(exp) < n
+
+
 def test_nms_score_threshold_max_num_numpy_and_empty():
     ops, O = _ops(), _oracle()
     b = synth.hboxes(500, 8, cluster=True)
