@@ -147,6 +147,16 @@ def roi_align_rotated_forward(input, rois, output, pooled_height, pooled_width, 
         raise SM3Error('wrong roi size')
     B, C, H, W = input.shape
     with torch.cuda.device(input.device):
+        bins = int(pooled_height) * int(pooled_width)
+        if (layout == 0 and H * W >= 1024 and C >= 32 and B <= 65535 and (H * W + 31) // 32 <= 65535 and
+                n * bins * 4 * max(int(sampling_ratio), 1) ** 2 > B * H * W):
+            # NCHW maps make every bilinear tap of a (bin, channel) lane a separate 4-byte gather from its own plane; on
+            # NHWC memory a tap is one coalesced channel vector (3x faster on the 256x256x256 level).  With enough RoIs to
+            # pay for one pass over the map, gather from an NHWC copy: same taps, same order, same results -- the output
+            # is written in the caller's (n, C, ph, pw) layout either way.
+            nhwc = torch.empty(B, H, W, C, device=input.device, dtype=torch.float32)
+            check(lib().sm3_transpose_f32(ptr(input), ptr(nhwc), B, C, H * W, stream_ptr()), 'transpose_f32')
+            input, layout = nhwc, 1
         check(lib().sm3_roi_align_rotated_forward(ptr(input), ptr(rois), ptr(output), n, B, C, H, W,
                                                   int(pooled_height), int(pooled_width), float(spatial_scale),
                                                   int(sampling_ratio), int(bool(aligned)), int(bool(clockwise)),

@@ -185,7 +185,7 @@ def test_nms_chains_of_dependent_boxes_vs_oracle(n, step):
     assert np.array_equal(keep.cpu().numpy(), exp), (len(exp), keep.numel())
     assert 1 < len(exp) < n
     rb = np.stack([x + 5, np.full(n, 5, np.float32), np.full(n, 10, np.float32), np.full(n, 10, np.float32),
-                   np.full(n, 0.3, np.float32)], 1)
+                   np.full(n, 0.02, np.float32)], 1)
     _, keep = ops.nms_rotated(dev(rb), dev(s), 0.2)
     exp = O.nms_rotated(rb, s, 0.2)
     assert np.array_equal(keep.cpu().numpy(), exp), (len(exp), keep.numel())
