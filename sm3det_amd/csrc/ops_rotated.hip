@@ -1028,8 +1028,10 @@ __global__ __launch_bounds__(256) void max_iou_pass1_kernel(const float* __restr
       bi = i;
     }
     // a non-finite IoU (degenerate box with inf / NaN coordinates) has a bit pattern above every finite float: it must not
-    // become the gt's maximum and switch off its low-quality matching
-    if (ov >= 0.f && ov <= 2.f) atomicMax(gt_max_bits + i, __float_as_uint(ov));
+    // become the gt's maximum and switch off its low-quality matching.  An IoU of 0 cannot raise the zero-initialised
+    // maximum: skipping it removes the same-address atomics of the ~98 % of the anchors that miss a given gt (262 k
+    // anchors x 8 gts on 8 addresses were 0.3 of the 0.39 ms this operator took)
+    if (ov > 0.f && ov <= 2.f) atomicMax(gt_max_bits + i, __float_as_uint(ov));
   }
   max_ov[j] = k > 0 ? best : 0.f;
   argmax[j] = bi;
