@@ -243,6 +243,11 @@ def ops_microbench():
             batches.append((time.perf_counter() - t0) / n * 1e6)
         return sorted(batches)[1]
 
+    # SM3_BENCH_OPS=slice: only the detector slice runs (profiling aid: rocprofv3 then sees the slice's kernels alone)
+    timeit_real = timeit
+    if os.environ.get('SM3_BENCH_OPS') == 'slice':
+        timeit = lambda fn, n=10: 0.0  # noqa: E731
+
     out = {}
     b1, b2 = dev(synth.rotated_boxes(2000, 0)), dev(synth.rotated_boxes(512, 1))
     out['box_iou_rotated_2000x512'] = timeit(lambda: ops.box_iou_rotated(b1, b2))
@@ -427,7 +432,7 @@ def ops_microbench():
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
-        out['detector_slice_eager_train_step_bs2_1024'] = timeit(slice_step, n=3)
+        out['detector_slice_eager_train_step_bs2_1024'] = timeit_real(slice_step, n=3)
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     first = {k: float(v) for k, v in sl_losses.items()}
@@ -444,7 +449,7 @@ def ops_microbench():
         def replay():
             g1.replay()
             g2.replay()
-        out['detector_slice_train_step_bs2_1024'] = timeit(replay, n=5)
+        out['detector_slice_train_step_bs2_1024'] = timeit_real(replay, n=5)
     except Exception as e:  # noqa: BLE001
         print(f'[bench] detector slice: hipGraph capture failed ({type(e).__name__}: {e})', file=sys.stderr)
         out['detector_slice_train_step_bs2_1024'] = out['detector_slice_eager_train_step_bs2_1024']
