@@ -57,6 +57,13 @@ size_t sm3_argsort_desc_workspace_bytes(int n);
 int sm3_argsort_desc_f32(const float* scores, int n, int64_t* order, void* workspace,
                          size_t workspace_bytes, sm3_stream_t stream);
 
+/* The k (<= 2048) best scores in descending order: order[0..min(k,n)) = exactly the first entries sm3_argsort_desc_f32
+ * would produce (ties by lower index), without sorting the rest -- `scores.topk(nms_pre)` of the proposal stage
+ * (mmrotate/models/dense_heads/oriented_rpn_head.py:239-244).  k > 2048: SM3_ERR_UNSUPPORTED (use the argsort). */
+size_t sm3_topk_desc_workspace_bytes(int n);
+int sm3_topk_desc_f32(const float* scores, int n, int k, int64_t* order, void* workspace, size_t workspace_bytes,
+                      sm3_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * nms  -- replaces `nms(boxes, scores, iou_threshold, offset) -> Tensor[int64]`
  *   pybind: pytorch/pybind.cpp:185,634-635; CPU semantics followed: pytorch/cpu/nms.cpp:5-54

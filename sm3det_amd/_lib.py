@@ -38,6 +38,8 @@ def _declare(lib):
         'sm3_max_iou_assign_masked': (I, [P, I, I, P, P, I, I, I, F, F, F, I, P, P, P, P, P, S, P]),
         'sm3_argsort_desc_workspace_bytes': (S, [I]),
         'sm3_argsort_desc_f32': (I, [P, I, P, P, S, P]),
+        'sm3_topk_desc_workspace_bytes': (S, [I]),
+        'sm3_topk_desc_f32': (I, [P, I, I, P, P, S, P]),
         'sm3_nms_workspace_bytes': (S, [I]),
         'sm3_nms': (I, [P, P, P, I, F, I, P, P, P, S, P]),
         'sm3_nms_rotated_workspace_bytes': (S, [I]),

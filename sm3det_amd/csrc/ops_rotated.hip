@@ -373,6 +373,82 @@ int argsort_desc(const float* scores, int n, int64_t* order, void* ws, size_t ws
   return SM3_OK;
 }
 
+// ---------------------------------------------------------------- top-k (k <= 2048) without the full sort
+// The proposal stage keeps the nms_pre = 2000 best of up to 196 608 anchor scores per level (oriented_rpn_head.py:239-244
+// `scores.topk(nms_pre)`).  A full bitonic sort of 2^18 keys is 29 launches; here every 4096-key chunk is sorted once in
+// LDS (the existing kernel: even chunks come out ascending, odd ones descending -- the direction bit of the k = 4096
+// stage), and a tree of bitonic MERGES of two 2048-runs keeps the better 2048 keys of each pair: log2(chunks) launches
+// of 12 LDS stages each.  Keys are (~orderable(score)) << 32 | index, unique, so the first k keys are exactly the
+// first k of the full sort (ties by lower index).
+constexpr int TOPK_RUN = SORT_CHUNK / 2;
+__global__ void topk_init_kernel(const float* __restrict__ scores, int n, int npad, uint64_t* __restrict__ keys) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npad) return;
+  keys[i] = (i < n) ? (((uint64_t)(~orderable(scores[i]))) << 32) | (uint32_t)i : ~0ull;
+}
+// output run p = the 2048 smallest keys of input runs 2p and 2p + 1, ascending.  first != 0: the inputs are whole sorted
+// chunks of 4096 (run 2p = first half of an ascending chunk, run 2p + 1 = last half of a descending chunk, i.e. already
+// reversed); otherwise ascending runs of 2048 back to back.
+__global__ __launch_bounds__(1024) void topk_merge_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
+                                                         int nruns, int first) {
+  __shared__ uint64_t s[SORT_CHUNK];
+  const int p = blockIdx.x;
+  const bool has_b = 2 * p + 1 < nruns;
+  const uint64_t* a = in + (size_t)(2 * p) * (first ? SORT_CHUNK : TOPK_RUN);
+  const uint64_t* b = in + (size_t)(2 * p + 1) * (first ? SORT_CHUNK : TOPK_RUN) + (first ? TOPK_RUN : 0);
+  for (int i = threadIdx.x; i < TOPK_RUN; i += blockDim.x) {
+    s[i] = a[i];
+    const uint64_t v = has_b ? b[i] : ~0ull;
+    if (first) s[TOPK_RUN + i] = v;  // descending already
+    else s[SORT_CHUNK - 1 - i] = v;  // ascending run, reversed: ascending + descending = bitonic
+  }
+  __syncthreads();
+  for (int j = TOPK_RUN; j > 0; j >>= 1) {
+    for (int t = threadIdx.x; t < TOPK_RUN; t += blockDim.x) {
+      const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+      const int q = i | j;
+      const uint64_t x = s[i], y = s[q];
+      if (x > y) {
+        s[i] = y;
+        s[q] = x;
+      }
+    }
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < TOPK_RUN; i += blockDim.x) out[(size_t)p * TOPK_RUN + i] = s[i];
+}
+
+size_t topk_ws_bytes(int n) {
+  const size_t npad = ((size_t)(n > 0 ? n : 1) + SORT_CHUNK - 1) / SORT_CHUNK * SORT_CHUNK;
+  return (npad + npad / 2) * 8;
+}
+
+int topk_desc(const float* scores, int n, int k, int64_t* order, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (k > n) k = n;
+  if (k <= 0) return SM3_OK;
+  if (k > TOPK_RUN) return SM3_ERR_UNSUPPORTED;
+  if (ws_bytes < topk_ws_bytes(n)) return SM3_ERR_WORKSPACE;
+  const int npad = (n + SORT_CHUNK - 1) / SORT_CHUNK * SORT_CHUNK;
+  uint64_t* bufa = (uint64_t*)ws;
+  uint64_t* bufb = bufa + npad;
+  topk_init_kernel<<<(npad + 255) / 256, 256, 0, st>>>(scores, n, npad, bufa);
+  int nruns = npad / SORT_CHUNK;
+  sort_lds_kernel<<<nruns, 1024, 0, st>>>(bufa, npad, 2, SORT_CHUNK);
+  const uint64_t* cur = bufa;  // one chunk: ascending, the first k keys are the answer
+  uint64_t* nxt = bufb;
+  int first = 1;
+  while (nruns > 1) {
+    const int nout = (nruns + 1) / 2;
+    topk_merge_kernel<<<nout, 1024, 0, st>>>(cur, nxt, nruns, first);
+    cur = nxt;
+    nxt = (nxt == bufb) ? bufa : bufb;
+    nruns = nout;
+    first = 0;
+  }
+  sort_emit_kernel<<<(k + 255) / 256, 256, 0, st>>>(cur, k, order);
+  return SM3_OK;
+}
+
 // ---------------------------------------------------------------- NMS (shared structure)
 // Stage 1: suppression bit-matrix over the score-sorted boxes. Tile = 64 rows x 64 cols = ONE wavefront:
 //   lane r owns sorted box rb*64+r and builds its 64-bit word against the 64 column boxes staged in LDS.
@@ -1133,6 +1209,17 @@ int sm3_box_iou_rotated(const float* boxes1, const float* boxes2, float* ious, i
   else if (rounds == 4) box_iou_rotated_kernel<4><<<(int)blocks, 256, 0, st>>>(boxes1, boxes2, ious, n1, n2, mode_flag, aligned);
   else box_iou_rotated_kernel<1><<<(int)blocks, 256, 0, st>>>(boxes1, boxes2, ious, n1, n2, mode_flag, aligned);
   return launch_status();
+}
+
+size_t sm3_topk_desc_workspace_bytes(int n) { return topk_ws_bytes(n); }
+
+int sm3_topk_desc_f32(const float* scores, int n, int k, int64_t* order, void* workspace, size_t workspace_bytes,
+                      sm3_stream_t stream) {
+  if (n < 0 || k < 0) return SM3_ERR_INVALID_ARG;
+  if (n == 0 || k == 0) return SM3_OK;
+  if (!scores || !order || !workspace) return SM3_ERR_INVALID_ARG;
+  int rc = topk_desc(scores, n, k, order, workspace, workspace_bytes, (hipStream_t)stream);
+  return rc ? rc : launch_status();
 }
 
 size_t sm3_argsort_desc_workspace_bytes(int n) { return (size_t)next_pow2(n > 0 ? n : 1) * 8; }

@@ -136,6 +136,24 @@ def rbbox2roi(bbox_list):
     return torch.cat(rois, 0)
 
 
+def _top_order(scores, n, k):
+    """indices of the k highest of `scores` (n,) in descending score order, ties by lower index = the first k entries of
+    the descending sort the reference takes (oriented_rpn_head.py:248-254).  k <= 2048: the merge-tree top-k (one LDS sort
+    per 4096 scores + log2 merges) instead of a full sort of up to 196 608 scores."""
+    L = _lib.lib()
+    if k <= 2048:
+        nb = L.sm3_topk_desc_workspace_bytes(n)
+        ws = _lib.workspace(nb, scores.device)
+        order = torch.empty(k, dtype=torch.int64, device=scores.device)
+        call('topk_desc_f32', scores, n, k, order, ws, nb)
+        return order
+    nb = L.sm3_argsort_desc_workspace_bytes(n)
+    ws = _lib.workspace(nb, scores.device)
+    full = torch.empty(n, dtype=torch.int64, device=scores.device)
+    call('argsort_desc_f32', scores, n, full, ws, nb)
+    return full[:k]
+
+
 def grid_anchors(featmap_sizes, strides, scales=(8,), ratios=(0.5, 1.0, 2.0), device='cuda'):
     """[memory] mmdet ``AnchorGenerator(scales, ratios, strides).grid_priors``: per level (H*W*A, 4) x1,y1,x2,y2,
     position-major (y, x) then base anchor (ratio-major, scale-minor), centre offset 0."""
@@ -247,11 +265,7 @@ class OrientedRPNHead(nn.Module):
             call('sigmoid_f32', logits, sc, n)
             order = None
             if nms_pre > 0 and n > nms_pre:  # sort descending, keep the first nms_pre (:248-254)
-                nb = L.sm3_argsort_desc_workspace_bytes(n)
-                ws = _lib.workspace(nb, sc.device)
-                full = torch.empty(n, dtype=torch.int64, device=sc.device)
-                call('argsort_desc_f32', sc, n, full, ws, nb)
-                order = full[:nms_pre]
+                order = _top_order(sc, n, nms_pre)
             p, hb, s = self.bbox_coder.decode(mlvl_anchors[idx], deltas, max_shape=img_shape, order=order,
                                               scores=sc)
             props.append(p)
@@ -301,11 +315,7 @@ class OrientedRPNHead(nn.Module):
                 call('sigmoid_f32', logits, sc, n)
                 order = None
                 if nms_pre > 0 and n > nms_pre:
-                    nb = L.sm3_argsort_desc_workspace_bytes(n)
-                    ws = _lib.workspace(nb, sc.device)
-                    full = torch.empty(n, dtype=torch.int64, device=sc.device)
-                    call('argsort_desc_f32', sc, n, full, ws, nb)
-                    order = full[:nms_pre]
+                    order = _top_order(sc, n, nms_pre)
                 p, hb, s = self.bbox_coder.decode(mlvl_anchors[idx], deltas, max_shape=img_shape, order=order, scores=sc)
                 props.append(p)
                 hboxes.append(hb)

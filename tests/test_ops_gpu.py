@@ -240,6 +240,26 @@ def test_argsort_matches_stable_sort():
         assert torch.equal(order, exp), n
 
 
+def test_topk_equals_prefix_of_stable_descending_sort():
+    """merge-tree top-k (k <= 2048) == the first k entries of the stable descending sort, on tie-heavy and tie-free
+    scores, chunk counts that are odd / even / one, k at and below the run length; larger k is refused"""
+    from sm3det_amd import _lib
+    L = _lib.lib()
+    for n, k, ties in ((1, 1, True), (100, 17, True), (4096, 2000, True), (4097, 2048, False), (12295, 2000, True),
+                       (49152, 2000, False), (196608, 2000, True), (196608, 2048, False), (70001, 1, True)):
+        rs = np.random.RandomState(n + k)
+        v = rs.randint(0, 500, size=n).astype(np.float32) if ties else rs.permutation(n).astype(np.float32)
+        sc = torch.from_numpy(v).cuda()
+        order = torch.full((k,), -1, dtype=torch.long, device='cuda')
+        nb = L.sm3_topk_desc_workspace_bytes(n)
+        ws = _lib.workspace(nb, sc.device)
+        _lib.check(L.sm3_topk_desc_f32(_lib.ptr(sc), n, k, _lib.ptr(order), _lib.ptr(ws), nb, _lib.stream_ptr()), 'topk')
+        exp = torch.sort(sc, descending=True, stable=True)[1][:k]
+        assert torch.equal(order, exp), (n, k)
+    rc = L.sm3_topk_desc_f32(_lib.ptr(sc), n, 4096, _lib.ptr(order), _lib.ptr(ws), nb, _lib.stream_ptr())
+    assert rc != 0  # SM3_ERR_UNSUPPORTED: the caller falls back to the argsort
+
+
 @pytest.mark.parametrize('aligned,clockwise,ratio', [(True, True, 2), (True, False, 0), (False, True, 2)])
 @pytest.mark.parametrize('channels_last', [False, True])
 def test_roi_align_rotated_vs_oracle(aligned, clockwise, ratio, channels_last):
