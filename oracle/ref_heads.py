@@ -163,3 +163,132 @@ def make_reference_rpn_head(mlvl_anchors, assign_cfg, picks, means, stds, beta, 
     head.assigner, head.sampler = _Assigner(), _Sampler()
     head._oracle_state = state
     return head
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# inference-side classes run LIVE on CPU: OrientedRPNHead._get_bboxes_single with the reference's own `batched_nms`,
+# RotatedSingleRoIExtractor with the reference's own RoIAlignRotated wrapper, RotatedShared2FCBBoxHead.forward -- every
+# native operator underneath is the reference's CPU C++ compiled by oracle/build_ref.py.  They pin oracle/rpn_oracle.py
+# (`rpn_forward_single`, `get_bboxes_single`) and oracle/roi_oracle.py (`extract`, `extract_backward`,
+# `shared2fc_forward`), which the GPU tests use as the checker (tests/test_oracle_heads_live.py).
+def compiled_reference_ext():
+    """an ``mmcv._ext``-shaped module over the reference's CPU operators (oracle/_ref): the pybind shim of build_ref.py
+    declares no argument names, so the keyword calls of the python wrappers are mapped to positionals here"""
+    import types
+
+    from oracle import build_ref
+    ref = build_ref.load_ref()
+    m = types.ModuleType('mmcv._ext')
+    m.nms = lambda boxes, scores, iou_threshold, offset: ref.nms(boxes, scores, float(iou_threshold), int(offset))
+    m.nms_rotated = lambda dets, scores, order, dets_sorted, iou_threshold, multi_label: \
+        ref.nms_rotated_cpu(dets, scores, float(iou_threshold))  # pytorch/nms_rotated.cpp: the CPU branch ignores the rest
+    m.box_iou_rotated = lambda b1, b2, ious, mode_flag=0, aligned=False: \
+        ref.box_iou_rotated(b1, b2, ious, int(mode_flag), bool(aligned))
+
+    def fwd(input, rois, output, pooled_height, pooled_width, spatial_scale, sampling_ratio, aligned, clockwise):
+        return ref.roi_align_rotated_forward(input, rois, output, int(pooled_height), int(pooled_width),
+                                             float(spatial_scale), int(sampling_ratio), bool(aligned), bool(clockwise))
+
+    def bwd(grad_output, rois, grad_input, pooled_height, pooled_width, spatial_scale, sampling_ratio, aligned,
+            clockwise):
+        return ref.roi_align_rotated_backward(grad_output, rois, grad_input, int(pooled_height), int(pooled_width),
+                                              float(spatial_scale), int(sampling_ratio), bool(aligned), bool(clockwise))
+    m.roi_align_rotated_forward, m.roi_align_rotated_backward = fwd, bwd
+
+    def _missing(name):
+        def stub(*a, **k):
+            raise NotImplementedError(name)
+        return stub
+    def _getattr(name):  # load_ext asserts that every name of a wrapper file exists; dunders must stay absent (inspect)
+        if name.startswith('__'):
+            raise AttributeError(name)
+        return _missing(name)
+    m.__getattr__ = _getattr
+    return m
+
+
+_EXTRACTOR_FILE = ('mmrotate', 'models', 'roi_heads', 'roi_extractors', 'rotate_single_level_roi_extractor.py')
+_CONVFC_FILE = ('mmrotate', 'models', 'roi_heads', 'bbox_heads', 'convfc_rbbox_head.py')
+
+
+def load_inference():
+    """-> dict(oriented_rpn_head=<module, its `batched_nms` = the reference's own>, extractor=RotatedSingleRoIExtractor,
+    shared2fc=RotatedShared2FCBBoxHead, ops=<the reference's mmcv.ops wrapper modules>)."""
+    import torch
+
+    from oracle import ref_mmcv_ops
+    _, O, _ = load()
+    ops = ref_mmcv_ops.load(ext=compiled_reference_ext())  # reference wrappers over reference C++ (assembles `mmcv*`)
+    O.batched_nms = ops['nms'].batched_nms
+    name_e, name_c = f'{_PKG}.roi_heads.roi_extractors.rotate_single_level_roi_extractor', \
+        f'{_PKG}.roi_heads.bbox_heads.convfc_rbbox_head'
+    if name_e in sys.modules and name_c in sys.modules:
+        return dict(oriented_rpn_head=O, extractor=sys.modules[name_e].RotatedSingleRoIExtractor,
+                    shared2fc=sys.modules[name_c].RotatedShared2FCBBoxHead, ops=ops)
+    ident = lambda *a, **k: (lambda f: f)  # noqa: E731
+
+    class _Base(nn.Module):
+        def __init__(self, init_cfg=None):
+            super().__init__()
+            self.init_cfg = init_cfg
+
+    class BaseRoIExtractor(_Base):  # [memory] mmdet 2.x base_roi_extractor.py: what the subclass's own code relies on
+        def __init__(self, roi_layer, out_channels, featmap_strides, init_cfg=None):
+            super().__init__(init_cfg)
+            self.roi_layers = self.build_roi_layers(roi_layer, featmap_strides)
+            self.out_channels, self.featmap_strides, self.fp16_enabled = out_channels, featmap_strides, False
+
+        @property
+        def num_inputs(self):
+            return len(self.featmap_strides)
+
+    mmcv_ops = _mod('mmcv.ops', RoIAlignRotated=ops['roi_align_rotated'].RoIAlignRotated,
+                    RiRoIAlignRotated=type('RiRoIAlignRotated', (), {}), batched_nms=ops['nms'].batched_nms)
+    T, C, X = ref_rpn.load()
+
+    def build_bbox_coder(cfg):
+        cfg = dict(cfg)
+        t = cfg.pop('type')
+        return {'MidpointOffsetCoder': C.MidpointOffsetCoder, 'DeltaXYWHAOBBoxCoder': X.DeltaXYWHAOBBoxCoder}[t](**cfg)
+
+    shims = {
+        'mmcv': _mod('mmcv', ops=mmcv_ops), 'mmcv.ops': mmcv_ops,
+        'mmcv.cnn': _mod('mmcv.cnn', ConvModule=type('ConvModule', (nn.Module,), {})),
+        'mmcv.runner': _mod('mmcv.runner', force_fp32=ident, auto_fp16=ident, BaseModule=_Base),
+        'mmcv.utils': _mod('mmcv.utils', to_2tuple=lambda v: (v, v) if not isinstance(v, (tuple, list)) else tuple(v)),
+        'mmdet': _mod('mmdet'), 'mmdet.core': _mod('mmdet.core', multi_apply=LO.multi_apply),
+        'mmdet.models': _mod('mmdet.models'), 'mmdet.models.roi_heads': _mod('mmdet.models.roi_heads'),
+        'mmdet.models.roi_heads.roi_extractors': _mod('mmdet.models.roi_heads.roi_extractors'),
+        'mmdet.models.roi_heads.roi_extractors.base_roi_extractor':
+            _mod('mmdet.models.roi_heads.roi_extractors.base_roi_extractor', BaseRoIExtractor=BaseRoIExtractor),
+        'mmdet.models.losses': _mod('mmdet.models.losses', accuracy=LO.accuracy),
+        'mmdet.models.utils': _mod('mmdet.models.utils', build_linear_layer=lambda cfg, *a, **k: nn.Linear(*a, **k)),
+        # forward() reads these two to pick `.output_size` (mmcv != 1.4.5)
+        'mmrotate': _mod('mmrotate', digit_version=lambda v: tuple(int(x) for x in v.split('.')), mmcv_version=(1, 6, 1)),
+        'mmrotate.core': _mod('mmrotate.core', build_bbox_coder=build_bbox_coder, multiclass_nms_rotated=None),
+        f'{_PKG}.builder': _mod(f'{_PKG}.builder', ROTATED_HEADS=_Registry(), ROTATED_ROI_EXTRACTORS=_Registry(),
+                                build_loss=LO.build_loss),
+        f'{_PKG}.roi_heads.roi_extractors': _mod(f'{_PKG}.roi_heads.roi_extractors', __path__=[]),
+    }
+    keep_alive = ('mmrotate',)  # imported lazily inside RotatedSingleRoIExtractor.forward
+    saved = {k: sys.modules.get(k) for k in shims}
+    sys.modules.update(shims)
+    try:
+        mods = []
+        for name, parts in ((name_e, _EXTRACTOR_FILE), (name_c, _CONVFC_FILE)):
+            spec = importlib.util.spec_from_file_location(name, os.path.join(REF_ROOT, *parts))
+            mod = importlib.util.module_from_spec(spec)
+            sys.modules[name] = mod
+            spec.loader.exec_module(mod)
+            mods.append(mod)
+    finally:
+        for k, v in saved.items():
+            if k.startswith(_PKG) or k in keep_alive:
+                continue
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    del torch
+    return dict(oriented_rpn_head=O, extractor=mods[0].RotatedSingleRoIExtractor,
+                shared2fc=mods[1].RotatedShared2FCBBoxHead, ops=ops)

@@ -6,8 +6,10 @@
 * ``extract_backward``   -- its gradient w.r.t. every level (the reference gets it from autograd: index_put backward ->
   RoIAlignRotated backward per level);
 * ``shared2fc_forward``  -- RotatedConvFCBBoxHead.forward for the Shared2FC form, convfc_rbbox_head.py:162-201.
-The extractor class itself cannot be imported here (its base class lives in mmdet); parity of the glue is therefore
-pinned on its two ingredients (level rule = the same torch expression; per-level op = pinned oracle)."""
+Pinned: tests/test_oracle_heads_live.py runs the reference's own ``RotatedSingleRoIExtractor`` (over a stand-in for its
+mmdet base class's constructor bookkeeping, with the reference's own ``RoIAlignRotated`` wrapper and the reference's CPU
+C++ compiled by oracle/build_ref.py underneath) and ``RotatedShared2FCBBoxHead`` live: forward bit-identical, the
+extractor's backward (through the reference's autograd Function) within 1e-5."""
 import numpy as np
 import torch
 import torch.nn.functional as F

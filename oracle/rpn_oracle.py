@@ -8,8 +8,11 @@ torch-CPU restatements, each citing the reference lines it follows:
 * ``get_bboxes_single``   -- OrientedRPNHead._get_bboxes_single, oriented_rpn_head.py:189-281, with mmcv's
   ``batched_nms`` (mmcv/mmcv/ops/nms.py:264-382) over the plain-C NMS oracle (oracle/ops_oracle.py).
 
-Pinned: tests/test_oracle_rpn.py compares them with the reference functions imported from /root/reference
-(oracle/ref_rpn.py) when present, and with fixtures generated from those (tests/golden/make_golden_rpn.py)."""
+Pinned: tests/test_oracle_rpn.py compares the box functions with the reference functions imported from /root/reference
+(oracle/ref_rpn.py) when present, and with fixtures generated from those (tests/golden/make_golden_rpn.py);
+tests/test_oracle_heads_live.py runs the reference's own ``OrientedRPNHead._init_layers`` / ``forward_single`` /
+``_get_bboxes_single`` live (with the reference's own ``batched_nms`` over its compiled CPU ``nms``): ``rpn_forward_single``
+and ``get_bboxes_single`` reproduce them bit for bit."""
 import numpy as np
 import torch
 import torch.nn.functional as F

@@ -1,0 +1,114 @@
+"""CPU tier: the proposal / RoI oracles against the REFERENCE'S OWN head classes run live (oracle/ref_heads.py
+`load_inference`): `OrientedRPNHead._init_layers` / `forward_single` / `_get_bboxes_single` with the reference's own
+`batched_nms`, `RotatedSingleRoIExtractor` with the reference's own `RoIAlignRotated` wrapper (forward and, through
+autograd, backward), `RotatedShared2FCBBoxHead.forward` -- every native operator underneath is the reference's CPU C++
+compiled by oracle/build_ref.py.  This pins oracle/rpn_oracle.py and oracle/roi_oracle.py, which the GPU tests
+(tests/test_rpn_gpu.py, tests/test_roi_head_gpu.py) use as their checker.  Only the mmdet base classes are stand-ins
+(AnchorHead: empty; BaseRoIExtractor: the constructor bookkeeping), none of their code is on these paths."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_heads as RH
+from oracle import roi_oracle, rpn_oracle
+from tests import synth
+
+
+def _live():
+    try:
+        return RH.load_inference()
+    except (FileNotFoundError, ImportError, OSError) as e:
+        pytest.skip(f'live reference heads unavailable: {e}')
+
+
+class _Cfg(dict):
+    __getattr__ = dict.__getitem__
+
+    def __deepcopy__(self, memo):
+        return _Cfg({k: (_Cfg(v) if isinstance(v, dict) else v) for k, v in self.items()})
+
+
+def _grid_anchors(sizes, strides):
+    from sm3det_amd.rpn_head import grid_anchors
+    return grid_anchors(sizes, strides, [8], [0.5, 1.0, 2.0], device='cpu')
+
+
+def _reference_rpn_head(live, in_channels, feat_channels, means, stds, test_cfg):
+    O = live['oriented_rpn_head']
+    from oracle import ref_rpn
+    _, C, _ = ref_rpn.load()
+    head = O.OrientedRPNHead.__new__(O.OrientedRPNHead)
+    torch.nn.Module.__init__(head)
+    head.in_channels, head.feat_channels, head.num_anchors, head.cls_out_channels = in_channels, feat_channels, 3, 1
+    head.use_sigmoid_cls, head.version = True, 'le90'
+    head.bbox_coder = C.MidpointOffsetCoder(target_means=means, target_stds=stds, angle_range='le90')
+    head.test_cfg = test_cfg
+    head._init_layers()  # oriented_rpn_head.py:18-24
+    return head
+
+
+def test_rpn_tower_and_proposals_vs_live_reference():
+    live = _live()
+    torch.manual_seed(0)
+    means, stds = (0.,) * 6, (1.0, 1.0, 1.0, 1.0, 0.5, 0.5)
+    cfg = _Cfg(nms_pre=300, max_per_img=200, nms=_Cfg(type='nms', iou_threshold=0.8), min_bbox_size=0)
+    head = _reference_rpn_head(live, 16, 16, means, stds, cfg)
+    for m in (head.rpn_conv, head.rpn_cls, head.rpn_reg):
+        torch.nn.init.normal_(m.weight, std=0.05)
+        torch.nn.init.normal_(m.bias, std=0.05)
+    sizes, strides = [(32, 32), (16, 16), (8, 8)], [4, 8, 16]
+    feats = [torch.randn(1, 16, h, w) for h, w in sizes]
+    params = {k: v.detach() for k, v in head.state_dict().items()}
+    cls, reg = [], []
+    for f in feats:
+        c_ref, r_ref = head.forward_single(f)  # rotated_rpn_head.py:43-50
+        c_or, r_or = rpn_oracle.rpn_forward_single(f, params)
+        assert torch.equal(c_ref, c_or) and torch.equal(r_ref, r_or)
+        cls.append(c_ref[0].detach())
+        reg.append((r_ref[0] * 0.3).detach())
+    anchors = _grid_anchors(sizes, strides)
+    ref = head._get_bboxes_single(cls, reg, anchors, None, None, cfg)  # oriented_rpn_head.py:189-281
+    mine = rpn_oracle.get_bboxes_single(cls, reg, anchors, dict(cfg, nms=dict(cfg['nms'])), means, stds)
+    assert ref.shape == mine.shape and ref.shape[0] > 20 and ref.shape[1] == 6
+    assert torch.equal(ref, mine), float((ref - mine).abs().max())
+    assert bool((ref[:, 5][:-1] >= ref[:, 5][1:]).all())  # batched_nms returns score order
+
+
+@pytest.mark.parametrize('aligned,clockwise', [(True, True), (False, False)])
+def test_roi_extractor_forward_backward_vs_live_reference(aligned, clockwise):
+    live = _live()
+    strides = [4, 8, 16, 32]
+    ext = live['extractor'](roi_layer=dict(type='RoIAlignRotated', out_size=7, sample_num=2, aligned=aligned,
+                                           clockwise=clockwise), out_channels=8, featmap_strides=strides)
+    rng = np.random.RandomState(3)
+    feats = [torch.from_numpy(rng.randn(2, 8, 256 // s, 256 // s).astype(np.float32)).requires_grad_(True) for s in strides]
+    rois = np.concatenate([synth.rois_for_level(40, 5 + i, batch=2, extent=256.0, wh=w)
+                           for i, w in enumerate(((8., 60.), (60., 200.), (200., 700.)))])
+    rois_t = torch.from_numpy(rois)
+    out = ext(tuple(feats), rois_t)  # rotate_single_level_roi_extractor.py:86-140
+    lv_ref = ext.map_roi_levels(rois_t, len(strides))
+    mine, lv = roi_oracle.extract([f.detach() for f in feats], rois_t, strides, 7, 2, aligned, clockwise)
+    assert torch.equal(lv_ref, lv) and len(set(lv.tolist())) >= 3
+    assert torch.equal(out.detach(), mine), float((out.detach() - mine).abs().max())
+    g = torch.from_numpy(rng.randn(*out.shape).astype(np.float32))
+    out.backward(g)
+    grads = roi_oracle.extract_backward(g, [tuple(f.shape) for f in feats], rois_t, strides, 7, 2, aligned, clockwise)
+    for f, go in zip(feats, grads):
+        ref_g = f.grad if f.grad is not None else torch.zeros_like(f)
+        assert float((ref_g - go).abs().max()) <= 1e-5 * max(1.0, float(ref_g.abs().max()))
+
+
+def test_shared2fc_forward_vs_live_reference():
+    live = _live()
+    torch.manual_seed(1)
+    head = live['shared2fc'](in_channels=8, fc_out_channels=32, roi_feat_size=7, num_classes=5,
+                             bbox_coder=dict(type='DeltaXYWHAOBBoxCoder', angle_range='le90', target_means=(0.,) * 5,
+                                             target_stds=(0.1, 0.1, 0.2, 0.2, 0.1)),
+                             reg_class_agnostic=True,
+                             loss_cls=dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0),
+                             loss_bbox=dict(type='SmoothL1Loss', beta=1.0, loss_weight=1.0))
+    x = torch.randn(11, 8, 7, 7)
+    c_ref, r_ref = head(x)  # convfc_rbbox_head.py:168-206
+    c, r = roi_oracle.shared2fc_forward(x, {k: v.detach() for k, v in head.state_dict().items()})
+    assert c_ref.shape == (11, 6) and r_ref.shape == (11, 5)
+    assert torch.equal(c_ref, c) and torch.equal(r_ref, r)
