@@ -511,6 +511,13 @@ def ops_roofline(us):
                              unit='G pairs/s', valu_lane_instr_per_pair=ipp,
                              peak=round(peak / 1e9, 3) if peak else None, frac=round(rate / peak, 4) if peak else None,
                              serial_floor_us=pmc.get(name, {}).get('serial_floor_us'))
+            # the pair-test kernel alone (rocprofv3 duration from the committed per-operator pass): `us` above is the
+            # whole operator -- argsort, mask kernel, serial sweep, 5-9 launches
+            kern = pmc.get(name, {}).get('kernels', {})
+            pk = next((kern[k]['us_per_call'] for k in ('box_iou_rotated_kernel', 'nms_rotated_mask_kernel', 'nms_mask_kernel')
+                       if k in kern), None)
+            if pk and peak:
+                out[name].update(pair_kernel_us=pk, pair_kernel_frac=round(pairs / (pk * 1e-6) / peak, 4))
     n, C, HW = 512, 256, 256 * 256
     fmap, roi_out = 1 * C * HW * 4, n * C * 49 * 4
     hbm('roi_align_rotated_fwd_nchw', 'roi_align_rotated_fwd_512x256x7x7', roi_out + fmap + n * 24)
