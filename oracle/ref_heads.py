@@ -292,3 +292,61 @@ def load_inference():
     del torch
     return dict(oriented_rpn_head=O, extractor=mods[0].RotatedSingleRoIExtractor,
                 shared2fc=mods[1].RotatedShared2FCBBoxHead, ops=ops)
+
+
+_ROI_HEAD_FILES = (('mmrotate', 'models', 'roi_heads', 'rotate_standard_roi_head.py'),
+                   ('mmrotate', 'models', 'roi_heads', 'oriented_standard_roi_head.py'))
+
+
+def load_roi_head(assigner_factory, sampler_factory):
+    """-> the reference's own ``OrientedStandardRoIHead`` class (oriented_standard_roi_head.py over
+    rotate_standard_roi_head.py), importable on CPU: ``build_head`` / ``build_roi_extractor`` resolve to the LIVE reference
+    classes of `load_inference`, ``rbbox2roi`` / ``obb2xyxy`` are the live reference transforms, ``build_assigner`` /
+    ``build_sampler`` call the given factories (mmdet's assigner and sampler classes are absent from the tree)."""
+    live = load_inference()
+    name_s, name_o = f'{_PKG}.roi_heads.rotate_standard_roi_head', f'{_PKG}.roi_heads.oriented_standard_roi_head'
+    T, _, _ = ref_rpn.load()
+
+    class _Base(nn.Module):
+        def __init__(self, init_cfg=None):
+            super().__init__()
+            self.init_cfg = init_cfg
+
+    def build_head(cfg):
+        cfg = dict(cfg)
+        assert cfg.pop('type') == 'RotatedShared2FCBBoxHead'
+        return live['shared2fc'](**cfg)
+
+    def build_roi_extractor(cfg):
+        cfg = dict(cfg)
+        assert cfg.pop('type') == 'RotatedSingleRoIExtractor'
+        return live['extractor'](**cfg)
+
+    shims = {
+        'mmcv': _mod('mmcv'), 'mmcv.runner': _mod('mmcv.runner', BaseModule=_Base),
+        'mmdet': _mod('mmdet'), 'mmdet.core': _mod('mmdet.core', bbox2roi=None),
+        'mmrotate': sys.modules.get('mmrotate') or _mod('mmrotate'),
+        'mmrotate.core': _mod('mmrotate.core', build_assigner=assigner_factory, build_sampler=sampler_factory,
+                              obb2xyxy=T.obb2xyxy, rbbox2result=None, rbbox2roi=T.rbbox2roi),
+        f'{_PKG}.builder': _mod(f'{_PKG}.builder', ROTATED_HEADS=_Registry(), build_head=build_head,
+                                build_roi_extractor=build_roi_extractor, build_shared_head=None),
+    }
+    saved = {k: sys.modules.get(k) for k in shims}
+    sys.modules.update(shims)
+    try:
+        mods = []
+        for name, parts in ((name_s, _ROI_HEAD_FILES[0]), (name_o, _ROI_HEAD_FILES[1])):
+            spec = importlib.util.spec_from_file_location(name, os.path.join(REF_ROOT, *parts))
+            mod = importlib.util.module_from_spec(spec)
+            sys.modules[name] = mod
+            spec.loader.exec_module(mod)
+            mods.append(mod)
+    finally:
+        for k, v in saved.items():
+            if k.startswith(_PKG) or k == 'mmrotate':
+                continue
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    return mods[1].OrientedStandardRoIHead

@@ -112,3 +112,68 @@ def test_shared2fc_forward_vs_live_reference():
     c, r = roi_oracle.shared2fc_forward(x, {k: v.detach() for k, v in head.state_dict().items()})
     assert c_ref.shape == (11, 6) and r_ref.shape == (11, 5)
     assert torch.equal(c_ref, c) and torch.equal(r_ref, r)
+
+
+def test_roi_head_forward_train_composition_vs_live_reference():
+    """`OrientedStandardRoIHead.forward_train` of the reference (oriented_standard_roi_head.py:33-118 over
+    rotate_standard_roi_head.py: assign -> sample -> rbbox2roi -> extractor -> Shared2FC -> get_targets -> loss) run
+    live with the assignment of oracle/assign_oracle.py and a sampler that returns fixed picks, against the composition the
+    GPU test of the product head checks itself with (tests/test_losses_gpu.py): roi_oracle.extract + shared2fc_forward +
+    loss_oracle.rcnn_loss on the same picks, positives before negatives, image by image."""
+    from oracle import assign_oracle
+    from oracle import loss_oracle as LO
+    from tests import losses_common as LC
+    C = 26
+    c = LC.rcnn_case(5, extent=256, P=120, num=48)
+    picks = []
+
+    class _Assigner:
+        def assign(self, proposals, gts, gt_bboxes_ignore, gt_labels):
+            gi, mo, lab, _ = assign_oracle.max_iou_assign(proposals[:, :5].numpy(), gts.numpy(), True,
+                                                          gt_labels=gt_labels.numpy(), **LC.RCNN_ASSIGN)
+            return RH._Cfg(gt_inds=torch.from_numpy(gi), max_overlaps=torch.from_numpy(np.asarray(mo)),
+                           labels=torch.from_numpy(np.asarray(lab)))
+
+    class _Sampler:
+        def sample(self, assign_result, proposals, gts, gt_labels, feats=None):
+            gi = assign_result.gt_inds
+            pos = (gi > 0).nonzero().squeeze(1)[:10]
+            neg = (gi == 0).nonzero().squeeze(1)[:30]
+            assert pos.numel() >= 3 and neg.numel() >= 10
+            res = RH._FixedSampling(pos, neg, proposals[:, :5], gts, gi, gt_labels)
+            res.bboxes = torch.cat([res.pos_bboxes, res.neg_bboxes])
+            picks.append(res)
+            return res
+
+    Head = RH.load_roi_head(lambda cfg: _Assigner(), lambda cfg, context=None: _Sampler())
+    torch.manual_seed(4)
+    head = Head(
+        bbox_roi_extractor=dict(type='RotatedSingleRoIExtractor',
+                                roi_layer=dict(type='RoIAlignRotated', out_size=7, sample_num=2, clockwise=True),
+                                out_channels=8, featmap_strides=[4, 8, 16, 32]),
+        bbox_head=dict(type='RotatedShared2FCBBoxHead', in_channels=8, fc_out_channels=32, roi_feat_size=7,
+                       num_classes=C, reg_class_agnostic=True,
+                       bbox_coder=dict(type='DeltaXYWHAOBBoxCoder', angle_range='le90', norm_factor=None, edge_swap=True,
+                                       proj_xy=True, target_means=LC.RCNN_MEANS, target_stds=LC.RCNN_STDS),
+                       loss_cls=dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0),
+                       loss_bbox=dict(type='SmoothL1Loss', beta=1.0, loss_weight=1.0)),
+        train_cfg=RH._Cfg(assigner=None, sampler=None, pos_weight=-1), version='le90')
+    g = torch.Generator().manual_seed(9)
+    feats = [torch.randn(2, 8, 64 >> i, 64 >> i, generator=g) for i in range(4)]
+    props = []
+    for i in range(2):  # proposals: jittered copies of the gts + far-away boxes
+        src = c['gts'][i][torch.randint(0, c['gts'][i].shape[0], (120,), generator=g)]
+        p = src + torch.randn(120, 5, generator=g) * torch.tensor([5.0, 5.0, 3.0, 2.0, 0.1])
+        p[60:, :2] = torch.rand(60, 2, generator=g) * 256
+        p[:, 2:4] = p[:, 2:4].clamp(min=4.0)
+        props.append(torch.cat([p, torch.rand(120, 1, generator=g)], 1))
+    ref = head.forward_train(feats, [dict(), dict()], props, c['gts'], c['labels'])
+    assert set(ref) == {'loss_cls', 'loss_bbox', 'acc'} and len(picks) == 2
+    rois = torch.cat([torch.cat([torch.full((r.bboxes.shape[0], 1), float(i)), r.bboxes], 1) for i, r in enumerate(picks)])
+    x, _ = roi_oracle.extract(feats, rois, [4, 8, 16, 32], 7, 2, True, True)
+    cs, bp = roi_oracle.shared2fc_forward(x, {k: v.detach() for k, v in head.bbox_head.state_dict().items()})
+    exp = LO.rcnn_loss(cs, bp, [r.pos_bboxes for r in picks], [r.neg_bboxes for r in picks],
+                       [r.pos_gt_bboxes for r in picks], [r.pos_gt_labels for r in picks], C, LC.RCNN_MEANS, LC.RCNN_STDS)
+    for k in ('loss_cls', 'loss_bbox', 'acc'):
+        torch.testing.assert_close(ref[k].detach(), exp[k].detach(), rtol=1e-6, atol=1e-7)
+    assert float(ref['loss_bbox']) > 0
