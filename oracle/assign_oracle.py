@@ -2,10 +2,12 @@
 ``assign_wrt_overlaps`` (core/bbox/assigners/max_iou_assigner.py) with ``BboxOverlaps2D`` (bbox_overlaps, mode 'iou',
 eps 1e-6) or ``RBboxOverlaps2D`` (mmrotate rotate_iou2d_calculator.py:52-87: w,h clamped to >= 1e-3, box_iou_rotated).
 
-TEST INFRASTRUCTURE ONLY.  **PARITY UNPINNED** for the assigner rule (mmdet is not vendored under /root/reference; the
-rule below is the published one: negatives `0 <= max < neg_thr`, positives `max >= pos_thr` -> argmax+1, then for each gt
-in order `overlaps[i] == gt_max[i] >= min_pos_iou` -> i+1).  The rotated IoU underneath IS pinned: oracle/ops_oracle.c,
-bit-exact against the compiled reference."""
+TEST INFRASTRUCTURE ONLY.  The assigner rule (negatives `0 <= max < neg_thr`, positives `max >= pos_thr` -> argmax+1, then
+for each gt in order `overlaps[i] == gt_max[i] >= min_pos_iou` -> i+1) is pinned on the copy of it the reference tree
+carries -- ``MaxConvexIoUAssigner.assign_wrt_overlaps``, mmrotate/core/bbox/assigners/max_convex_iou_assigner.py:124-207,
+run live by tests/test_oracle_heads_live.py (the ``MaxIoUAssigner`` class the configs name is mmdet's and is not vendored;
+its horizontal ``bbox_overlaps`` is restated here from the published formula and is NOT pinned).  The rotated IoU
+underneath is pinned: oracle/ops_oracle.c, bit-exact against the compiled reference."""
 import numpy as np
 
 from oracle import ops_oracle

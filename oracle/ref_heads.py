@@ -350,3 +350,55 @@ def load_roi_head(assigner_factory, sampler_factory):
             else:
                 sys.modules[k] = v
     return mods[1].OrientedStandardRoIHead
+
+
+_ASSIGNER_FILE = ('mmrotate', 'core', 'bbox', 'assigners', 'max_convex_iou_assigner.py')
+
+
+def load_assign_rule():
+    """-> the reference tree's ``MaxConvexIoUAssigner`` class, whose ``assign_wrt_overlaps``
+    (max_convex_iou_assigner.py:124-207) is the MaxIoU assignment rule -- mmrotate's own copy of
+    ``mmdet MaxIoUAssigner.assign_wrt_overlaps`` (negatives, positives, every box that ties a gt's best IoU), the one
+    piece of the mmdet assigner that exists as CODE under /root/reference.  ``AssignResult`` is a plain container here."""
+    name = f'{_PKG}_assign.max_convex_iou_assigner'
+    if name in sys.modules:
+        return sys.modules[name].MaxConvexIoUAssigner
+
+    class AssignResult:
+        def __init__(self, num_gts, gt_inds, max_overlaps, labels=None):
+            self.num_gts, self.gt_inds, self.max_overlaps, self.labels = num_gts, gt_inds, max_overlaps, labels
+
+    pkg = f'{_PKG}_assign'
+    shims = {
+        'mmcv': _mod('mmcv'), 'mmcv.ops': _mod('mmcv.ops', convex_iou=None),
+        'mmdet': _mod('mmdet'), 'mmdet.core': _mod('mmdet.core'), 'mmdet.core.bbox': _mod('mmdet.core.bbox'),
+        'mmdet.core.bbox.assigners': _mod('mmdet.core.bbox.assigners'),
+        'mmdet.core.bbox.assigners.assign_result': _mod('mmdet.core.bbox.assigners.assign_result',
+                                                        AssignResult=AssignResult),
+        'mmdet.core.bbox.assigners.base_assigner': _mod('mmdet.core.bbox.assigners.base_assigner',
+                                                        BaseAssigner=type('BaseAssigner', (), {})),
+        pkg: _mod(pkg, __path__=[]),
+        f'{_PKG}.builder': _mod(f'{_PKG}.builder', ROTATED_BBOX_ASSIGNERS=_Registry()),
+    }
+    # the file imports `..builder` relative to its package: give it a parent package of its own
+    shims[f'{pkg}.builder'] = shims.pop(f'{_PKG}.builder')
+    sub = f'{pkg}.assigners'
+    shims[sub] = _mod(sub, __path__=[])
+    name = f'{sub}.max_convex_iou_assigner'
+    saved = {k: sys.modules.get(k) for k in shims}
+    sys.modules.update(shims)
+    try:
+        spec = importlib.util.spec_from_file_location(name, os.path.join(REF_ROOT, *_ASSIGNER_FILE))
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[name] = mod
+        spec.loader.exec_module(mod)
+    finally:
+        for k, v in saved.items():
+            if k.startswith(pkg):
+                continue
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    sys.modules[f'{_PKG}_assign.max_convex_iou_assigner'] = mod
+    return mod.MaxConvexIoUAssigner

@@ -177,3 +177,47 @@ def test_roi_head_forward_train_composition_vs_live_reference():
     for k in ('loss_cls', 'loss_bbox', 'acc'):
         torch.testing.assert_close(ref[k].detach(), exp[k].detach(), rtol=1e-6, atol=1e-7)
     assert float(ref['loss_bbox']) > 0
+
+
+@pytest.mark.parametrize('rotated,cfg', [(False, dict(pos_iou_thr=0.7, neg_iou_thr=0.3, min_pos_iou=0.3, match_low_quality=True)),
+                                         (True, dict(pos_iou_thr=0.5, neg_iou_thr=0.5, min_pos_iou=0.5, match_low_quality=True)),
+                                         (True, dict(pos_iou_thr=0.5, neg_iou_thr=0.5, min_pos_iou=0.5, match_low_quality=False))])
+def test_max_iou_rule_vs_the_copy_in_the_reference_tree(rotated, cfg):
+    """oracle/assign_oracle.py's MaxIoU rule against the reference tree's own code for it:
+    `MaxConvexIoUAssigner.assign_wrt_overlaps` (mmrotate/core/bbox/assigners/max_convex_iou_assigner.py:124-207), mmrotate's
+    copy of mmdet's `MaxIoUAssigner.assign_wrt_overlaps` (the class the SM3Det configs name is mmdet's and absent from the
+    tree).  That copy always applies the low-quality step; `match_low_quality=False` is reproduced with an unreachable
+    `min_pos_iou`.  The overlaps are the oracle's (rotated: the pinned C IoU)."""
+    from oracle import assign_oracle
+    try:
+        Rule = RH.load_assign_rule()
+    except (FileNotFoundError, ImportError) as e:
+        pytest.skip(str(e))
+    rng = np.random.RandomState(11)
+    for n, k in ((600, 7), (50, 1), (300, 12), (40, 0)):
+        if rotated:
+            gts = synth.rotated_boxes(k, 21 + k, extent=256.0) if k else np.zeros((0, 5), np.float32)
+            src = gts[rng.randint(0, max(k, 1), n)] if k else synth.rotated_boxes(n, 5, extent=256.0)
+            boxes = (src + rng.randn(n, 5).astype(np.float32) * np.array([6, 6, 4, 3, 0.15], np.float32)).astype(np.float32)
+            boxes[:, 2:4] = np.maximum(boxes[:, 2:4], 2.0)
+            boxes[: n // 3] = synth.rotated_boxes(n // 3, 9, extent=256.0)
+            boxes[-5:] = gts[:1] if k else boxes[-5:]  # exact ties with a gt's best IoU
+            ov = assign_oracle.rbbox_overlaps(gts, boxes) if k else np.zeros((0, n), np.float32)
+        else:
+            gts = synth.hboxes(k, 31 + k, extent=256.0) if k else np.zeros((0, 4), np.float32)
+            src = gts[rng.randint(0, max(k, 1), n)] if k else synth.hboxes(n, 6, extent=256.0)
+            boxes = (src + rng.randn(n, 4).astype(np.float32) * 5).astype(np.float32)
+            boxes[:, 2:] = np.maximum(boxes[:, 2:], boxes[:, :2] + 2)
+            boxes[: n // 3] = synth.hboxes(n // 3, 8, extent=256.0)
+            boxes[-5:] = gts[:1] if k else boxes[-5:]
+            ov = assign_oracle.bbox_overlaps(gts, boxes) if k else np.zeros((0, n), np.float32)
+        labels = rng.randint(0, 26, k).astype(np.int64)
+        rule = Rule(pos_iou_thr=cfg['pos_iou_thr'], neg_iou_thr=cfg['neg_iou_thr'],
+                    min_pos_iou=cfg['min_pos_iou'] if cfg['match_low_quality'] else 2.0, gt_max_assign_all=True)
+        ref = rule.assign_wrt_overlaps(torch.from_numpy(np.ascontiguousarray(ov)), torch.from_numpy(labels))
+        gi, mo, lab, _ = assign_oracle.max_iou_assign(boxes, gts, rotated, gt_labels=labels, **cfg)
+        assert np.array_equal(gi, ref.gt_inds.numpy()), (n, k)
+        assert np.array_equal(np.asarray(lab), ref.labels.numpy()), (n, k)
+        if k:
+            assert np.array_equal(np.asarray(mo), ref.max_overlaps.numpy())
+            assert (gi > 0).any() and (gi == 0).any()
