@@ -402,3 +402,55 @@ def load_assign_rule():
                 sys.modules[k] = v
     sys.modules[f'{_PKG}_assign.max_convex_iou_assigner'] = mod
     return mod.MaxConvexIoUAssigner
+
+
+_SAMPLER_FILE = ('mmrotate', 'core', 'bbox', 'samplers', 'rotate_random_sampler.py')
+
+
+def load_sampler():
+    """-> the reference's own ``RRandomSampler`` (rotate_random_sampler.py): its ``sample`` -- add_gt_as_proposals, the
+    expected-positive / negative counts, neg_pos_ub -- and ``_sample_pos`` / ``_sample_neg`` are code of the reference
+    tree; the mmdet pieces it leans on are stand-ins ([memory] mmdet 2.x): ``BaseSampler.__init__`` bookkeeping,
+    ``SamplingResult`` as a container, ``AssignResult.add_gt_`` supplied by the caller's assign result."""
+    name = f'{_PKG}_samplers.samplers.rotate_random_sampler'
+    if name in sys.modules:
+        return sys.modules[name].RRandomSampler
+
+    class BaseSampler:
+        def __init__(self, num, pos_fraction, neg_pos_ub=-1, add_gt_as_proposals=True, **kwargs):
+            self.num, self.pos_fraction, self.neg_pos_ub = num, pos_fraction, neg_pos_ub
+            self.add_gt_as_proposals = add_gt_as_proposals
+            self.pos_sampler = self.neg_sampler = self
+
+    class SamplingResult:
+        def __init__(self, pos_inds, neg_inds, bboxes, gt_bboxes, assign_result, gt_flags):
+            self.pos_inds, self.neg_inds, self.bboxes, self.gt_flags = pos_inds, neg_inds, bboxes, gt_flags
+
+    pkg = f'{_PKG}_samplers'
+    shims = {
+        'mmdet': _mod('mmdet'), 'mmdet.core': _mod('mmdet.core'),
+        'mmdet.core.bbox': _mod('mmdet.core.bbox', demodata=_mod('demodata', ensure_rng=lambda rng: rng)),
+        'mmdet.core.bbox.samplers': _mod('mmdet.core.bbox.samplers'),
+        'mmdet.core.bbox.samplers.base_sampler': _mod('mmdet.core.bbox.samplers.base_sampler', BaseSampler=BaseSampler),
+        'mmdet.core.bbox.samplers.sampling_result': _mod('mmdet.core.bbox.samplers.sampling_result',
+                                                         SamplingResult=SamplingResult),
+        pkg: _mod(pkg, __path__=[]), f'{pkg}.builder': _mod(f'{pkg}.builder', ROTATED_BBOX_SAMPLERS=_Registry()),
+        f'{pkg}.samplers': _mod(f'{pkg}.samplers', __path__=[]),
+    }
+    saved = {k: sys.modules.get(k) for k in shims}
+    sys.modules.update(shims)
+    keep = ('mmdet.core.bbox',)  # `from mmdet.core.bbox import demodata` runs inside __init__
+    try:
+        spec = importlib.util.spec_from_file_location(name, os.path.join(REF_ROOT, *_SAMPLER_FILE))
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[name] = mod
+        spec.loader.exec_module(mod)
+    finally:
+        for k, v in saved.items():
+            if k.startswith(pkg) or k in keep or k in ('mmdet', 'mmdet.core'):
+                continue
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    return mod.RRandomSampler

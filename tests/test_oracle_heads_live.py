@@ -221,3 +221,52 @@ def test_max_iou_rule_vs_the_copy_in_the_reference_tree(rotated, cfg):
         if k:
             assert np.array_equal(np.asarray(mo), ref.max_overlaps.numpy())
             assert (gi > 0).any() and (gi == 0).any()
+
+
+@pytest.mark.parametrize('num,frac,ub,add_gt', [(64, 0.25, -1, True), (256, 0.5, -1, False), (64, 0.25, 3, True),
+                                                (512, 0.25, -1, True)])
+def test_sampler_counts_vs_live_reference_sampler(num, frac, ub, add_gt):
+    """The product sampler's sync-free core (sm3det_amd/assign.py `sample_fixed`, plain torch: runs on CPU) against the
+    reference's own `RRandomSampler.sample` (rotate_random_sampler.py) run live: both draw at random, so what is compared
+    is what the reference's code DETERMINES -- how many positives and negatives, that positives come first and from the
+    positive set, no duplicates, gts prepended when `add_gt_as_proposals` -- over assignments with too few, exactly enough
+    and too many candidates of either kind."""
+    from sm3det_amd.assign import RRandomSampler as Mine
+    try:
+        Ref = RH.load_sampler()
+    except (FileNotFoundError, ImportError) as e:
+        pytest.skip(str(e))
+
+    class _Assign:  # [memory] mmdet AssignResult.add_gt_: the gts become proposals 0..k-1 assigned to themselves
+        def __init__(self, gt_inds, k):
+            self.gt_inds, self.num_gts = gt_inds, k
+            self.max_overlaps = torch.zeros(gt_inds.numel())
+            self.labels = torch.zeros_like(gt_inds)
+
+        def add_gt_(self, gt_labels):
+            self_inds = torch.arange(1, len(gt_labels) + 1, dtype=torch.long)
+            self.gt_inds = torch.cat([self_inds, self.gt_inds])
+            self.max_overlaps = torch.cat([self.max_overlaps.new_ones(len(gt_labels)), self.max_overlaps])
+            self.labels = torch.cat([gt_labels, self.labels])
+
+    rng = np.random.RandomState(num + int(frac * 100) + ub)
+    ref_s = Ref(num=num, pos_fraction=frac, neg_pos_ub=ub, add_gt_as_proposals=add_gt)
+    mine_s = Mine(num=num, pos_fraction=frac, neg_pos_ub=ub, add_gt_as_proposals=add_gt)
+    for n, p_pos, p_neg, k in ((2000, 0.05, 0.9, 8), (2000, 0.001, 0.99, 3), (300, 0.5, 0.1, 6), (40, 0.1, 0.3, 2),
+                               (500, 0.0, 1.0, 4)):
+        u = rng.rand(n)
+        gi = np.where(u < p_pos, rng.randint(1, k + 1, n), np.where(u < p_pos + p_neg, 0, -1)).astype(np.int64)
+        boxes, gts = torch.rand(n, 5), torch.rand(k, 5)
+        labels = torch.randint(0, 26, (k,))
+        ra = _Assign(torch.from_numpy(gi.copy()), k)
+        ref = ref_s.sample(ra, boxes, gts, labels)
+        full = ra.gt_inds  # after add_gt_ when applicable
+        assert full.numel() == n + (k if add_gt else 0) and ref.bboxes.shape[0] == full.numel()
+        idx, is_pos, valid, n_pos, n_neg = mine_s.sample_fixed(full)
+        assert int(n_pos) == ref.pos_inds.numel() and int(n_neg) == ref.neg_inds.numel(), (n, k)
+        sel_pos, sel_neg = idx[is_pos & valid], idx[(~is_pos) & valid]
+        assert sel_pos.numel() == int(n_pos) and sel_neg.numel() == int(n_neg)
+        assert bool((full[sel_pos] > 0).all()) and bool((full[sel_neg] == 0).all())
+        assert sel_pos.unique().numel() == sel_pos.numel() and sel_neg.unique().numel() == sel_neg.numel()
+        assert bool(valid[:int(n_pos) + int(n_neg)].all()) and not bool(valid[int(n_pos) + int(n_neg):].any())
+        assert bool(is_pos[:int(n_pos)].all())  # positives first
