@@ -620,9 +620,13 @@ def main():
     reducer.broadcast_parameters(0, module=net)
     # optimizer of local_configs/main_SM3Det.py: AdamW(lr 1e-4, betas (0.9, 0.999), wd 0.05), one param group per
     # parameter (paramwise_cfg / dynamic-lr hook), grad_clip max_norm 35 -- here one fused launch with a per-tensor lr vector
-    from sm3det_amd.optim import MultiTensorAdamW
-    opt = MultiTensorAdamW([dict(params=[p]) for p in params], lr=1e-4, betas=(0.9, 0.999), weight_decay=0.05,
-                           max_grad_norm=35.0, loss_scale='dynamic' if args.amp else None)
+    # built from the config's own `optimizer` / `optimizer_config` dicts by the rules of mmcv's
+    # DefaultOptimizerConstructor (sm3det_amd.optim.build_optimizer, pinned on that class by
+    # tests/test_optim_constructor_cpu.py)
+    from sm3det_amd.optim import build_optimizer
+    opt = build_optimizer({'backbone': net}, cfg_entry['optimizer'], cfg_entry['optimizer_config'],
+                          loss_scale='dynamic' if args.amp else None)
+    assert [id(q) for g_ in opt.param_groups for q in g_['params']] == [id(q) for q in params]
 
     g = torch.Generator(device='cpu').manual_seed(rank)  # rank r draws its own synthetic shard
     x = torch.randn(BATCH, 3, RES, RES, generator=g).cuda()

@@ -328,3 +328,135 @@ class DynamicLrPolicy:
                     break
             out[pn] = mult
         return out
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# mmcv DefaultOptimizerConstructor (mmcv/mmcv/runner/optimizer/default_constructor.py:95-260) on this package's modules
+def _reference_keys(module):
+    """the parameter names of `module` under the REFERENCE key schema, in the reference's `named_parameters()` order
+    (``state_dict()`` is emitted in that schema and order by the modules' hooks; buffers dropped)"""
+    buffers = {n for n, _ in module.named_buffers()}
+    return [k for k in module.state_dict().keys() if k not in buffers]
+
+
+def _module_kind(module, key):
+    """'norm' | 'dwconv' | 'other' of the module that owns reference parameter `key` -- what
+    `DefaultOptimizerConstructor.add_params` tests with isinstance (:167-172): norm layers (BatchNorm / InstanceNorm /
+    GroupNorm / LayerNorm and subclasses) and depth-wise convolutions (Conv2d with in_channels == groups).  A key whose
+    module path does not exist here belongs to a tensor this package stores fused (expert Linear layers): 'other'."""
+    import torch.nn as nn
+    path = key.rsplit('.', 1)[0] if '.' in key else ''
+    try:
+        m = module.get_submodule(path) if path else module
+    except AttributeError:
+        return 'other'
+    if isinstance(m, (nn.modules.batchnorm._BatchNorm, nn.modules.instancenorm._InstanceNorm, nn.GroupNorm, nn.LayerNorm)):
+        return 'norm'
+    if type(m).__name__ == 'DepthwiseConv7x7' or (isinstance(m, nn.Conv2d) and m.in_channels == m.groups):
+        return 'dwconv'
+    return 'other'
+
+
+def reference_param_options(module, optimizer_cfg, prefix=''):
+    """{reference key: dict(lr=, weight_decay=)} for every parameter of `module` (mounted at `prefix` in the detector,
+    e.g. 'backbone'), by the rules of `DefaultOptimizerConstructor.add_params` (:140-238): a parameter whose dotted name
+    contains a `custom_keys` entry takes that entry's `lr_mult` / `decay_mult` (longest key first, then alphabetical) and
+    nothing else; otherwise `bias_lr_mult` for biases outside norm layers, and `norm_decay_mult` / `dwconv_decay_mult` /
+    `bias_decay_mult` in that precedence.  (`dcn_offset_lr_mult`: no DCN layer exists in the SM3Det models.)"""
+    cfg = dict(optimizer_cfg)
+    pw = dict(cfg.get('paramwise_cfg') or {})
+    base_lr, base_wd = cfg.get('lr'), cfg.get('weight_decay')
+    custom = pw.get('custom_keys', {})
+    if not isinstance(custom, dict):
+        raise TypeError(f'If specified, custom_keys must be a dict, but got {type(custom)}')
+    if base_wd is None and (any('decay_mult' in v for v in custom.values()) or
+                            any(k in pw for k in ('bias_decay_mult', 'norm_decay_mult', 'dwconv_decay_mult'))):
+        raise ValueError('base_wd should not be None')
+    sorted_keys = sorted(sorted(custom.keys()), key=len, reverse=True)
+    bias_lr_mult, bias_decay_mult = pw.get('bias_lr_mult', 1.), pw.get('bias_decay_mult', 1.)
+    norm_decay_mult, dwconv_decay_mult = pw.get('norm_decay_mult', 1.), pw.get('dwconv_decay_mult', 1.)
+    out = {}
+    for key in _reference_keys(module):
+        full = f'{prefix}.{key}' if prefix else (key if '.' in key else f'.{key}')  # f'{prefix}.{name}' of add_params
+        leaf = key.rsplit('.', 1)[-1]
+        kind = _module_kind(module, key)
+        lr, wd = base_lr, base_wd
+        for ck in sorted_keys:
+            if ck in full:
+                lr = base_lr * custom[ck].get('lr_mult', 1.)
+                if base_wd is not None:
+                    wd = base_wd * custom[ck].get('decay_mult', 1.)
+                break
+        else:
+            if pw:
+                if leaf == 'bias' and kind != 'norm':
+                    lr = base_lr * bias_lr_mult
+                if base_wd is not None:
+                    if kind == 'norm':
+                        wd = base_wd * norm_decay_mult
+                    elif kind == 'dwconv':
+                        wd = base_wd * dwconv_decay_mult
+                    elif leaf == 'bias':
+                        wd = base_wd * bias_decay_mult
+        out[key] = dict(lr=lr, weight_decay=wd)
+    return out
+
+
+def param_groups_from_cfg(modules, optimizer_cfg):
+    """One param group per trainable parameter of `modules` ({detector attribute name: module}, e.g.
+    {'backbone': net, 'neck': fpn}) with the `lr` / `weight_decay` the reference's constructor would give it.  The options
+    are computed per REFERENCE parameter and carried onto this package's storage by loading them through the modules' own
+    `load_state_dict` hooks on a CPU shadow (the hooks that fuse the expert Linears and re-lay the convolutions): a fused
+    tensor whose reference parameters disagree (e.g. a custom key that names one expert) is refused."""
+    import copy
+    groups = []
+    for prefix, module in modules.items():
+        opts = reference_param_options(module, optimizer_cfg, prefix)
+        shadow = copy.deepcopy(module).to('cpu')
+        ref_sd = {k: v for k, v in shadow.state_dict().items() if k in opts}
+        per_field = {}
+        for field in ('lr', 'weight_decay'):
+            vals = sorted({o[field] for o in opts.values() if o[field] is not None})
+            code = {v: float(i + 1) for i, v in enumerate(vals)}  # exact small integers survive any layout hook
+            with torch.no_grad():
+                for q in shadow.parameters():
+                    q.fill_(float('nan'))
+            sd = {k: torch.full_like(v, code[opts[k][field]] if opts[k][field] is not None else 0.0, dtype=torch.float32)
+                  for k, v in ref_sd.items()}
+            res = shadow.load_state_dict(sd, strict=False)
+            if res.unexpected_keys:
+                raise ValueError(f'unknown reference parameters {res.unexpected_keys[:4]}')
+            back = {c: v for v, c in code.items()}
+            back[0.0] = None
+            per_field[field] = {}
+            for name, q in shadow.named_parameters():
+                lo, hi = float(q.detach().min()), float(q.detach().max())
+                if lo != hi or lo not in back:
+                    raise NotImplementedError(f'{prefix}.{name}: its reference parameters carry different `{field}` options; '
+                                              'this package stores them in one tensor')
+                per_field[field][name] = back[lo]
+        for name, p in module.named_parameters():
+            if not p.requires_grad:
+                continue
+            g = dict(params=[p], name=f'{prefix}.{name}' if prefix else name)
+            if per_field['lr'][name] is not None:
+                g['lr'] = per_field['lr'][name]
+            if per_field['weight_decay'][name] is not None:
+                g['weight_decay'] = per_field['weight_decay'][name]
+            groups.append(g)
+    return groups
+
+
+def build_optimizer(modules, optimizer_cfg, optimizer_config=None, loss_scale=None):
+    """`build_optimizer(model, cfg.optimizer)` + `OptimizerHook(**cfg.optimizer_config)` of the reference's training
+    script (mmrotate/apis/train.py) for `type='AdamW'`: `MultiTensorAdamW` over `param_groups_from_cfg`, `grad_clip`
+    from `optimizer_config`, `loss_scale` as `cfg.fp16['loss_scale']`."""
+    cfg = dict(optimizer_cfg)
+    if cfg.get('type') != 'AdamW':
+        raise NotImplementedError(f"optimizer type {cfg.get('type')!r}: the SM3Det configs use AdamW")
+    clip = (optimizer_config or {}).get('grad_clip') or {}
+    if clip and clip.get('norm_type', 2) != 2:
+        raise NotImplementedError('grad_clip norm_type != 2')
+    return MultiTensorAdamW(param_groups_from_cfg(modules, cfg), lr=cfg['lr'], betas=tuple(cfg.get('betas', (0.9, 0.999))),
+                            eps=cfg.get('eps', 1e-8), weight_decay=cfg.get('weight_decay', 1e-2),
+                            max_grad_norm=clip.get('max_norm'), loss_scale=loss_scale)
