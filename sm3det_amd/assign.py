@@ -2,8 +2,9 @@
 
 What it stands in for (all by ``type`` string in ``local_configs/main_SM3Det.py:165-196``):
 
-* ``MaxIoUAssigner`` (mmdet 2.x ``core/bbox/assigners/max_iou_assigner.py`` -- NOT vendored by the reference: semantics
-  restated, **parity unpinned**) with ``BboxOverlaps2D`` (rpn: horizontal anchors vs ``obb2xyxy(gt)``,
+* ``MaxIoUAssigner`` (mmdet 2.x ``core/bbox/assigners/max_iou_assigner.py`` -- NOT vendored by the reference; its rule
+  ``assign_wrt_overlaps`` exists in the tree as mmrotate's copy, ``max_convex_iou_assigner.py:124-207``, which pins the
+  oracle of this module: tests/test_oracle_heads_live.py) with ``BboxOverlaps2D`` (rpn: horizontal anchors vs ``obb2xyxy(gt)``,
   ``oriented_rpn_head.py:72-78``) or ``RBboxOverlaps2D`` (rcnn: rotated proposals vs rotated gts,
   ``mmrotate/core/bbox/iou_calculators/rotate_iou2d_calculator.py:8-87``, ``oriented_standard_roi_head.py:66-70``);
 * ``RandomSampler`` / ``RRandomSampler`` (``mmrotate/core/bbox/samplers/rotate_random_sampler.py:10-80`` on mmdet's
