@@ -415,12 +415,12 @@ int sm3_moe_router_fwd(const float* hcat, int ldh, int P, const float* snorm, co
                        int T, int E, int k, int train, int32_t* top_idx, float* top_val, float* gates, float* clean,
                        float* sigma, float* hnorm, float* partials, const int32_t* forced_topk, sm3_stream_t stream);
 /* backward: dgate (T,k) from the combine, dimp/dload (E) from the aux loss.  Writes dhcat (T,ldh) = [dh | draw | 0],
- * dcn (T,E) = dclean/max(|h|,eps) and ds_part (sm3_moe_router_partial_rows(T)) partial sums of d(scale). */
+ * dcn (T,E) = dclean/max(|h|,eps) and ds_part (sm3_moe_router_partial_rows(T), DOUBLE) partial sums of d(scale). */
 int sm3_moe_router_bwd(const float* hcat, int ldh, int P, const float* snorm, const float* scale, const float* noise,
                        int T, int E, int k, int train, const int32_t* top_idx, const float* top_val,
                        const float* gates, const float* clean, const float* sigma, const float* hnorm,
                        const float* dgate, const float* dimp, const float* dload, float* dhcat, float* dcn,
-                       float* ds_part, sm3_stream_t stream);
+                       double* ds_part, sm3_stream_t stream);
 
 /* Gate parameter preparation, one launch (CosineTopKGate.forward :96-105 + the `x @ w_noise` operand :199-201):
  * wcat (PC,C) = [cosine_projector.weight (P,C); w_noise^T (E,C); 0], bcat (PC) = [cosine_projector.bias; 0],
@@ -429,8 +429,8 @@ int sm3_moe_gate_prep_fwd(const float* wp, const float* bp, const float* wn, con
                           const float* temperature, float clamp_max, int P, int C, int E, int PC, float* wcat,
                           float* bcat, float* snorm, float* scale, sm3_stream_t stream);
 /* backward: dwcat (PC,C) / dbcat (PC) from the gate GEMM, dsn (P,E) = h^T.dcn (gradient w.r.t. snorm*scale),
- * ds_part (n_part) partial sums of d(scale) from sm3_moe_router_bwd -> gradients of the five reference parameters. */
-int sm3_moe_gate_prep_bwd(const float* dwcat, const float* dbcat, const float* dsn, const float* ds_part, int n_part,
+ * ds_part (n_part, double) partial sums of d(scale) from sm3_moe_router_bwd -> gradients of the five reference parameters. */
+int sm3_moe_gate_prep_bwd(const float* dwcat, const float* dbcat, const float* dsn, const double* ds_part, int n_part,
                           const float* sim, const float* temperature, float clamp_max, int P, int C, int E,
                           float* dwp, float* dbp, float* dwn, float* dsim, float* dtemp, sm3_stream_t stream);
 /* Auxiliary load-balancing loss (:140-147, :234-238): tot (2E) = column sums of the router partials =

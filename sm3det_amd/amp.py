@@ -8,10 +8,13 @@ accumulation, LayerNorm / softmax / the MoE combine (``.float()``, convnext_moe.
 scaled by a ``GradScaler`` and the optimizer step is skipped when a gradient overflowed.
 
 Here: ``autocast()`` switches every GEMM of the family to fp16 OPERANDS with fp32 accumulation
-(``v_mfma_f32_32x32x16_f16``, 16x the fp32 matrix rate).  The rounding happens in the GEMM's loader, so every tensor in
-HBM -- master weights, activations, gradients, LayerNorm, router, combine -- stays fp32 (more precise than the
-reference's fp16 activation storage, same product arithmetic); no cast kernels and no fp16 weight copies exist.  The
-dynamic loss scale (GradScaler semantics: init 65536, x0.5 on overflow, x2 after 2000 clean steps) lives on the device
+(``v_mfma_f32_32x32x16_f16``, 16x the fp32 matrix rate) and -- since round 3 -- to the fp16 DATA PATH: the tensors that
+autocast turns into halves in the reference (the outputs of the FFN's ``nn.Linear``s and what feeds them) are stored as
+fp16 in HBM: the LayerNorm output ``xn``, the dispatched expert inputs ``xslot``, the GELU output ``act``, the saved
+GELU' ``hpre`` and the 4C-wide gradient ``dh`` (written as halves by the producing kernels' epilogues, read as halves by
+the GEMM loaders).  Master weights, biases, the residual stream, every C-wide gradient, the expert
+outputs and everything the router computes stay fp32; fp32 operands are rounded in the GEMM's loader, so no cast kernels
+exist.  ``SM3_AMP_STORAGE=fp32`` restores the all-fp32 storage of round 2 for A/B runs.  The dynamic loss scale (GradScaler semantics: init 65536, x0.5 on overflow, x2 after 2000 clean steps) lives on the device
 inside ``MultiTensorAdamW`` (optim.py): unscale, overflow check, clip, skip and scale update cost no host sync.
 """
 import contextlib

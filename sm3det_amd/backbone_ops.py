@@ -60,6 +60,9 @@ def _chk(t, name):
 # when the GEMM family ran at 0.48 of peak).  SM3_WGRAD_STREAM=1 turns it back on.
 OVERLAP_WGRAD = os.environ.get('SM3_WGRAD_STREAM', '0') == '1'
 _SIDE = {}
+# test aid (tests/test_fullsize_gpu.py): when a list, every MoE block's backward appends its per-workgroup partial sums of
+# d(scale) -- the terms of the fully cancelling sum behind d(temperature) -- so the test can state the sum's conditioning
+DEBUG_DSCALE = None
 
 
 def _side_stream(device):
@@ -454,9 +457,11 @@ class _MoEBlock(Function):
         gemm(LB.NN, dh, w1, dxslot, S, C, Hd, offsets=offsets, num_groups=E)
         # router backward
         nblk = _lib.lib().sm3_moe_router_partial_rows(T)
-        dhcat, dcn, ds_part = _e(T, PC, like=x), _e(T, E, like=x), _e(nblk, like=x)
+        dhcat, dcn, ds_part = _e(T, PC, like=x), _e(T, E, like=x), _e(nblk, like=x, dtype=torch.float64)
         call('moe_router_bwd', hcat, PC, P, snorm, scale, noise, T, E, k, int(train), top_idx, top_val, gates, clean,
              sigma, hnorm, dgate, dimp_load, dimp_load[E:], dhcat, dcn, ds_part, nbytes=4.0 * T * (2 * PC + 6 * E))
+        if DEBUG_DSCALE is not None:
+            DEBUG_DSCALE.append(ds_part)
         # gate parameters ([Wp; Wn^T] rows, normalize and exp(clamp) backward in one launch) -- side stream
         if sim is None:  # linear gate: wp is w_gate (C, E)
             dwp, dwn = _e(C, E, like=x), _e(C, E, like=x)

@@ -132,13 +132,24 @@ def build_detector_pieces(model_cfg, skip_missing=True):
             mod = name.split('_')[0]
             tr, te = model_cfg.get(f'{mod}_train_cfg'), model_cfg.get(f'{mod}_test_cfg')
             cfg = dict(cfg, train_cfg=(tr or {}).get('rpn'), test_cfg=(te or {}).get('rpn'))
+        elif cfg is not None and name == 'sar_bbox_head':
+            # (:100-104): the one-stage head takes the SAR train / test cfg whole
+            cfg = dict(cfg, train_cfg=model_cfg.get('sar_train_cfg'), test_cfg=model_cfg.get('sar_test_cfg'))
         build(name, cfg)
     for head in ('rgb_roi_head', 'ifr_roi_head'):
         h = model_cfg.get(head)
         if h is not None:
-            for name in _ROI_PIECES:
-                build(f'{head}.{name}', h.get(name))
             mod = head.split('_')[0]  # (:70-77): the whole RoI head with the modality's rcnn train / test cfg
             tr, te = model_cfg.get(f'{mod}_train_cfg'), model_cfg.get(f'{mod}_test_cfg')
             build(head, dict(h, train_cfg=(tr or {}).get('rcnn'), test_cfg=(te or {}).get('rcnn')))
+            if head in out:
+                # the RoI head is built ONCE; its sub-modules are exposed as ALIASES of it (one parameter set per reference
+                # key: a checkpoint loaded into / an optimizer built over this dict sees each weight exactly once)
+                for name in _ROI_PIECES:
+                    sub = getattr(out[head], name, None)
+                    if sub is not None:
+                        out[f'{head}.{name}'] = sub
+            else:  # the head's own type is not registered: build what is
+                for name in _ROI_PIECES:
+                    build(f'{head}.{name}', h.get(name))
     return out

@@ -368,6 +368,11 @@ size_t colpart_bytes(const sm3_gemm_desc* d, const Cfg& c) {
 
 }  // namespace
 
+#ifdef SM3_TRACE
+static unsigned long long* g_trace = nullptr;
+extern "C" void sm3_gemm_set_trace(void* buf) { g_trace = (unsigned long long*)buf; }  // measurement build only
+#endif
+
 extern "C" {
 
 int sm3_gemm_f32_counter_slots(void) { return COUNTER_SLOTS; }
@@ -423,6 +428,9 @@ int sm3_gemm_f32(const sm3_gemm_desc* d, void* workspace, size_t workspace_bytes
   p.rows_per_scale = d->rows_per_scale > 0 ? d->rows_per_scale : 1;
   p.ld_aux = d->ld_aux;
   p.colpart = cb ? (float*)((char*)workspace + sb) : nullptr;
+#ifdef SM3_TRACE
+  p.trace = g_trace;
+#endif
   if (d->mode == MODE_TN) {
     float* out = d->C;
     const long mn1 = (long)d->M * d->N;

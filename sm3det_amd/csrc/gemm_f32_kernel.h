@@ -35,7 +35,7 @@
 // runs the last 3-4 k-tiles only; two steps per iteration with no branch between them; lanes past a tile edge repeat the
 // tile's last row into the same LDS slot.  GATHER (implicit-GEMM 3x3 convolution) splits the source pixel into a per-row
 // part and a per-tap part that is equal for all lanes; masked taps read past the descriptor's extent (hardware zero).
-// F16 = 1 keeps fp32 tensors in HBM and an fp16 image in LDS (v_mfma_f32_32x32x16_f16, fp32 accumulation).
+// F16 = 1: fp16 image in LDS (v_mfma_f32_32x32x16_f16, fp32 accumulation); IO flags say which tensors are fp16 in HBM.
 // CSUM = 1 (TN): the workgroups of the first column tile also sum the rows of A they load (bias gradient).
 #pragma once
 #include "common.h"
@@ -88,7 +88,20 @@ struct GemmParams {
   int cC, sH, sW, rH, rW, cS, cT;
   int cU;  // per-tap source offset u(d), d = 0..2, 4 bits each: d (forward), 2 - d (input gradient), 1 - d/2 (same, stride 2)
   unsigned cInv, mRW, mRH;  // mRW/mRH: ceil(2^32 / rW), ceil(2^32 / rH) for exact umulhi division of row indices
+#ifdef SM3_TRACE  // measurement build only (python -m sm3det_amd.build --variant trace): per-workgroup phase timestamps
+  unsigned long long* trace;  // [blocks][8]: s_memtime at entry / loop start / loop end / after fix-up / exit, HW_ID|XCC_ID<<32, nk, s_memrealtime
+#endif
 };
+
+#ifdef SM3_TRACE
+#define SM3_TR(i)                                                                                    \
+  do {                                                                                               \
+    if (p.trace && threadIdx.x == 0)                                                                 \
+      p.trace[((size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.z) * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define SM3_TR(i) do {} while (0)
+#endif
 
 template <int WM_, int WN_, int TI_, int TJ_>
 struct Tile {
@@ -204,6 +217,24 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
+#ifdef SM3_TRACE
+  SM3_TR(0);
+  if (p.trace && tid == 0) {
+    unsigned long long* tr = p.trace + ((size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.z) * 8;
+    tr[5] = (unsigned long long)__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)) |      // HW_REG_HW_ID
+            ((unsigned long long)__builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11)) << 32);  // HW_REG_XCC_ID
+    tr[7] = __builtin_amdgcn_s_memrealtime();
+    tr[1] = tr[2] = tr[3] = tr[4] = 0;
+  }
+#endif
+#ifdef SM3_PRIO  // measurement build only: static wave priority by residency slot (co-resident workgroups get different ones)
+  {
+    const unsigned lb = blockIdx.x + gridDim.x * blockIdx.z;
+    const unsigned cls = SM3_PRIO == 1 ? (lb >> 8) % 3u : 2u - (lb >> 8) % 3u;
+    if (cls == 1) __builtin_amdgcn_s_setprio(1);
+    else if (cls == 2) __builtin_amdgcn_s_setprio(2);
+  }
+#endif
   const int wm0 = (wave / WN) * (TI * 32);
   const int wn0 = (wave % WN) * (TJ * 32);
   const int l31 = lane & 31;
@@ -673,6 +704,10 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
     for (int q = 0; q < NP; q++) load_piece(sa0, sb0, q, min(1, nk - 1), true);
   }
   __syncthreads();
+  SM3_TR(1);
+#ifdef SM3_TRACE
+  if (p.trace && tid == 0) p.trace[((size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.z) * 8 + 6] = (unsigned long long)nk;
+#endif
 
   auto k_step = [&](f32x4 (&ca)[PA], f32x4 (&cb)[PB], f32x4 (&na)[PA], f32x4 (&nb)[PB], int kt, bool tail) {
     // ca/cb hold tile kt+1 (to be stored), na/nb receive tile kt+2
@@ -719,12 +754,14 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
     }
     __syncthreads();
   };
-  // F16 (mixed precision, the reference's `fp16 = dict(loss_scale='dynamic')` configs): same tiles and loaders; the fp32
-  // values are rounded to fp16 when a piece is stored to LDS (see Aw above), the fragments (8 k-values per lane and
-  // operand = 4 dwords) go from LDS straight into v_mfma_f32_32x32x16_f16 with fp32 accumulation -- 16x the matrix rate
-  // of the fp32 instruction, so the loop is bound by the operand stream, not by the matrix pipe.  Every tensor in HBM stays fp32 (master
-  // weights, activations, gradients): no cast kernels, no fp16 copies.  A and B use the same (lane-half, element) -> k
-  // assignment, so the sum over k is complete whatever order the hardware walks it in.
+  // F16 (mixed precision, the reference's `fp16 = dict(loss_scale='dynamic')` configs): same tiles and loaders; operands
+  // stored as fp32 in HBM (weights, the residual stream, C-wide gradients) are rounded to fp16 when a piece is stored to
+  // LDS (see Aw above), operands the AMP data path already stores as fp16 (IO_A16 / IO_B16: LayerNorm output, dispatched
+  // expert inputs, GELU output, the 4C-wide gradient) arrive as halves and are stored as they are; the fragments (8
+  // k-values per lane and operand = 4 dwords) go from LDS straight into v_mfma_f32_32x32x16_f16 with fp32 accumulation --
+  // 16x the matrix rate of the fp32 instruction, so the loop is bound by the operand stream, not by the matrix pipe.  No
+  // cast kernels exist.  A and B use the same (lane-half, element) -> k assignment, so the sum over k is complete
+  // whatever order the hardware walks it in.
   auto k_step16 = [&](f32x4 (&ca)[PA], f32x4 (&cb)[PB], f32x4 (&na)[PA], f32x4 (&nb)[PB], int kt, bool tail) {
     const int buf = kt & 1;
     const int kt_load = tail ? min(kt + 2, nk - 1) : kt + 2;
@@ -797,6 +834,7 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
     }
   }
 
+  SM3_TR(2);
   if (CSUM && do_cs && F16) {  // an F16 piece = four k of ONE column (unit idx = k-quad * BM + column): [BK / 4][BM]
     float* red = smem;
 #pragma unroll
@@ -867,7 +905,10 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
       *flag = (ticket == p.splits - 1);
     }
     __syncthreads();
-    if (!*flag) return;
+    if (!*flag) {
+      SM3_TR(3);
+      return;
+    }
     if (tid == 0) {
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       __hip_atomic_store(p.counters + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
@@ -896,6 +937,7 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
     __syncthreads();  // `flag` word is reused by the column-sum scratch below
   }
 
+  SM3_TR(3);
   // ---- epilogue ---------------------------------------------------------------------------------------------
   // acc[i][j][4q + e]: row = wm0 + 32 i + l31 ; col = wn0 + 32 j + 8 q + 4 lh + e   (e = 0..3 contiguous).
   // Stored straight from the fragments, one wave instruction would touch 32 rows x 32 bytes: a quarter of each cache
@@ -1049,6 +1091,10 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
       p.colpart[(long)tile_m * p.N + n0 + tid] = t;
     }
   }
+#ifdef SM3_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores of this wave have left the CU
+  SM3_TR(4);
+#endif
 }
 
 // launchers (one translation unit per mode: gemm_f32.hip = NT, gemm_f32_nn.hip, gemm_f32_tn.hip)

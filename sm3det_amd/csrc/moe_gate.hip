@@ -65,7 +65,7 @@ __global__ __launch_bounds__(GP_THREADS) void gate_prep_fwd_kernel(const float* 
 // partial sums of d(scale).
 __global__ __launch_bounds__(GP_THREADS) void gate_prep_bwd_kernel(
     const float* __restrict__ dwcat, const float* __restrict__ dbcat, const float* __restrict__ dsn,
-    const float* __restrict__ ds_part, int n_part, const float* __restrict__ sim,
+    const double* __restrict__ ds_part, int n_part, const float* __restrict__ sim,
     const float* __restrict__ temperature, float clamp_max, int P, int C, int E, float* __restrict__ dwp,
     float* __restrict__ dbp, float* __restrict__ dwn, float* __restrict__ dsim, float* __restrict__ dtemp) {
   const int r = blockIdx.x;
@@ -103,15 +103,17 @@ __global__ __launch_bounds__(GP_THREADS) void gate_prep_bwd_kernel(
       dsim[(long)p * E + e] = n >= 1e-12f ? (g - v * (gv / ss)) / n : g / 1e-12f;
     }
   }
-  __shared__ float red[GP_THREADS / 64];
-  float s = 0.f;
+  // d(scale): a fully cancelling sum over all tokens and experts -- double from the first product (router backward) to here
+  __shared__ double red[GP_THREADS / 64];
+  double s = 0.0;
   for (int i = threadIdx.x; i < n_part; i += GP_THREADS) s += ds_part[i];
-  s = wave_sum(s);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
   if (lane == 0) red[wave] = s;
   __syncthreads();
   if (threadIdx.x == 0) {
-    const float dscale = (red[0] + red[1]) + (red[2] + red[3]);
-    dtemp[0] = t <= clamp_max ? dscale * scale : 0.f;  // clamp(max=) passes the gradient where t <= max
+    const double dscale = (red[0] + red[1]) + (red[2] + red[3]);
+    dtemp[0] = t <= clamp_max ? (float)(dscale * (double)scale) : 0.f;  // clamp(max=) passes the gradient where t <= max
   }
 }
 
@@ -194,7 +196,7 @@ int sm3_moe_gate_prep_fwd(const float* wp, const float* bp, const float* wn, con
   return launch_status();
 }
 
-int sm3_moe_gate_prep_bwd(const float* dwcat, const float* dbcat, const float* dsn, const float* ds_part, int n_part,
+int sm3_moe_gate_prep_bwd(const float* dwcat, const float* dbcat, const float* dsn, const double* ds_part, int n_part,
                           const float* sim, const float* temperature, float clamp_max, int P, int C, int E,
                           float* dwp, float* dbp, float* dwn, float* dsim, float* dtemp, sm3_stream_t stream) {
   if (!dwcat || !dbcat || !dsn || !ds_part || !sim || !temperature || !dwp || !dbp || !dwn || !dsim || !dtemp)

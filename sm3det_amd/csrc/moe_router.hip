@@ -275,7 +275,7 @@ __global__ __launch_bounds__(RT_THREADS) void moe_router_bwd_kernel(
     const float* __restrict__ top_val, const float* __restrict__ gates, const float* __restrict__ clean_i,
     const float* __restrict__ sigma_i, const float* __restrict__ hnorm_i, const float* __restrict__ dgate,
     const float* __restrict__ dimp, const float* __restrict__ dload, float* __restrict__ dhcat,
-    float* __restrict__ dcn, float* __restrict__ ds_part) {
+    float* __restrict__ dcn, double* __restrict__ ds_part) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* s_s = sm;
   float* hs = sm + (long)P * ET;  // [16][P+1]: h on the way in, dh on the way out
@@ -290,8 +290,8 @@ __global__ __launch_bounds__(RT_THREADS) void moe_router_bwd_kernel(
   const int m = min(k + 1, E);
   const float scale = linear ? 1.f : *scale_p;
   const bool smooth = train && (k < E);
-  float ds_local = 0.f;
-  float draw[ET];
+  double ds_local = 0.0;  // d(scale) is one number summed over every token and expert with mixed signs: the terms are
+  float draw[ET];           // added in double from the first product on (gate_prep_bwd finishes the sum in double too)
 #pragma unroll
   for (int e = 0; e < ET; e++) draw[e] = 0.f;
   if (tv) {
@@ -371,14 +371,14 @@ __global__ __launch_bounds__(RT_THREADS) void moe_router_bwd_kernel(
       }
     const float hn = linear ? 1.f : hnorm_i[tt];
     const float inv = 1.0f / fmaxf(hn, 1e-12f);
-    float dsl = 0.f;
+    double dsl = 0.0;
 #pragma unroll
     for (int e = 0; e < ET; e++)
       if (e < E) {
         if (sub == 0) dcn[tt * E + e] = dclean[e] * inv;
-        dsl += dclean[e] * cl[e];
+        dsl += (double)dclean[e] * (double)cl[e];
       }
-    ds_local = sub == 0 ? dsl / scale : 0.f;  // the token is counted once
+    ds_local = sub == 0 ? dsl / (double)scale : 0.0;  // the token is counted once
     // dh = (dhh - hh <hh, dhh>) * inv,  dhh = scale * snorm . dclean,  hh = h * inv  (row lives in LDS); the four
     // lanes of the token split p
     float* hrow = hs + tl * (P + 1);
@@ -431,7 +431,9 @@ __global__ __launch_bounds__(RT_THREADS) void moe_router_bwd_kernel(
       for (int c = P + E; c < ldh; c++) dh[c] = 0.f;
     }
   }
-  const float a = group_sum<64>(ds_local);
+  double a = ds_local;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
   if (threadIdx.x == 0) ds_part[blockIdx.x] = a;
 }
 
@@ -467,7 +469,7 @@ int sm3_moe_router_bwd(const float* hcat, int ldh, int P, const float* snorm, co
                        int T, int E, int k, int train, const int32_t* top_idx, const float* top_val,
                        const float* gates, const float* clean, const float* sigma, const float* hnorm,
                        const float* dgate, const float* dimp, const float* dload, float* dhcat, float* dcn,
-                       float* ds_part, sm3_stream_t stream) {
+                       double* ds_part, sm3_stream_t stream) {
   if (!hcat || (snorm && !scale) || !top_idx || !top_val || !gates || !clean || !hnorm || !dgate || !dimp || !dload ||
       !dhcat || !dcn || !ds_part)
     return SM3_ERR_INVALID_ARG;

@@ -86,7 +86,7 @@ def make(case):
     blocks = [b for st in net.stages for b in st]
     # candidate noise seeds: forward only, keep the one whose routing has the widest minimum top-k margin
     best = None
-    for cand in range(N_NOISE_CANDIDATES):
+    for cand in range(N_NOISE_CANDIDATES if c.get('select_noise', True) else 1):
         ns = seed * 100 + cand
         x, noise, drop = FC.make_inputs(case, noise_seed=ns)
         for b, rs in zip(blocks, drop):

@@ -102,7 +102,9 @@ def _run_case(case, amp, forced=False):
     # without it the fp16 gradient operands of the deep blocks underflow (measured on ConvNeXt-B: stages.1.2 gradients
     # 60-90 % off at scale 1, 2e-3 at scale 1024).  Gradients are unscaled before the comparison.
     loss_scale = 65536.0 if amp else 1.0
+    from sm3det_amd import backbone_ops as BO
     while True:
+        BO.DEBUG_DSCALE = []
         for q in net.parameters():
             q.grad = None
         outs, gl = net(x.cuda(), ['single'], noise=[n.cuda() for n in noise], drop_scale=[d.cuda() for d in drop],
@@ -115,6 +117,7 @@ def _run_case(case, amp, forced=False):
             break
         loss_scale /= 2.0
         assert loss_scale >= 1.0, 'non-finite gradients at loss scale 1'
+    ds_parts, BO.DEBUG_DSCALE = [t.double().cpu() for t in BO.DEBUG_DSCALE], None
     report = dict(case=case, amp=bool(amp), forced_routing=bool(forced), loss_scale=loss_scale)
     tag = ('_amp' if amp else '') + ('_forced' if forced else '')
 
@@ -128,6 +131,7 @@ def _run_case(case, amp, forced=False):
     first_flip_stage, n_flips, n_second_gen = None, 0, 0
     ref_iter = iter(fx['routing'])
     cont = None
+    stage_cont = []  # footprint of the flips on each stage's output grid (what out_i can differ on by design)
     for i, stage in enumerate(net.stages):
         Hs = x.shape[2] // 4 >> i
         cont = torch.zeros(B_img, 1, Hs, Hs) if cont is None else torch.nn.functional.max_pool2d(cont, 2)
@@ -161,14 +165,30 @@ def _run_case(case, amp, forced=False):
             assert int((counts - fx['expert_counts'][len(report.get('blocks', []))]).abs().sum()) <= 2 * bad.numel()
             report.setdefault('blocks', []).append(dict(stage=i, block=j, flips=int(bad.numel()), tokens=int(got.shape[0]),
                                                         footprint=float(cont.mean())))
+        stage_cont.append(cont.clone())
     report['second_generation_flips'] = n_second_gen
     report['routing_flips'] = n_flips
     if forced:
         assert n_flips == 0, 'teacher-forced routing must reproduce the reference routing exactly'
-    if amp and not forced:  # natural routing: the routing rule is the test (see the docstring); keep the numbers
+    if amp and not forced:
+        # natural routing: the routing rule above is the first half of the test; the second half compares the OUTPUTS on
+        # every sampled element whose token lies OUTSIDE the footprint of the flips (tokens no flipped token can reach
+        # through the 7x7 convolutions and downsamples in between), at the tolerance of the tensor: max-norm 2e-2.
+        # Inside the footprint outputs differ by design (a flipped token's block output changes by O(1) with randomly
+        # initialised experts); deep stages can be covered entirely, the count of compared samples is reported.
         for i, (o, ref) in enumerate(zip(outs, fx['outs'])):
             e = FC.compare_output(i, o, ref)['samples']
-            report[f'out{i}'] = dict(median=float(e.median()), frac_above_tol=float((e > FWD_TOL).double().mean()))
+            Bo, Co, Ho, Wo = ref['shape']
+            idx = FC.sample_index(f'out{i}', Bo * Co * Ho * Wo, FC.N_OUT_SAMPLES)
+            clean = stage_cont[i][idx // (Co * Ho * Wo), 0, (idx % (Ho * Wo)) // Wo, idx % Wo] == 0
+            got_s = FC.summarise_output(i, o)['samples'].double()
+            err = (got_s - ref['samples'].double()).abs() / ref['max_abs']
+            mx_clean = float(err[clean].max()) if bool(clean.any()) else 0.0
+            report[f'out{i}'] = dict(median=float(e.median()), frac_above_tol=float((e > FWD_TOL).double().mean()),
+                                     samples_outside_flip_footprint=int(clean.sum()), footprint=float(stage_cont[i].mean()),
+                                     max_norm_rel_outside_footprint=mx_clean,
+                                     max_norm_rel_all_samples=float(err.max()))
+            assert mx_clean < AMP_TOL, (case, f'out{i}', 'natural routing, outside the flip footprint', report[f'out{i}'])
         os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
         with open(os.path.join(ROOT, 'gpurun_out', f'fullsize_{case}{tag}.json'), 'w') as f:
             json.dump(report, f, indent=1)
@@ -224,9 +244,19 @@ def _run_case(case, amp, forced=False):
     # The element-wise form above floors its denominator at 1 % of the tensor's scale, i.e. it asks for an ABSOLUTE error
     # of 2e-4 of the scale on small elements, 10x below fp16 resolution of the summed terms (measured: max-norm 1-4e-3
     # everywhere while the element-wise figure reaches 0.1-0.35 on the smallest elements); it is reported, not asserted.
-    # The scalar `temperature` gradients (fully cancelling sums, see above) get 5e-2: observed up to 3.4e-2 on
-    # ConvNeXt-B, with the other 900+ tensors below 5e-3.
+    # The scalar `temperature` gradients are fully cancelling sums over all tokens and experts; since round 4 they are
+    # accumulated in double from the first product on and held to the same 2e-2, unless the conditioning of the sum itself
+    # (measured below from the run's own terms) says fp16 input rounding alone exceeds it.
     floor = fx.get('grad_fp32_floor', {})
+    # conditioning of d(temperature) per MoE block (backward order = reverse block order): S = sum of the per-workgroup
+    # partials s_i (16 tokens each), accumulated in double on the device since round 4.  Every s_i carries the fp16 rounding
+    # of its factors (relative 2^-11 each, independent), so the achievable accuracy of S is ~ 2^-11 * |s|_2 / |S|.
+    temp_keys = [f'stages.{i}.{j}.ffn.w_gate.temperature' for i, j, _b in _moe_blocks(net)]
+    temp_cond = {}
+    if len(ds_parts) == len(temp_keys):
+        for key, part in zip(reversed(temp_keys), ds_parts):
+            temp_cond[key] = float(part.norm() / max(float(part.sum().abs()), 1e-300))
+    report['temperature_grad_conditioning_l2_over_abs_sum'] = temp_cond
     worst = (0.0, None)
     worst_l2 = (0.0, None)
     worst_ew = (0.0, None)
@@ -239,7 +269,13 @@ def _run_case(case, amp, forced=False):
             if e > worst_ew[0]:
                 worst_ew = (e, key)
             e, l2 = FC.compare_grad_maxnorm(key, g, fx['grads'])
-            te = tl2 = 5e-2 if key.endswith('.temperature') else BWD_TOL
+            te = tl2 = BWD_TOL
+            if key.endswith('.temperature'):
+                # one tolerance (2e-2) unless the sum's own conditioning puts fp16 input rounding above it: 4 sigma of
+                # 2^-11 * |s|_2 / |S| (measured on this run's terms, reported above) -- not a chosen constant
+                te = tl2 = max(BWD_TOL, 4.0 * 2.0 ** -11 * temp_cond.get(key, 0.0))
+                if te > BWD_TOL:
+                    loosened[key] = dict(tol=te, conditioning=temp_cond.get(key))
         else:
             te, tl2 = max(BWD_TOL, 4.0 * fe), max(BWD_TOL, 4.0 * fl2)
             if te > BWD_TOL or tl2 > BWD_TOL:
