@@ -16,7 +16,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np  # noqa: E402
 
-MAXB = 1 << 16
+MAXB = 1 << 18
 
 
 def operands(mode, M, N, K, G, epi, dev):
@@ -111,7 +111,7 @@ def analyse(path, verbose=False):
         ideal = flops / 157.3e12 * 1e6
         # per-CU occupancy of the k-loop phase
         hw = t[:, 5]
-        cu_key = ((hw >> 32) & 0xf) * 4096 + ((hw >> 8) & 0xfff)  # xcc, (se, sh, cu)
+        cu_key = ((hw >> 32) & 0xf) * 256 + ((hw >> 8) & 0xff)  # XCC_ID, HW_ID[15:8] = (se, sh, cu)
         shares = np.zeros(5)
         spreads = []
         for c in np.unique(cu_key):

@@ -40,7 +40,8 @@ VARIANTS = {
     # phase ablations of the fp16-operand GEMM loop (results are WRONG by construction: timing only)
     'abl_noload': ['-DSM3_ABL_NOLOAD=1'], 'abl_nostore': ['-DSM3_ABL_NOSTORE=1'], 'abl_nomfma': ['-DSM3_ABL_NOMFMA=1'],
     # per-workgroup phase timestamps of the GEMM kernel (scripts/gemm_trace.py) / static wave priority by residency slot
-    'trace': ['-DSM3_TRACE=1'], 'prio1': ['-DSM3_PRIO=1'], 'prio2': ['-DSM3_PRIO=2'],
+    'trace': ['-DSM3_TRACE=1'], 'prio1': ['-DSM3_PRIO=1'], 'prio2': ['-DSM3_PRIO=2'], 'stagger': ['-DSM3_STAGGER=1'],
+    'trace_stagger': ['-DSM3_TRACE=1', '-DSM3_STAGGER=1'],
     'abl_noepi': ['-DSM3_ABL_NOEPI=1'], 'abl_loop_only_mfma': ['-DSM3_ABL_NOLOAD=1', '-DSM3_ABL_NOSTORE=1', '-DSM3_ABL_NOEPI=1'],
 }
 

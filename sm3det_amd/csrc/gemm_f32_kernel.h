@@ -704,6 +704,16 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
     for (int q = 0; q < NP; q++) load_piece(sa0, sb0, q, min(1, nk - 1), true);
   }
   __syncthreads();
+#ifdef SM3_STAGGER  // measurement build only: the workgroups of the first dispatch round start their k-loops a third of a
+  {                  // tile-time apart per residency slot (tests whether co-resident workgroups run in lockstep)
+    const unsigned lb = blockIdx.x + gridDim.x * blockIdx.z;
+    if (lb < 768u) {
+      const long long wait = (long long)((lb >> 8) % 3u) * nk * (BK * TI * TJ * 32);  // cls x MFMA cycles of the tile alone
+      const long long t_in = __builtin_amdgcn_s_memtime();
+      while ((long long)__builtin_amdgcn_s_memtime() - t_in < wait) __builtin_amdgcn_s_sleep(32);
+    }
+  }
+#endif
   SM3_TR(1);
 #ifdef SM3_TRACE
   if (p.trace && tid == 0) p.trace[((size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.z) * 8 + 6] = (unsigned long long)nk;
