@@ -134,7 +134,7 @@ def analyse(path, verbose=False):
             if len(grp) >= 2:
                 spreads.append((grp[:, 2].max() - grp[:, 2].min()) / max(np.median(grp[:, 2] - grp[:, 1]), 1))
         shares /= shares.sum()
-        nkm = np.median(t[:, 6])
+        nkm = np.median(t[:, 6] & 0xffffffff)
         print(f'{names[mode]} {M}x{N}x{K} g{G} e{epi} x{cnt} | {t.shape[0]} | {us(span_c):.1f} ({ev_us}) | {ideal:.1f} | '
               f'{us(pro):.1f} / {us(loop):.1f} / {us(fix):.1f} / {us(epi_c):.1f} | '
               f'{shares[0]:.2f} {shares[1]:.2f} {shares[2]:.2f} {shares[3] + shares[4]:.2f} | '

@@ -169,3 +169,27 @@ class RandomSampler:
 @BBOX_SAMPLERS.register_module()
 class RRandomSampler(RandomSampler):
     """mmrotate/core/bbox/samplers/rotate_random_sampler.py:10 -- same rule on rotated boxes"""
+
+
+@BBOX_ASSIGNERS.register_module()
+class ATSSAssigner:
+    """mmdet 2.x ``ATSSAssigner`` by ``type`` string (``local_configs/main_SM3Det.py:146``: ``topk=9``) -- SURVEY.md 8(f) row 3.
+    mmdet code the reference does not vendor: restated in ``sm3det_amd/gfl_losses.py::atss_assign`` (fixed-shape, no host
+    loop over the gts, no sync), **parity unpinned**; ``tests/test_gfl_loss_cpu.py`` pins it on the oracle's second
+    restatement in mmdet's indexing form.  Pure PyTorch: the SAR head assigns 21 824 anchors x <= a few dozen gts per image."""
+
+    def __init__(self, topk, iou_calculator=dict(type='BboxOverlaps2D'), ignore_iof_thr=-1, alpha=None, **kwargs):
+        if iou_calculator.get('type', 'BboxOverlaps2D') != 'BboxOverlaps2D':
+            raise NotImplementedError(f"ATSSAssigner: iou_calculator {iou_calculator.get('type')}")
+        if ignore_iof_thr > 0:
+            raise NotImplementedError('ignore_iof_thr > 0 (crowd regions) is not used by any SM3Det config')
+        if alpha is not None:
+            raise NotImplementedError('ATSSAssigner(alpha=...) is the DDOD cost form (needs cls_scores / bbox_preds)')
+        self.topk = int(topk)
+
+    def assign(self, bboxes, num_level_bboxes, gt_bboxes, gt_bboxes_ignore=None, gt_labels=None, valid=None):
+        from .gfl_losses import atss_assign
+        if gt_bboxes_ignore is not None:
+            raise NotImplementedError('gt_bboxes_ignore')
+        gt_inds, max_ov, labels = atss_assign(bboxes, list(num_level_bboxes), gt_bboxes, gt_labels, self.topk, valid)
+        return AssignResult(gt_bboxes.size(0), gt_inds, max_ov, labels)

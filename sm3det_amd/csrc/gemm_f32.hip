@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
 }
 
 // ---- configuration: tile shape, k-step, split-K ---------------------------------------------------------------
-constexpr int COUNTER_SLOTS = 1 << 16;
+constexpr int COUNTER_SLOTS = kCounterSlots;  // the 16 top slots are the persistent launches' item queue
 
 struct Cfg {
   int tile, bk, splits, fixup;
@@ -216,6 +216,13 @@ struct Cfg {
 };
 
 inline int pad_to(int n, int b) { return (n + b - 1) / b * b; }
+
+// workgroups per CU the kernel's launch bounds ask for (gemm_f32_kernel.h: occupancy<>)
+inline int resident_per_cu(int tile, int bk, bool f16) {
+  static const int titj[6] = {4, 3, 3, 6, 6, 2};
+  if (f16) return bk == 64 ? 2 : SM3_F16_OCC;
+  return (titj[tile] >= 6 || bk == 32) ? 2 : (titj[tile] >= 3 ? 3 : 4);
+}
 
 // blocks -> rounds of 256 CUs actually paid for / rounds of work (>= 1): the matrix pipes of a CU are shared by its
 // resident workgroups, so a launch costs as many tile-times as the fullest CU holds
@@ -276,7 +283,7 @@ Cfg choose_cfg(const sm3_gemm_desc* d) {
       const long slots = (long)((d->M + bm - 1) / bm + (d->group_offsets ? G : 0)) * ((d->N + bn - 1) / bn);
       const double waste = (double)pad_to(d->N, bn) / d->N;
       for (int s = 1; s <= 8; s++) {
-        if (s > 1 && (!have_counters || slots > COUNTER_SLOTS || d->splits == 1 || tiles >= kNumCU || kt < 24 ||
+        if (s > 1 && (!have_counters || slots > COUNTER_SLOTS - 16 || d->splits == 1 || tiles >= kNumCU || kt < 24 ||
                       kt / s < 6 || t_tile >= 0))
           break;
         const double pc = (double)tiles * s / kNumCU;
@@ -296,7 +303,7 @@ Cfg choose_cfg(const sm3_gemm_desc* d) {
     const int ktc = d->K / c.bk;
     const long tiles = (long)c.ntm * c.ntn;
     int s = 1;
-    if (have_counters && tiles <= COUNTER_SLOTS) {
+    if (have_counters && tiles <= COUNTER_SLOTS - 16) {
       s = best_s;
       if (d->splits > 1) s = d->splits;
       if (t_splits) s = t_splits;
@@ -347,7 +354,7 @@ Cfg choose_cfg(const sm3_gemm_desc* d) {
   c.ntm = (d->M + c.bm - 1) / c.bm;
   c.splits = t_splits ? t_splits : best_s;
   const long tiles = (long)c.ntm * c.ntn * G;
-  c.fixup = (c.splits > 1 && ((tune >> 16) & 1) && have_counters && tiles <= COUNTER_SLOTS) ? 1 : 0;
+  c.fixup = (c.splits > 1 && ((tune >> 16) & 1) && have_counters && tiles <= COUNTER_SLOTS - 16) ? 1 : 0;
   return c;
 }
 
@@ -460,13 +467,35 @@ int sm3_gemm_f32(const sm3_gemm_desc* d, void* workspace, size_t workspace_bytes
   }
   if (d->M == 0) return SM3_OK;
   dim3 grid(c.ntn * c.ntm, 1, c.splits);
+  // Persistent form: with more tiles than the chip holds workgroups at once, launch exactly the resident set and let it
+  // walk the tiles (gemm_f32_kernel.h, "work items").  SM3_GEMM_PERSIST=0 keeps one workgroup per tile (A/B runs).
+  bool persist = false;
+  {
+    static const int enabled = [] { const char* e = getenv("SM3_GEMM_PERSIST"); return (e && e[0] == '0') ? 0 : 1; }();
+    const int resident = kNumCU * resident_per_cu(c.tile, c.bk, d->compute == 1);
+    const bool have = d->compute == 1 ? (d->io != 0 && has_persistent_h16(d->mode, d->epilogue, c.tile, c.bk, d->io))
+                                      : has_persistent_f32(c.tile, c.bk);
+    if (enabled && have && c.splits == 1 && d->counters != nullptr && (long)c.ntn * c.ntm > resident) {
+      persist = true;
+      p.total_tiles = c.ntn * c.ntm;
+      grid = dim3(resident, 1, 1);
+    }
+  }
   int rc;
-  if (d->compute == 1)
+  if (persist) {
+    if (d->compute == 1)
+      rc = d->mode == MODE_NT ? launch_nt_h16_p(p, d->epilogue, c.tile, c.bk, d->io, grid, st)
+                              : launch_nn_h16_p(p, d->epilogue, c.tile, c.bk, d->io, grid, st);
+    else
+      rc = d->mode == MODE_NT ? launch_nt_p(p, d->epilogue, c.tile, c.bk, grid, st)
+                              : launch_nn_p(p, d->epilogue, c.tile, c.bk, grid, st);
+  } else if (d->compute == 1) {
     rc = d->mode == MODE_NT ? launch_nt16(p, d->epilogue, c.tile, c.bk, d->io, grid, st)
                             : launch_nn16(p, d->epilogue, c.tile, c.bk, d->io, grid, st);
-  else
+  } else {
     rc = d->mode == MODE_NT ? launch_nt(p, d->epilogue, c.tile, c.bk, 0, grid, st)
                             : launch_nn(p, d->epilogue, c.tile, c.bk, 0, grid, st);
+  }
   if (rc) return rc;
   if (cb) {
     dim3 rg((d->N + 63) / 64, c.groups);

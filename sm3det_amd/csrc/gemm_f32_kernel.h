@@ -51,6 +51,12 @@ constexpr int NTHREADS = 256;
 // EPI codes (must match include/sm3det_hip.h)
 constexpr int EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_BIAS_SCALE_RES = 3, EPI_GELU_BWD = 4;
 constexpr int EPI_BIAS_RELU = 5;
+// persistent launches: 16 words at the top of the ticket-counter array (sm3_gemm_f32_counter_slots() ints) hold the item
+// queue -- one head per XCD (a workgroup draws items of its own residue mod 8: hardware block b runs on XCD b % 8, and the
+// tile remap keeps consecutive logical tiles on one XCD for L2 reuse of the shared operand) -- and the count of workgroups
+// that have left; the split-K tickets use the slots below
+constexpr int kCounterSlots = 1 << 16;
+constexpr int kPersistQueueSlot = kCounterSlots - 16;
 
 struct GemmParams {
   const float* A;
@@ -70,6 +76,7 @@ struct GemmParams {
   int kTilesPerSplit;  // NT/NN: k-tiles per slice
   float* slabs;        // fixup: [tile][split][BM*BN]
   int* counters;       // fixup: one ticket counter per tile, zero on entry, zero on exit
+  int total_tiles;     // PERSIST instantiations: grid.x workgroups walk this many items (first blockIdx.x, then a queue)
   // epilogue operands
   const float* bias;      // [N] (per group)
   const float* aux_in;    // EPI_GELU_BWD: gelu'(h)[M,N];  EPI_BIAS_SCALE_RES: residual[M,N]
@@ -96,7 +103,7 @@ struct GemmParams {
 #ifdef SM3_TRACE
 #define SM3_TR(i)                                                                                    \
   do {                                                                                               \
-    if (p.trace && threadIdx.x == 0)                                                                 \
+    if (p.trace && threadIdx.x == 0 && sm3_first_pass)                                               \
       p.trace[((size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.z) * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
   } while (0)
 #else
@@ -178,8 +185,9 @@ __device__ __forceinline__ void gelu_erf_both(float h, float& y, float& dy) {
 // output, GELU', their gradient) are fp16: half the bytes of the launches that move them.
 constexpr int IO_A16 = 1, IO_B16 = 2, IO_C16 = 4, IO_X16 = 8;  // A operand, B operand, C output, aux_in / aux_out
 
-template <int MODE, int EPI, int BK, class TL, int GATHER, int F16 = 0, int CSUM = 0, int IO = 0>
+template <int MODE, int EPI, int BK, class TL, int GATHER, int F16 = 0, int CSUM = 0, int IO = 0, int PERSIST = 0>
 __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32_kernel(GemmParams p) {
+  static_assert(!PERSIST || (MODE != MODE_TN && !GATHER), "persistent form: NT / NN without GATHER");
   constexpr int BM = TL::BM, BN = TL::BN, TI = TL::TI, TJ = TL::TJ, WN = TL::WN, WM = TL::WM;
   constexpr bool A16 = (IO & IO_A16) != 0, B16 = (IO & IO_B16) != 0, C16 = (IO & IO_C16) != 0, X16 = (IO & IO_X16) != 0;
   static_assert(IO == 0 || (F16 && !GATHER), "fp16 storage only with fp16 operands");
@@ -218,6 +226,8 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
   const int lane = tid & 63;
   const int wave = tid >> 6;
 #ifdef SM3_TRACE
+  bool sm3_first_pass = true;  // the timestamps describe the workgroup's first item
+  unsigned sm3_items = 0;
   SM3_TR(0);
   if (p.trace && tid == 0) {
     unsigned long long* tr = p.trace + ((size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.z) * 8;
@@ -240,87 +250,35 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
   const int l31 = lane & 31;
   const int lh = lane >> 5;
 
-  // ---- XCD-aware remap of the linear block id (speed only): consecutive logical tiles share an XCD ----------
+  // ---- work items ------------------------------------------------------------------------------------------------
+  // One item = one output tile (x one k-slice: blockIdx.z).  Plain launches run one item per workgroup (grid.x = items).
+  // PERSISTENT launches (PERSIST instantiations: NT / NN without GATHER, no k-slices): grid.x resident workgroups walk the items --
+  // the first is blockIdx.x, the following ones come from a device-side queue (one relaxed atomic per item, fetched a
+  // whole k-loop ahead of its use) -- and the operands of the next item's first k-tile are requested INSIDE the epilogue
+  // of the current one (after its first 32x32 accumulator tile has been staged: those registers take the data), so that neither the workgroup launch, nor the group look-up, nor the first HBM round trip of a
+  // tile (3-14 us under load, measured per workgroup with the `trace` build: profiles/r04/gemm_trace_*.txt) is exposed
+  // after the first item, and the store drain of an epilogue overlaps the next k-loop.
+  // PERSIST is a template flag: the plain instantiations keep exactly the register budget they had (the item loop folds
+  // away); the persistent ones carry the next item's state across the epilogue.
+  constexpr bool CAN_PERSIST = PERSIST != 0;
+  constexpr bool persist = CAN_PERSIST;
+  const int nitems = persist ? p.total_tiles : (int)gridDim.x;
   const int ntn = (p.N + BN - 1) / BN;
-  int bid = blockIdx.x;
-  {
-    const int nblk = gridDim.x;
-    const int q = nblk / kNumXCD, r = nblk % kNumXCD;
-    const int xcd = bid % kNumXCD, idx = bid / kNumXCD;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int tile_n = bid % ntn;
-  const int tile_m = bid / ntn;
+  // group offsets of a grouped NT / NN launch in ONE vector load: lane l holds offsets[l] and the tile -> group look-up is
+  // scalar ALU over v_readlane (the look-up used to issue up to 2 * G dependent scalar loads per workgroup)
+  const bool off_in_reg = MODE != MODE_TN && p.offsets != nullptr && p.num_groups < 64;
+  int off_v = 0;
+  if (off_in_reg) off_v = p.offsets[min(lane, p.num_groups)];
 
-  // ---- group / row-range / k-slice resolution ---------------------------------------------------------------
+  // state of the current item (block-uniform)
+  int bid = 0, tile_n = 0, tile_m = 0;
   int g = 0, split = 0;
-  int row0, row_end;  // NT/NN: rows of A and C handled by this block; TN: reduction rows [row0,row_end)
-  int m0;             // first output row of this tile
-  if (MODE == MODE_TN) {
-    g = blockIdx.z / p.splits;
-    split = blockIdx.z - g * p.splits;
-    int seg0 = 0, seg1 = p.K;
-    if (p.offsets) {
-      seg0 = p.offsets[g];
-      seg1 = p.offsets[g + 1];
-    }
-    const int cnt = seg1 - seg0;
-    int chunk = (cnt + p.splits - 1) / p.splits;
-    chunk = (chunk + BK - 1) / BK * BK;
-    // slices whose first rows sit a large power of two apart start on the same HBM channels and crawl (measured: 256
-    // slices of 512 rows: 287 us, 192 or 341 slices: 121 / 162 us): keep the slice length off multiples of 128 rows
-    if (p.splits > 1 && (chunk & 127) == 0) chunk += BK;
-    row0 = min(seg1, seg0 + split * chunk);
-    row_end = min(seg1, row0 + chunk);
-    m0 = tile_m * BM;
-  } else {
-    split = blockIdx.z;
-    if (p.offsets) {
-      int base = 0;
-      bool found = false;
-      for (int gg = 0; gg < p.num_groups; gg++) {
-        const int o0 = p.offsets[gg], o1 = p.offsets[gg + 1];
-        const int nt = (o1 - o0 + BM - 1) / BM;
-        if (tile_m < base + nt) {
-          g = gg;
-          row0 = o0 + (tile_m - base) * BM;
-          row_end = o1;
-          found = true;
-          break;
-        }
-        base += nt;
-      }
-      if (!found) return;  // surplus block of a ragged launch (all slices of it leave: no ticket is ever drawn)
-    } else {
-      row0 = tile_m * BM;
-      row_end = p.M;
-      if (row0 >= row_end) return;
-    }
-    m0 = row0;
-  }
-  const int n0 = tile_n * BN;
+  int row0 = 0, row_end = 0;  // NT/NN: rows of A and C handled by this item; TN: reduction rows [row0,row_end)
+  int m0 = 0, n0 = 0;         // first output row / column of this tile
+  int nk = 0, kbase = 0;      // k-tiles of this item, first k-tile
+  bool valid = true;          // false: surplus item of a ragged grouped launch (no rows)
   const float* __restrict__ Ag = p.A;
-  const float* __restrict__ Bg = p.B + (MODE == MODE_TN ? 0 : (long)g * p.strideB);
-
-  int nk, kbase = 0;  // k-tiles of this block, first k-tile
-  if (MODE == MODE_TN) {
-    nk = (max(row_end - row0, 0) + BK - 1) / BK;
-  } else {
-    nk = p.K / BK;
-    if (p.splits > 1) {
-      kbase = split * p.kTilesPerSplit;
-      nk = max(0, min(p.kTilesPerSplit, nk - kbase));
-    }
-  }
-
-  // block-uniform by construction; readfirstlane makes it provable, so loop counters and k-offsets live in SGPRs (the
-  // TN kernel kept its trip count in a spilled VGPR and drained vmcnt(0) every iteration to reload it)
-  nk = __builtin_amdgcn_readfirstlane(nk);
-  kbase = __builtin_amdgcn_readfirstlane(kbase);
-  row0 = __builtin_amdgcn_readfirstlane(row0);
-  row_end = __builtin_amdgcn_readfirstlane(row_end);
-  m0 = __builtin_amdgcn_readfirstlane(m0);
-  g = __builtin_amdgcn_readfirstlane(g);
+  const float* __restrict__ Bg = p.B;
 
   // ---- loaders ----------------------------------------------------------------------------------------------
   // transposed loader (source rows k-contiguous): thread -> (row t_r + T_ROWS i, k quad t_kq)
@@ -337,7 +295,7 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
   constexpr int KP = BK / 2;   // k-pairs = MFMA groups per k-tile
   static_assert(NP <= KP, "piece schedule: one load and one store slot per k-pair");
 
-  // Per-thread source pointers and LDS offsets, computed once.  Out-of-range rows / columns are CLAMPED to a valid
+  // Per-thread source offsets (per item) and LDS offsets (once).  Out-of-range rows / columns are CLAMPED to a valid
   // address instead of branched around (the garbage they bring only reaches output rows/columns the epilogue masks);
   // reduction rows past the segment end in TN are zeroed by a select after the load.
   // Addresses: GATHER keeps one 64-bit pointer per piece; the plain GEMMs split every address into a block-uniform base
@@ -357,130 +315,67 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
   int gy[PA], gx[PA];    // GATHER (NT/NN): grid coordinates of this thread's A rows
   unsigned m9[PA];       // GATHER (NT/NN): bit t set <=> tap t of this row reads a pixel inside the image
   int tn_tap = 0;        // GATHER (TN): the tap this N-tile belongs to (cC % BN == 0)
+  // item-independent part: where a piece lands in the LDS image
 #pragma unroll
   for (int i = 0; i < PA; i++) {
     gy[i] = gx[i] = 0;
     m9[i] = 0;
     ka[i] = 0;
+    ha[i] = 0;
+    pa[i] = nullptr;
     if (A_TRANS) {
       const int rl = t_r + T_ROWS * i;
       sa[i] = (4 * t_kq) * LDA_S + min(rl, BM - 1);  // surplus lanes repeat row BM-1 (same data, same slot)
       ha[i] = ((t_kq >> 1) * LDA16 + min(rl, BM - 1)) * 4 + 2 * (t_kq & 1);
-      const int r = min(row0 + min(rl, BM - 1), row_end - 1);
-      if (GATHER) {
-        const unsigned t = fast_div((unsigned)r, (unsigned)p.rW, p.mRW);
-        gx[i] = r - (int)t * p.rW;
-        const unsigned b = fast_div(t, (unsigned)p.rH, p.mRH);
-        gy[i] = (int)t - (int)b * p.rH;
-        pa[i] = Ag + (long)b * p.sH * p.sW * p.cC + 4 * t_kq;
-        // Implicit im2col without per-load coordinate arithmetic: source pixel = (ay + uy(dy) - 1, ax + ux(dx) - 1) with a
-        // per-row part (ay, ax) and a per-tap part that is the same for every lane:
-        //   forward / weight gradient (cT = 0): ay = gy * stride,          uy(d) = d
-        //   input gradient, stride 1:           ay = gy,                   uy(d) = 2 - d
-        //   input gradient, stride 2:           ay = (gy + 1) >> 1,        uy(d) = 1 - d / 2   (taps of the wrong parity
-        //                                                                                      are masked in m9)
-        // so the address is  [base - (sW + 1) * cC]  +  lane offset (fixed)  +  scalar tap offset, and a lane whose tap
-        // falls outside the image swaps its offset for one beyond the descriptor's extent: the load returns 0.
-        const int ay = p.cT ? (p.cS == 2 ? (gy[i] + 1) >> 1 : gy[i]) : gy[i] * p.cS;
-        const int ax = p.cT ? (p.cS == 2 ? (gx[i] + 1) >> 1 : gx[i]) : gx[i] * p.cS;
-        oa[i] = (unsigned)(((((long)b * p.sH + ay) * p.sW + ax) * p.cC + 4 * t_kq) * 4);
-        m9[i] = 0;
-#pragma unroll
-        for (int tp = 0; tp < 9; tp++) {
-          const int sy = gather_coord(gy[i], tp / 3, p.cS, p.cT, p.sH);
-          const int sx = gather_coord(gx[i], tp % 3, p.cS, p.cT, p.sW);
-          if (sy >= 0 && sx >= 0) m9[i] |= 1u << tp;
-        }
-      } else {
-        pa[i] = Ag + (long)r * p.lda + 4 * t_kq + (long)kbase * BK;
-        oa[i] = (unsigned)(((long)(r - row0) * p.lda + 4 * t_kq) * EA);
-      }
     } else {
       constexpr int QR = BM / 4;
       const int idx = tid + NTHREADS * i;
       const int kk = idx / QR, cq = idx - kk * QR;
       ka[i] = min(kk, BK - 1);  // surplus lanes (kk >= BK) repeat k-row BK-1: same data into the same slot
       sa[i] = min(kk, BK - 1) * LDA_S + 4 * cq;
-      pa[i] = Ag + min(m0 + 4 * cq, p.M - 4);
-      oa[i] = (unsigned)(((long)min(kk, BK - 1) * p.lda + min(m0 + 4 * cq, p.M - 4)) * 4);  // kk >= BK: lane without an element
       if (F16) {
         // F16: a piece is FOUR CONSECUTIVE k OF ONE COLUMN (four coalesced 4-byte loads, lanes along the columns), so
         // that it lands in the fp16 image as 8 contiguous bytes like a transposed piece; a piece of four columns at
         // one k would scatter 2-byte stores 16 B apart (8-way bank conflicts: measured 13.5 vs 9.4 ms per step)
         const int g4 = min(idx / BM, BK / 4 - 1), c = idx % BM;  // surplus units repeat the last k-quad
         ha[i] = ((g4 >> 1) * LDA16 + c) * 4 + 2 * (g4 & 1);
-        oa[i] = (unsigned)(((long)(4 * g4) * p.lda + min(m0 + c, p.M - 1)) * 4);
         if (A16) {
           // unit = (k-octet, column pair, k-quad parity), parity fastest: the two 8-byte LDS stores of 16 consecutive
           // lanes then spread over 16 banks (2-way) instead of 8 (column pairs are 32 B apart in the image)
           const int par = idx & 1, u = idx >> 1;
           const int g8 = min(u / (BM / 2), BK / 8 - 1), cc = 2 * (u % (BM / 2));
           ha[i] = (g8 * LDA16 + cc) * 4 + 2 * par;
-          oa[i] = (unsigned)(((long)(8 * g8 + 4 * par) * p.lda + min(m0 + cc, p.M - 2)) * 2);
         }
       }
     }
   }
-  if (MODE == MODE_TN) a_base = reinterpret_cast<const char*>(Ag) + (long)row0 * p.lda * EA;
-  else if (GATHER) a_base = reinterpret_cast<const char*>(Ag) - (long)(p.sW + 1) * p.cC * 4;
-  else a_base = reinterpret_cast<const char*>(Ag) + ((long)row0 * p.lda + (long)kbase * BK) * EA;
 #pragma unroll
   for (int i = 0; i < PB; i++) {
     kb[i] = 0;
+    hb[i] = 0;
+    pb[i] = nullptr;
     if (B_TRANS) {
       const int rl = t_r + T_ROWS * i;
       sb[i] = (4 * t_kq) * LDB_S + min(rl, BN - 1);
       hb[i] = ((t_kq >> 1) * LDB16 + min(rl, BN - 1)) * 4 + 2 * (t_kq & 1);
-      const int n = min(n0 + min(rl, BN - 1), p.N - 1);
-      pb[i] = Bg + (long)n * p.ldb + 4 * t_kq + (long)kbase * BK;
-      ob[i] = (unsigned)(((long)(n - n0) * p.ldb + 4 * t_kq) * 4);
     } else {
       constexpr int QR = BN / 4;
       const int idx = tid + NTHREADS * i;
       const int kk = idx / QR, cq = idx - kk * QR;
       kb[i] = min(kk, BK - 1);
       sb[i] = min(kk, BK - 1) * LDB_S + 4 * cq;
-      const int nc = min(n0 + 4 * cq, p.N - 4);
-      if (MODE == MODE_TN) {
-        if (GATHER) {
-          tn_tap = n0 / p.cC;
-          pb[i] = Bg + (nc - tn_tap * p.cC);  // channel offset inside the tap; the row part is added per load
-          // GATHER == 2 (rW % BK == 0: a k-tile of BK output positions lies inside one image row, so its first source
-          // pixel is the same for every lane): lane part = this lane's position inside the k-tile + channel offset
-          ob[i] = (unsigned)(((long)min(kk, BK - 1) * p.cS * p.cC + (nc - tn_tap * p.cC)) * 4);
+      if (F16) {
+        if (B16) {
+          const int par = idx & 1, u = idx >> 1;
+          const int g8 = min(u / (BN / 2), BK / 8 - 1), cc = 2 * (u % (BN / 2));
+          hb[i] = (g8 * LDB16 + cc) * 4 + 2 * par;
         } else {
-          pb[i] = Bg + nc;
-          ob[i] = (unsigned)(((long)min(kk, BK - 1) * p.ldb + nc) * 4);
+          const int g4 = min(idx / BN, BK / 4 - 1), c = idx % BN;
+          hb[i] = ((g4 >> 1) * LDB16 + c) * 4 + 2 * (g4 & 1);
         }
-      } else {  // NN: B[K,N] rows are k
-        pb[i] = Bg + (long)min(kk, BK - 1) * p.ldb + nc + (GATHER ? 0 : (long)kbase * BK * p.ldb);
-        ob[i] = (unsigned)(((long)min(kk, BK - 1) * p.ldb + nc) * 4);
       }
     }
   }
-  if (F16 && !B_TRANS) {
-#pragma unroll
-    for (int i = 0; i < PB; i++) {
-      const int idx = tid + NTHREADS * i;
-      if (B16) {
-        const int par = idx & 1, u = idx >> 1;
-        const int g8 = min(u / (BN / 2), BK / 8 - 1), cc = 2 * (u % (BN / 2));
-        hb[i] = (g8 * LDB16 + cc) * 4 + 2 * par;
-        ob[i] = (unsigned)(((long)(8 * g8 + 4 * par) * p.ldb + min(n0 + cc, p.N - 2)) * 2);
-      } else {
-        const int g4 = min(idx / BN, BK / 4 - 1), c = idx % BN;
-        hb[i] = ((g4 >> 1) * LDB16 + c) * 4 + 2 * (g4 & 1);
-        ob[i] = (unsigned)(((long)(4 * g4) * p.ldb + min(n0 + c, p.N - 1)) * 4);
-      }
-    }
-  }
-  if (MODE == MODE_NT) b_base = reinterpret_cast<const char*>(Bg + (long)n0 * p.ldb + (long)kbase * BK);
-  else if (MODE == MODE_NN) b_base = reinterpret_cast<const char*>(Bg + (GATHER ? 0 : (long)kbase * BK * p.ldb));
-  else if (GATHER == 2) b_base = reinterpret_cast<const char*>(Bg) - (long)(p.sW + 1) * p.cC * 4;
-  else b_base = reinterpret_cast<const char*>(Bg) + (long)row0 * p.ldb * EB;
-  // piece q in [0, NP): q < PA -> A piece q, else B piece q - PA.  tail == false (the bulk of the k-loop): tile kt is a
-  // complete tile strictly before the last one, so no clamp and no select is issued; tail == true: the last steps, where
-  // kt may be clamped and TN reduction rows past the segment end are zeroed.
   auto make_rsrc = [](const char* base, long valid_floats, int esize) {
     // readfirstlane: base and extent are block-uniform by construction, this makes them provably so (no waterfall
     // loop).  The extent is the operand's valid span seen from the base: a stray offset reads 0 instead of faulting.
@@ -491,22 +386,217 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
     return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, nrec,
                                              0x00020000);
   };
-  long a_valid, b_valid;
-  if (MODE == MODE_TN) {
-    a_valid = (long)(row_end - 1 - row0) * p.lda + p.M;
-    b_valid = (long)(row_end - 1 - row0) * p.ldb + p.N;
-    if (row_end <= row0) a_valid = b_valid = 0;
-    if (GATHER == 2) b_valid = (long)(p.K / (p.rH * p.rW)) * p.sH * p.sW * p.cC + (long)(p.sW + 1) * p.cC;
-  } else if (GATHER) {
-    // gathered tensor: (M / (rH * rW)) images of sH x sW x cC, seen from the shifted base; NN weights: cC rows of ldb
-    a_valid = (long)(p.M / (p.rH * p.rW)) * p.sH * p.sW * p.cC + (long)(p.sW + 1) * p.cC;
-    b_valid = MODE == MODE_NT ? (long)(p.N - 1 - n0) * p.ldb + (p.K - (long)kbase * BK) : (long)p.cC * p.ldb;
-  } else {
-    a_valid = (long)(row_end - 1 - row0) * p.lda + (p.K - (long)kbase * BK);
-    b_valid = MODE == MODE_NT ? (long)(p.N - 1 - n0) * p.ldb + (p.K - (long)kbase * BK)
-                              : (long)(p.K - (long)kbase * BK - 1) * p.ldb + p.N;
-  }
-  const __amdgpu_buffer_rsrc_t a_rsrc = make_rsrc(a_base, a_valid, EA), b_rsrc = make_rsrc(b_base, b_valid, EB);
+  __amdgpu_buffer_rsrc_t a_rsrc, b_rsrc;
+
+  // ---- everything that depends on the item: tile coordinates, group, row range, k-slice, source offsets, descriptors ----
+  auto setup_item = [&](int item) {
+    // XCD-aware remap of the linear item id (speed only): consecutive logical tiles share an XCD (hardware block b runs
+    // on XCD b % 8; a persistent workgroup's items keep its residue: grid.x is a multiple of 8 there)
+    bid = item;
+    {
+      const int nblk = nitems;
+      const int q = nblk / kNumXCD, r = nblk % kNumXCD;
+      const int xcd = bid % kNumXCD, idx = bid / kNumXCD;
+      bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    tile_n = bid % ntn;
+    tile_m = bid / ntn;
+    valid = true;
+    g = 0;
+    // group / row-range / k-slice resolution
+    if (MODE == MODE_TN) {
+      g = blockIdx.z / p.splits;
+      split = blockIdx.z - g * p.splits;
+      int seg0 = 0, seg1 = p.K;
+      if (p.offsets) {
+        seg0 = p.offsets[g];
+        seg1 = p.offsets[g + 1];
+      }
+      const int cnt = seg1 - seg0;
+      int chunk = (cnt + p.splits - 1) / p.splits;
+      chunk = (chunk + BK - 1) / BK * BK;
+      // slices whose first rows sit a large power of two apart start on the same HBM channels and crawl (measured: 256
+      // slices of 512 rows: 287 us, 192 or 341 slices: 121 / 162 us): keep the slice length off multiples of 128 rows
+      if (p.splits > 1 && (chunk & 127) == 0) chunk += BK;
+      row0 = min(seg1, seg0 + split * chunk);
+      row_end = min(seg1, row0 + chunk);
+      m0 = tile_m * BM;
+    } else {
+      split = blockIdx.z;
+      if (p.offsets) {
+        int base = 0;
+        bool found = false;
+        int o0 = off_in_reg ? __builtin_amdgcn_readlane(off_v, 0) : p.offsets[0];
+        for (int gg = 0; gg < p.num_groups; gg++) {
+          const int o1 = off_in_reg ? __builtin_amdgcn_readlane(off_v, gg + 1) : p.offsets[gg + 1];
+          const int nt = (o1 - o0 + BM - 1) / BM;
+          if (tile_m < base + nt) {
+            g = gg;
+            row0 = o0 + (tile_m - base) * BM;
+            row_end = o1;
+            found = true;
+            break;
+          }
+          base += nt;
+          o0 = o1;
+        }
+        if (!found) {  // surplus item of a ragged launch: no rows (a plain launch leaves, see below)
+          valid = false;
+          row0 = row_end = 0;
+        }
+      } else {
+        row0 = tile_m * BM;
+        row_end = p.M;
+        if (row0 >= row_end) {
+          valid = false;
+          row0 = row_end = 0;
+        }
+      }
+      m0 = row0;
+    }
+    n0 = tile_n * BN;
+    Bg = p.B + (MODE == MODE_TN ? 0 : (long)g * p.strideB);
+    kbase = 0;
+    if (MODE == MODE_TN) {
+      nk = (max(row_end - row0, 0) + BK - 1) / BK;
+    } else {
+      nk = p.K / BK;
+      if (p.splits > 1) {
+        kbase = split * p.kTilesPerSplit;
+        nk = max(0, min(p.kTilesPerSplit, nk - kbase));
+      }
+      if (!valid) nk = 0;
+    }
+    // block-uniform by construction; readfirstlane makes it provable, so loop counters and k-offsets live in SGPRs (the
+    // TN kernel kept its trip count in a spilled VGPR and drained vmcnt(0) every iteration to reload it)
+    nk = __builtin_amdgcn_readfirstlane(nk);
+    kbase = __builtin_amdgcn_readfirstlane(kbase);
+    row0 = __builtin_amdgcn_readfirstlane(row0);
+    row_end = __builtin_amdgcn_readfirstlane(row_end);
+    m0 = __builtin_amdgcn_readfirstlane(m0);
+    n0 = __builtin_amdgcn_readfirstlane(n0);
+    g = __builtin_amdgcn_readfirstlane(g);
+#pragma unroll
+    for (int i = 0; i < PA; i++) {
+      if (A_TRANS) {
+        const int rl = t_r + T_ROWS * i;
+        const int r = min(row0 + min(rl, BM - 1), row_end - 1);
+        if (GATHER) {
+          const unsigned t = fast_div((unsigned)r, (unsigned)p.rW, p.mRW);
+          gx[i] = r - (int)t * p.rW;
+          const unsigned b = fast_div(t, (unsigned)p.rH, p.mRH);
+          gy[i] = (int)t - (int)b * p.rH;
+          pa[i] = Ag + (long)b * p.sH * p.sW * p.cC + 4 * t_kq;
+          // Implicit im2col without per-load coordinate arithmetic: source pixel = (ay + uy(dy) - 1, ax + ux(dx) - 1) with a
+          // per-row part (ay, ax) and a per-tap part that is the same for every lane:
+          //   forward / weight gradient (cT = 0): ay = gy * stride,          uy(d) = d
+          //   input gradient, stride 1:           ay = gy,                   uy(d) = 2 - d
+          //   input gradient, stride 2:           ay = (gy + 1) >> 1,        uy(d) = 1 - d / 2   (taps of the wrong parity
+          //                                                                                      are masked in m9)
+          // so the address is  [base - (sW + 1) * cC]  +  lane offset (fixed)  +  scalar tap offset, and a lane whose tap
+          // falls outside the image swaps its offset for one beyond the descriptor's extent: the load returns 0.
+          const int ay = p.cT ? (p.cS == 2 ? (gy[i] + 1) >> 1 : gy[i]) : gy[i] * p.cS;
+          const int ax = p.cT ? (p.cS == 2 ? (gx[i] + 1) >> 1 : gx[i]) : gx[i] * p.cS;
+          oa[i] = (unsigned)(((((long)b * p.sH + ay) * p.sW + ax) * p.cC + 4 * t_kq) * 4);
+          m9[i] = 0;
+#pragma unroll
+          for (int tp = 0; tp < 9; tp++) {
+            const int sy = gather_coord(gy[i], tp / 3, p.cS, p.cT, p.sH);
+            const int sx = gather_coord(gx[i], tp % 3, p.cS, p.cT, p.sW);
+            if (sy >= 0 && sx >= 0) m9[i] |= 1u << tp;
+          }
+        } else {
+          pa[i] = Ag + (long)r * p.lda + 4 * t_kq + (long)kbase * BK;
+          oa[i] = (unsigned)(((long)(r - row0) * p.lda + 4 * t_kq) * EA);
+        }
+      } else {
+        constexpr int QR = BM / 4;
+        const int idx = tid + NTHREADS * i;
+        const int kk = idx / QR, cq = idx - kk * QR;
+        pa[i] = Ag + min(m0 + 4 * cq, p.M - 4);
+        oa[i] = (unsigned)(((long)min(kk, BK - 1) * p.lda + min(m0 + 4 * cq, p.M - 4)) * 4);  // kk >= BK: lane without an element
+        if (F16) {
+          const int g4 = min(idx / BM, BK / 4 - 1), c = idx % BM;  // surplus units repeat the last k-quad
+          oa[i] = (unsigned)(((long)(4 * g4) * p.lda + min(m0 + c, p.M - 1)) * 4);
+          if (A16) {
+            const int par = idx & 1, u = idx >> 1;
+            const int g8 = min(u / (BM / 2), BK / 8 - 1), cc = 2 * (u % (BM / 2));
+            oa[i] = (unsigned)(((long)(8 * g8 + 4 * par) * p.lda + min(m0 + cc, p.M - 2)) * 2);
+          }
+        }
+      }
+    }
+    if (MODE == MODE_TN) a_base = reinterpret_cast<const char*>(Ag) + (long)row0 * p.lda * EA;
+    else if (GATHER) a_base = reinterpret_cast<const char*>(Ag) - (long)(p.sW + 1) * p.cC * 4;
+    else a_base = reinterpret_cast<const char*>(Ag) + ((long)row0 * p.lda + (long)kbase * BK) * EA;
+#pragma unroll
+    for (int i = 0; i < PB; i++) {
+      if (B_TRANS) {
+        const int rl = t_r + T_ROWS * i;
+        const int n = min(n0 + min(rl, BN - 1), p.N - 1);
+        pb[i] = Bg + (long)n * p.ldb + 4 * t_kq + (long)kbase * BK;
+        ob[i] = (unsigned)(((long)(n - n0) * p.ldb + 4 * t_kq) * 4);
+      } else {
+        constexpr int QR = BN / 4;
+        const int idx = tid + NTHREADS * i;
+        const int kk = idx / QR, cq = idx - kk * QR;
+        const int nc = min(n0 + 4 * cq, p.N - 4);
+        if (MODE == MODE_TN) {
+          if (GATHER) {
+            tn_tap = n0 / p.cC;
+            pb[i] = Bg + (nc - tn_tap * p.cC);  // channel offset inside the tap; the row part is added per load
+            // GATHER == 2 (rW % BK == 0: a k-tile of BK output positions lies inside one image row, so its first source
+            // pixel is the same for every lane): lane part = this lane's position inside the k-tile + channel offset
+            ob[i] = (unsigned)(((long)min(kk, BK - 1) * p.cS * p.cC + (nc - tn_tap * p.cC)) * 4);
+          } else {
+            pb[i] = Bg + nc;
+            ob[i] = (unsigned)(((long)min(kk, BK - 1) * p.ldb + nc) * 4);
+          }
+        } else {  // NN: B[K,N] rows are k
+          pb[i] = Bg + (long)min(kk, BK - 1) * p.ldb + nc + (GATHER ? 0 : (long)kbase * BK * p.ldb);
+          ob[i] = (unsigned)(((long)min(kk, BK - 1) * p.ldb + nc) * 4);
+        }
+        if (F16) {
+          if (B16) {
+            const int par = idx & 1, u = idx >> 1;
+            const int g8 = min(u / (BN / 2), BK / 8 - 1), cc = 2 * (u % (BN / 2));
+            ob[i] = (unsigned)(((long)(8 * g8 + 4 * par) * p.ldb + min(n0 + cc, p.N - 2)) * 2);
+          } else {
+            const int g4 = min(idx / BN, BK / 4 - 1), c = idx % BN;
+            ob[i] = (unsigned)(((long)(4 * g4) * p.ldb + min(n0 + c, p.N - 1)) * 4);
+          }
+        }
+      }
+    }
+    if (MODE == MODE_NT) b_base = reinterpret_cast<const char*>(Bg + (long)n0 * p.ldb + (long)kbase * BK);
+    else if (MODE == MODE_NN) b_base = reinterpret_cast<const char*>(Bg + (GATHER ? 0 : (long)kbase * BK * p.ldb));
+    else if (GATHER == 2) b_base = reinterpret_cast<const char*>(Bg) - (long)(p.sW + 1) * p.cC * 4;
+    else b_base = reinterpret_cast<const char*>(Bg) + (long)row0 * p.ldb * EB;
+    long a_valid, b_valid;
+    if (MODE == MODE_TN) {
+      a_valid = (long)(row_end - 1 - row0) * p.lda + p.M;
+      b_valid = (long)(row_end - 1 - row0) * p.ldb + p.N;
+      if (row_end <= row0) a_valid = b_valid = 0;
+      if (GATHER == 2) b_valid = (long)(p.K / (p.rH * p.rW)) * p.sH * p.sW * p.cC + (long)(p.sW + 1) * p.cC;
+    } else if (GATHER) {
+      // gathered tensor: (M / (rH * rW)) images of sH x sW x cC, seen from the shifted base; NN weights: cC rows of ldb
+      a_valid = (long)(p.M / (p.rH * p.rW)) * p.sH * p.sW * p.cC + (long)(p.sW + 1) * p.cC;
+      b_valid = MODE == MODE_NT ? (long)(p.N - 1 - n0) * p.ldb + (p.K - (long)kbase * BK) : (long)p.cC * p.ldb;
+    } else {
+      a_valid = (long)(row_end - 1 - row0) * p.lda + (p.K - (long)kbase * BK);
+      b_valid = MODE == MODE_NT ? (long)(p.N - 1 - n0) * p.ldb + (p.K - (long)kbase * BK)
+                                : (long)(p.K - (long)kbase * BK - 1) * p.ldb + p.N;
+      if (!valid) a_valid = 0;
+    }
+    a_rsrc = make_rsrc(a_base, a_valid, EA);
+    b_rsrc = make_rsrc(b_base, b_valid, EB);
+  };
+  int item = blockIdx.x;
+  setup_item(item);
+  if (!valid && !persist) return;  // surplus block of a ragged plain launch (all slices of it leave: no ticket is ever drawn)
+  // piece q in [0, NP): q < PA -> A piece q, else B piece q - PA.  tail == false (the bulk of the k-loop): tile kt is a
+  // complete tile strictly before the last one, so no clamp and no select is issued; tail == true: the last steps, where
+  // kt may be clamped and TN reduction rows past the segment end are zeroed.
   auto ldg = [&](const __amdgpu_buffer_rsrc_t& rs, long soff, unsigned voff) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, (int)soff, 0);
@@ -683,41 +773,12 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
   };
 
   f32x16 acc[TI][TJ];
-#pragma unroll
-  for (int i = 0; i < TI; i++)
-#pragma unroll
-    for (int j = 0; j < TJ; j++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
   // Two register sets: while tile kt is multiplied out of LDS, the global loads of tile kt+2 are ISSUED into one set
   // (first k-pairs) and tile kt+1 -- loaded one iteration earlier, long landed -- is WRITTEN to the other LDS buffer
   // from the other set (last k-pairs), one piece between each group of MFMAs.  The matrix pipe never waits for address
   // arithmetic, a vmcnt drain or the LDS write pass; one barrier per k-step remains.
   f32x4 sa0[PA], sb0[PB], sa1[PA], sb1[PB];
-  if (nk > 0) {
-#pragma unroll
-    for (int q = 0; q < NP; q++) load_piece(sa0, sb0, q, 0, true);
-#pragma unroll
-    for (int q = 0; q < NP; q++) store_piece(sa0, sb0, q, 0, true);
-#pragma unroll
-    for (int q = 0; q < NP; q++) load_piece(sa0, sb0, q, min(1, nk - 1), true);
-  }
-  __syncthreads();
-#ifdef SM3_STAGGER  // measurement build only: the workgroups of the first dispatch round start their k-loops a third of a
-  {                  // tile-time apart per residency slot (tests whether co-resident workgroups run in lockstep)
-    const unsigned lb = blockIdx.x + gridDim.x * blockIdx.z;
-    if (lb < 768u) {
-      const long long wait = (long long)((lb >> 8) % 3u) * nk * (BK * TI * TJ * 32);  // cls x MFMA cycles of the tile alone
-      const long long t_in = __builtin_amdgcn_s_memtime();
-      while ((long long)__builtin_amdgcn_s_memtime() - t_in < wait) __builtin_amdgcn_s_sleep(32);
-    }
-  }
-#endif
-  SM3_TR(1);
-#ifdef SM3_TRACE
-  if (p.trace && tid == 0) p.trace[((size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.z) * 8 + 6] = (unsigned long long)nk;
-#endif
 
   auto k_step = [&](f32x4 (&ca)[PA], f32x4 (&cb)[PB], f32x4 (&na)[PA], f32x4 (&nb)[PB], int kt, bool tail) {
     // ca/cb hold tile kt+1 (to be stored), na/nb receive tile kt+2
@@ -820,6 +881,48 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
     }
     __syncthreads();
   };
+  // ---- the item loop (one pass for a plain launch) -----------------------------------------------------------------
+  // persistent queue: q_head[0..7] = items handed out per XCD residue beyond the first grid.x, q_head[8] = workgroups that
+  // have left; all zero on entry, the last workgroup to leave zeroes them again (the kernel boundary publishes that).
+  __shared__ int s_next_item;
+  int* q_head = persist ? p.counters + kPersistQueueSlot : nullptr;
+  if (nk > 0) {  // first k-tile of the first item (later items: requested before the previous item's epilogue)
+#pragma unroll
+    for (int q = 0; q < NP; q++) load_piece(sa0, sb0, q, 0, true);
+  }
+  for (;;) {
+    unsigned ticket = 0;
+    if (CAN_PERSIST && tid == 0)  // the NEXT item: in flight during this item's whole k-loop
+      ticket = __hip_atomic_fetch_add(q_head + (blockIdx.x & 7), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int i = 0; i < TI; i++)
+#pragma unroll
+      for (int j = 0; j < TJ; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    if (nk > 0) {
+#pragma unroll
+      for (int q = 0; q < NP; q++) store_piece(sa0, sb0, q, 0, true);
+#pragma unroll
+      for (int q = 0; q < NP; q++) load_piece(sa0, sb0, q, min(1, nk - 1), true);
+    }
+    __syncthreads();
+#ifdef SM3_STAGGER  // measurement build only: the workgroups of the first dispatch round start their k-loops a third of a
+    {                // tile-time apart per residency slot (tests whether co-resident workgroups run in lockstep)
+      const unsigned lb = blockIdx.x + gridDim.x * blockIdx.z;
+      if (lb < 768u && item == (int)blockIdx.x && !persist) {
+        const long long wait = (long long)((lb >> 8) % 3u) * nk * (BK * TI * TJ * 32);  // cls x MFMA cycles of the tile alone
+        const long long t_in = __builtin_amdgcn_s_memtime();
+        while ((long long)__builtin_amdgcn_s_memtime() - t_in < wait) __builtin_amdgcn_s_sleep(32);
+      }
+    }
+#endif
+    SM3_TR(1);
+#ifdef SM3_TRACE
+    if (p.trace && tid == 0 && sm3_first_pass)
+      p.trace[((size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.z) * 8 + 6] = (unsigned long long)nk;
+#endif
+
   // Two steps per iteration WITHOUT a branch between them (a conditional second step made hipcc drain vmcnt(0) at the
   // loop header).  The bulk loop carries no clamp / select / zeroing at all; the last three or four steps run the
   // `tail` variant, which also absorbs an odd nk by one extra step on an all-zero stage (see store_piece).
@@ -891,12 +994,32 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
     return;
   }
 #endif
+  // ---- next item: its tile set-up and the request for its first k-tile go out INSIDE this item's epilogue, right after
+  // the first 32x32 accumulator tile has been staged (its 16 registers are dead then and receive the loads, so the
+  // epilogue's peak register use does not grow); the loads land in sa0 / sb0 while the rest of the epilogue runs.  The LDS
+  // image itself is free only after the epilogue's staging.
+  const int e_m0 = m0, e_n0 = n0, e_row_end = row_end, e_g = g, e_tile_m = tile_m, e_bid = bid, e_split = split;
+  bool has_next = false;
+  auto next_item = [&]() {
+    if (tid == 0) s_next_item = (int)gridDim.x + (int)(blockIdx.x & 7) + 8 * (int)ticket;  // same residue mod 8 (grid.x % 8 == 0)
+    __syncthreads();
+    const int nxt = s_next_item;
+    has_next = nxt < nitems;
+    if (has_next) {
+      item = nxt;
+      setup_item(item);
+      if (nk > 0) {
+#pragma unroll
+        for (int q = 0; q < NP; q++) load_piece(sa0, sb0, q, 0, true);
+      }
+    }
+  };
   // ---- split-K fix-up: publish this slice, the last arriver of the tile sums all slices in order ------------
   if (p.splits > 1 && p.fixup) {
     constexpr int NF = TI * TJ * 4;  // float4 fragments per thread
-    const long tile_id = (MODE == MODE_TN ? (long)g * gridDim.x : 0) + bid;
+    const long tile_id = (MODE == MODE_TN ? (long)e_g * gridDim.x : 0) + e_bid;
     float* tile_slabs = p.slabs + tile_id * p.splits * (long)(BM * BN);
-    f32x4* mine = reinterpret_cast<f32x4*>(tile_slabs + (long)split * (BM * BN));
+    f32x4* mine = reinterpret_cast<f32x4*>(tile_slabs + (long)e_split * (BM * BN));
 #pragma unroll
     for (int i = 0; i < TI; i++)
 #pragma unroll
@@ -956,17 +1079,23 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
   long c_base = 0;
   int m_lim;
   if (p.splits > 1 && !p.fixup) c_base = (long)blockIdx.z * p.strideC;  // raw slice z of a later reduce pass
-  else if (MODE == MODE_TN) c_base = (long)g * p.strideC;
-  m_lim = (MODE == MODE_TN) ? p.M : row_end;
+  else if (MODE == MODE_TN) c_base = (long)e_g * p.strideC;
+  m_lim = (MODE == MODE_TN) ? p.M : e_row_end;
   const float* bias = (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_SCALE_RES || EPI == EPI_BIAS_RELU)
-                          ? p.bias + (long)g * p.strideBias
+                          ? p.bias + (long)e_g * p.strideBias
                           : nullptr;
   // Staged epilogue: every 32x32 accumulator tile goes through a per-wave LDS patch (32 rows x 36 floats) and comes
   // back row-contiguous: one wave instruction then touches 8 rows x 128 contiguous bytes (full cache lines) of C and of
   // the auxiliary tensors.  LDS operations of one wave execute in order, so the write -> read hand-over needs no
   // barrier, only a compiler fence.
-  float* stg = smem + wave * (32 * 36);
-  const int sr = lane >> 3, sc = (lane & 7) * 4;
+  // (persistent form: the thread index goes through an opaque move first, otherwise hipcc hoists every constant of the
+  // epilogue -- staging addresses, row / column offsets -- out of the item loop and keeps them in registers through the
+  // k-loop, which is the kernel's register peak)
+  int tid_e = tid;
+  if (CAN_PERSIST) asm volatile("" : "+v"(tid_e));
+  const int lane_e = tid_e & 63, wave_e = tid_e >> 6;
+  float* stg = smem + wave_e * (32 * 36);
+  const int sr = lane_e >> 3, sc = (lane_e & 7) * 4;
   f32x4 cs[TJ];
   if (EPI == EPI_GELU_BWD) {
 #pragma unroll
@@ -982,10 +1111,10 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
   f32x4 pre[AUX_DEPTH + 1][4];
   auto aux_fetch = [&](int t, f32x4 (&dst)[4]) {
     const int j = t / TI, i = t - j * TI;
-    const int col = n0 + wn0 + 32 * j + sc;
+    const int col = e_n0 + wn0 + 32 * j + sc;
 #pragma unroll
     for (int it = 0; it < 4; it++) {
-      const int row = m0 + wm0 + 32 * i + sr + 8 * it;
+      const int row = e_m0 + wm0 + 32 * i + sr + 8 * it;
       const bool ok = row < m_lim && col < p.N;
       const long ai = ok ? (long)row * p.ld_aux + col : 0;
       if (X16) {
@@ -1022,7 +1151,7 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
   }
 #pragma unroll
   for (int j = 0; j < TJ; j++) {
-    const int col = n0 + wn0 + 32 * j + sc;
+    const int col = e_n0 + wn0 + 32 * j + sc;
     const bool col_ok = col < p.N;
     f32x4 bv = {0.f, 0.f, 0.f, 0.f}, gv = bv;
     if (bias && col_ok) bv = *reinterpret_cast<const f32x4*>(bias + col);
@@ -1035,6 +1164,7 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
         *reinterpret_cast<f32x4*>(stg + l31 * 36 + 8 * q + 4 * lh) =
             f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
       asm volatile("" ::: "memory");
+      if (CAN_PERSIST && t == 0) next_item();
       if (AUX_IN && t + AUX_DEPTH < NT_) aux_fetch(t + AUX_DEPTH, pre[(t + AUX_DEPTH) % (AUX_DEPTH + 1)]);
       f32x4 v[4];
 #pragma unroll
@@ -1042,7 +1172,7 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
       asm volatile("" ::: "memory");
 #pragma unroll
       for (int it = 0; it < 4; it++) {
-        const int row = m0 + wm0 + 32 * i + sr + 8 * it;
+        const int row = e_m0 + wm0 + 32 * i + sr + 8 * it;
         if (row >= m_lim || !col_ok) continue;
         const long ci = c_base + (long)row * p.ldc + col;
         const long ai = (long)row * p.ld_aux + col;
@@ -1093,18 +1223,38 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
       if (sr == 0) *reinterpret_cast<f32x4*>(red + wave * (TJ * 32) + 32 * j + sc) = t;
     }
     __syncthreads();
-    if (tid < BN && n0 + tid < p.N) {
+    if (tid < BN && e_n0 + tid < p.N) {
       const int wn = tid / (TJ * 32), c = tid - wn * (TJ * 32);
       float t = 0.f;
 #pragma unroll
       for (int w = 0; w < WM; w++) t += red[(w * WN + wn) * (TJ * 32) + c];
-      p.colpart[(long)tile_m * p.N + n0 + tid] = t;
+      p.colpart[(long)e_tile_m * p.N + e_n0 + tid] = t;
     }
   }
 #ifdef SM3_TRACE
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores of this wave have left the CU
+  if (sm3_first_pass) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores of this wave have left the CU
   SM3_TR(4);
+  sm3_first_pass = false;
+  sm3_items++;
 #endif
+  if (!has_next) break;
+  __syncthreads();  // every wave is done with its staging patch: the next item's LDS image overlays it
+  }  // item loop
+#ifdef SM3_TRACE
+  if (CAN_PERSIST && p.trace && tid == 0) {  // persistent form: [4] = the workgroup's exit, [6] |= items walked << 32
+    unsigned long long* tr = p.trace + ((size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.z) * 8;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    tr[4] = __builtin_amdgcn_s_memtime();
+    tr[6] |= (unsigned long long)sm3_items << 32;
+  }
+#endif
+  if (CAN_PERSIST && tid == 0) {  // leave the queue zeroed for the next launch (last workgroup out)
+    const int d = __hip_atomic_fetch_add(q_head + 8, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (d == (int)gridDim.x - 1) {
+#pragma unroll
+      for (int w = 0; w < 9; w++) __hip_atomic_store(q_head + w, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 // launchers (one translation unit per mode: gemm_f32.hip = NT, gemm_f32_nn.hip, gemm_f32_tn.hip)
@@ -1122,6 +1272,14 @@ int launch_tn16(const GemmParams& p, int tile, int bk, int io, dim3 grid, hipStr
 int launch_nt_h16(const GemmParams& p, int epi, int tile, int bk, int io, dim3 grid, hipStream_t st);
 int launch_nn_h16(const GemmParams& p, int epi, int tile, int bk, int io, dim3 grid, hipStream_t st);
 int launch_tn_h16(const GemmParams& p, int tile, int bk, int io, dim3 grid, hipStream_t st);
+
+// persistent instantiations (gemm_f32_p.hip, gemm_h16_p.hip): grid.x = resident workgroups, p.total_tiles = items
+bool has_persistent_f32(int tile, int bk);
+bool has_persistent_h16(int mode, int epi, int tile, int bk, int io);
+int launch_nt_p(const GemmParams& p, int epi, int tile, int bk, dim3 grid, hipStream_t st);
+int launch_nn_p(const GemmParams& p, int epi, int tile, int bk, dim3 grid, hipStream_t st);
+int launch_nt_h16_p(const GemmParams& p, int epi, int tile, int bk, int io, dim3 grid, hipStream_t st);
+int launch_nn_h16_p(const GemmParams& p, int epi, int tile, int bk, int io, dim3 grid, hipStream_t st);
 
 inline void tile_dims(int tile, int& bm, int& bn) {
   static const int d[6][2] = {{128, 128}, {128, 96}, {96, 128}, {128, 192}, {192, 128}, {64, 128}};

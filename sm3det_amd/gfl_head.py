@@ -17,7 +17,12 @@ bias}``, ``gfl_cls.{weight,bias}``, ``gfl_reg.{weight,bias}``, ``scales.{l}.scal
 are implicit GEMMs on the MFMA GEMM family (``sm3_conv3x3_nhwc_*``, ~206 GFLOP forward per 1024^2 SAR image: the largest
 block of detector FLOPs after the backbone), GroupNorm + ReLU is two HBM passes (``sm3_groupnorm_*``); everything stays
 NHWC.  ``gfl_cls`` / ``gfl_reg`` run with their output channels zero-padded to a multiple of 32 (the input-gradient
-GEMM contracts over them).  Losses / ATSS assignment / the Integral decoder are mmdet code as well and not built.
+GEMM contracts over them).
+
+Round 4: the loss side -- ``forward_train`` / ``loss`` / ``get_targets`` (``ATSSAssigner(topk=9)`` + ``PseudoSampler``,
+QFL / DFL / GIoU, the ``Integral`` layer) and ``get_bboxes`` / ``simple_test`` -- in plain PyTorch over fixed-shape masked
+tensors (``sm3det_amd/gfl_losses.py``: same sums as mmdet's ``nonzero``-indexed form, no host sync); mmdet code as well,
+restated, **parity unpinned**.
 """
 import math
 
@@ -167,3 +172,174 @@ class GFLHead(nn.Module):
         """multi_apply(forward_single, feats, self.scales) -> (list of cls scores, list of bbox preds)"""
         outs = [self.forward_single(f, s) for f, s in zip(feats, self.scales)]
         return [o[0] for o in outs], [o[1] for o in outs]
+
+    # ------------------------------------------------------------------------------------------- training side
+    # mmdet 2.25 GFLHead.loss / loss_single / get_targets / _get_target_single (gfl_head.py:233-471) and AnchorHead.
+    # get_anchors (anchor_head.py:170-211), restated over fixed-shape masked tensors -- parity unpinned (module docstring).
+    def _anchors(self, featmap_sizes, device):
+        """AnchorGenerator(ratios [1.0], octave_base_scale 8, scales_per_octave 1).grid_priors: ONE square anchor of side
+        8 * stride per position, centred on (x * stride, y * stride) (center_offset 0); level-major list of (H*W, 4)"""
+        from .rpn_head import grid_anchors
+        ag = self.anchor_cfg
+        if 'octave_base_scale' in ag:
+            scales = [ag['octave_base_scale'] * 2 ** (i / ag.get('scales_per_octave', 1))
+                      for i in range(ag.get('scales_per_octave', 1))]
+        else:
+            scales = list(ag.get('scales', [8]))
+        return grid_anchors(featmap_sizes, self.strides, scales, list(ag.get('ratios', [1.0])), device=device)
+
+    def _valid_flags(self, featmap_sizes, pad_shape, device):
+        """AnchorGenerator.valid_flags (anchor_generator.py:397-450): positions inside the padded image; allowed_border -1
+        (the SM3Det config) makes anchor_inside_flags == valid_flags"""
+        out = []
+        h, w = pad_shape[:2]
+        for (fh, fw), s in zip(featmap_sizes, self.strides):
+            vh, vw = min(int(math.ceil(h / s)), fh), min(int(math.ceil(w / s)), fw)
+            vy = torch.arange(fh, device=device) < vh
+            vx = torch.arange(fw, device=device) < vw
+            out.append((vy[:, None] & vx[None, :]).reshape(-1))
+        return out
+
+    def get_targets(self, anchors, num_level_anchors, valid_flags_list, gt_bboxes_list, gt_labels_list):
+        """per image ATSS assignment + PseudoSampler -> stacked (B, A) labels (num_classes = background), label weights,
+        (B, A, 4) box targets, (B, A) positive mask.  anchors (A, 4) level-major, shared by the images."""
+        from . import gfl_losses as GL
+        tc = self.train_cfg or {}
+        asg = dict(tc.get('assigner') or dict(type='ATSSAssigner', topk=9))
+        if asg.get('type') != 'ATSSAssigner':
+            raise NotImplementedError(f"GFLHead on MI355X: assigner {asg.get('type')!r} (the SM3Det configs use ATSSAssigner)")
+        if tc.get('allowed_border', -1) >= 0:
+            raise NotImplementedError('allowed_border >= 0 (the SM3Det configs use -1)')
+        pos_weight = float(tc.get('pos_weight', -1))
+        labels, weights, targets, poss = [], [], [], []
+        for valid, gtb, gtl in zip(valid_flags_list, gt_bboxes_list, gt_labels_list):
+            gt_inds, _, _ = GL.atss_assign(anchors, num_level_anchors, gtb.float(), None, topk=int(asg.get('topk', 9)),
+                                           valid=valid)
+            pos = gt_inds > 0
+            if gtb.size(0):
+                tgt = torch.where(pos[:, None], gtb.float()[(gt_inds - 1).clamp(min=0)], anchors.new_zeros(()))
+                lab = torch.where(pos, gtl.long()[(gt_inds - 1).clamp(min=0)], gt_inds.new_full((), self.num_classes))
+            else:
+                tgt = torch.zeros_like(anchors)
+                lab = gt_inds.new_full(gt_inds.shape, self.num_classes)
+            w = valid.float()  # negatives 1, positives pos_weight (<= 0: 1), anchors outside the image 0 (unmap fill)
+            if pos_weight > 0:
+                w = torch.where(pos, w * pos_weight, w)
+            labels.append(lab)
+            weights.append(w)
+            targets.append(tgt)
+            poss.append(pos & valid)
+        return torch.stack(labels), torch.stack(weights), torch.stack(targets), torch.stack(poss)
+
+    def loss(self, cls_scores, bbox_preds, gt_bboxes, gt_labels, img_metas, gt_bboxes_ignore=None):
+        """-> dict(loss_cls, loss_bbox, loss_dfl): lists with one scalar per pyramid level, as mmdet returns them"""
+        from . import gfl_losses as GL
+        if gt_bboxes_ignore is not None:
+            raise NotImplementedError('gt_bboxes_ignore (the SM3Det detector asserts it is None)')
+        sizes = [tuple(c.shape[-2:]) for c in cls_scores]
+        dev = cls_scores[0].device
+        lvl_anchors = self._anchors(sizes, dev)
+        num_level = [int(a.shape[0]) for a in lvl_anchors]
+        anchors = torch.cat(lvl_anchors)
+        valid = [torch.cat(self._valid_flags(sizes, m.get('pad_shape', m.get('img_shape')), dev)) for m in img_metas]
+        labels, label_w, box_t, pos = self.get_targets(anchors, num_level, valid, gt_bboxes, gt_labels)
+        B = labels.shape[0]
+        qb = float((self.loss_cls_cfg or {}).get('beta', 2.0))
+        w_cls = float((self.loss_cls_cfg or {}).get('loss_weight', 1.0))
+        w_dfl = float((self.loss_dfl_cfg or {}).get('loss_weight', 0.25))
+        w_box = float((self.loss_bbox_cfg or {}).get('loss_weight', 2.0))
+        # get_targets: num_total_pos = sum over the images of max(#positives, 1); loss: reduce_mean over ranks, max(., 1)
+        num_total = _reduce_mean(pos.sum(dim=1).clamp(min=1).sum().float()).clamp(min=1.0)
+        l_cls, l_box, l_dfl, avg = [], [], [], []
+        start = 0
+        R = self.reg_max
+        for lv, (cs, bp, stride) in enumerate(zip(cls_scores, bbox_preds, self.strides)):
+            nl = num_level[lv]
+            a = anchors[start:start + nl]
+            cs = cs.permute(0, 2, 3, 1).reshape(B * nl, self.cls_out_channels).float()
+            bp = bp.permute(0, 2, 3, 1).reshape(B * nl, 4 * (R + 1)).float()
+            lab = labels[:, start:start + nl].reshape(-1)
+            lw = label_w[:, start:start + nl].reshape(-1)
+            bt = box_t[:, start:start + nl].reshape(-1, 4)
+            ps = pos[:, start:start + nl].reshape(-1)
+            start += nl
+            centers = torch.stack(((a[:, 0] + a[:, 2]) / 2.0, (a[:, 1] + a[:, 3]) / 2.0), dim=1) / stride
+            centers = centers[None].expand(B, nl, 2).reshape(-1, 2)
+            psf = ps.float()
+            wt = cs.detach().sigmoid().max(dim=1)[0] * psf          # weight_targets (0 off the positives)
+            corners = GL.integral(bp, R)
+            dec = GL.distance2bbox(centers, corners)
+            dec_t = bt / stride
+            score = GL.bbox_overlaps(dec.detach(), dec_t, is_aligned=True) * psf
+            tgt_c = GL.bbox2distance(centers, dec_t, R).reshape(-1)
+            l_box.append((GL.giou_loss(dec, dec_t) * wt).sum() * w_box)                      # avg_factor 1.0
+            dfl = GL.distribution_focal_loss(bp.reshape(-1, R + 1), tgt_c)
+            l_dfl.append((dfl * wt[:, None].expand(-1, 4).reshape(-1)).sum() / 4.0 * w_dfl)  # avg_factor 4.0
+            qfl = GL.quality_focal_loss(cs, lab, score, ps, qb)
+            l_cls.append((qfl * lw).sum() / num_total * w_cls)
+            avg.append(wt.sum())
+        avg_factor = _reduce_mean(sum(avg)).clamp(min=1.0)
+        return dict(loss_cls=l_cls, loss_bbox=[v / avg_factor for v in l_box], loss_dfl=[v / avg_factor for v in l_dfl])
+
+    def forward_train(self, x, img_metas, gt_bboxes, gt_labels=None, gt_bboxes_ignore=None, proposal_cfg=None, **kwargs):
+        """BaseDenseHead.forward_train (base_dense_head.py:306-345): heads -> loss"""
+        cls_scores, bbox_preds = self(x)
+        return self.loss(cls_scores, bbox_preds, gt_bboxes, gt_labels, img_metas, gt_bboxes_ignore)
+
+    # ------------------------------------------------------------------------------------------- inference side
+    @torch.no_grad()
+    def get_bboxes(self, cls_scores, bbox_preds, img_metas, cfg=None, rescale=False):
+        """GFLHead._get_bboxes_single (gfl_head.py:473-573) per image: sigmoid scores, score_thr + nms_pre top-k per level,
+        Integral -> distances * stride -> boxes clipped to img_shape, then multiclass NMS (class-wise batched_nms,
+        max_per_img) -> list of (dets (n, 5), labels (n,)).  Variable-length outputs: host-synchronising by nature."""
+        from . import gfl_losses as GL
+        from . import mmcv_ops
+        cfg = dict(cfg or self.test_cfg or {})
+        sizes = [tuple(c.shape[-2:]) for c in cls_scores]
+        lvl_anchors = self._anchors(sizes, cls_scores[0].device)
+        out = []
+        for i, meta in enumerate(img_metas):
+            boxes, scores, labels = [], [], []
+            for cs, bp, a, stride in zip(cls_scores, bbox_preds, lvl_anchors, self.strides):
+                sc = cs[i].permute(1, 2, 0).reshape(-1, self.cls_out_channels).sigmoid()
+                bpi = bp[i].permute(1, 2, 0).reshape(-1, 4 * (self.reg_max + 1)).float()
+                # filter_scores_and_topk: (score > thr) pairs, then the nms_pre best of them
+                flat = sc.reshape(-1)
+                keep = (flat > cfg.get('score_thr', 0.05)).nonzero().squeeze(1)
+                k = min(int(cfg.get('nms_pre', 1000)), int(keep.numel()))
+                if k == 0:
+                    continue
+                top = flat[keep].sort(descending=True)[1][:k]
+                sel = keep[top]
+                ai, ci = sel // self.cls_out_channels, sel % self.cls_out_channels
+                centers = torch.stack(((a[ai, 0] + a[ai, 2]) / 2.0, (a[ai, 1] + a[ai, 3]) / 2.0), dim=1)
+                bb = GL.distance2bbox(centers, GL.integral(bpi[ai], self.reg_max) * stride)
+                h, w = meta['img_shape'][:2]
+                bb = torch.stack((bb[:, 0].clamp(0, w), bb[:, 1].clamp(0, h), bb[:, 2].clamp(0, w), bb[:, 3].clamp(0, h)), 1)
+                boxes.append(bb)
+                scores.append(flat[sel])
+                labels.append(ci)
+            if not boxes:
+                out.append((cls_scores[0].new_zeros(0, 5), cls_scores[0].new_zeros(0, dtype=torch.long)))
+                continue
+            bb, sc, lb = torch.cat(boxes), torch.cat(scores), torch.cat(labels)
+            if rescale and meta.get('scale_factor') is not None:
+                bb = bb / bb.new_tensor(meta['scale_factor'])
+            dets, keep = mmcv_ops.batched_nms(bb, sc, lb, dict(cfg.get('nms', dict(type='nms', iou_threshold=0.6))))
+            n = int(cfg.get('max_per_img', 100))
+            out.append((dets[:n], lb[keep][:n]))
+        return out
+
+    def simple_test(self, feats, img_metas, rescale=False):
+        """BBoxTestMixin.simple_test_bboxes (dense_test_mixins.py:18-38)"""
+        return self.get_bboxes(*self(feats), img_metas=img_metas, rescale=rescale)
+
+
+def _reduce_mean(t):
+    """mmdet.core.utils.reduce_mean: mean over the ranks of a data-parallel job (identity for one process)"""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return t
+    t = t.clone()
+    dist.all_reduce(t.div_(dist.get_world_size()), op=dist.ReduceOp.SUM)
+    return t

@@ -348,7 +348,7 @@ def test_gate_prep_and_aux_loss_vs_torch_autograd(P, C, E):
         (rwcat * dwcat).sum().add((rbcat * dbcat).sum()).add((rsn * (dsn * rscale.detach())).sum()).add(
             rscale.sum() * ds_part.sum()).backward()
         outs = [torch.empty_like(t) for t in d]
-        LB.call('moe_gate_prep_bwd', dwcat.cuda(), dbcat.cuda(), dsn.cuda(), ds_part.cuda(), 37, d[3], d[4], cmax, P,
+        LB.call('moe_gate_prep_bwd', dwcat.cuda(), dbcat.cuda(), dsn.cuda(), ds_part.double().cuda(), 37, d[3], d[4], cmax, P,
                 C, E, *outs)
         for a, r in zip(outs, ref_in):
             torch.testing.assert_close(a.cpu(), r.grad, rtol=2e-5, atol=1e-6)

@@ -275,7 +275,7 @@ def _run_case(case, amp, forced=False):
                 # 2^-11 * |s|_2 / |S| (measured on this run's terms, reported above) -- not a chosen constant
                 te = tl2 = max(BWD_TOL, 4.0 * 2.0 ** -11 * temp_cond.get(key, 0.0))
                 if te > BWD_TOL:
-                    loosened[key] = dict(tol=te, conditioning=temp_cond.get(key))
+                    loosened[key] = dict(err=e, projection_err=l2, tol=te, conditioning=temp_cond.get(key))
         else:
             te, tl2 = max(BWD_TOL, 4.0 * fe), max(BWD_TOL, 4.0 * fl2)
             if te > BWD_TOL or tl2 > BWD_TOL:
