@@ -463,6 +463,105 @@ def ops_microbench():
 
 
 
+def full_model_bench():
+    """Third named workload (never part of `value`): ONE TRAINING STEP OF THE WHOLE DETECTOR of local_configs/main_SM3Det.py
+    at the config's native modality mix -- 2 SAR + 1 RGB + 1 IR images of 1024^2 (source_ratio [2, 1, 1]) --
+    `MODELS.build(cfg.model)` -> `TriSourceDetector.forward_train` (one MoE backbone call on the 4 concatenated images,
+    MultitaskFPN x3, GFLHead with ATSS + QFL / DFL / GIoU for the SAR pair, OrientedRPNHead + OrientedStandardRoIHead with
+    their real targets and losses for the RGB and the IR image) -> BaseDetector._parse_losses -> backward -> grad-clip(35)
+    + AdamW over all 178 M parameters.  Inputs are device-resident; the step is sync-free and replayed from two hipGraphs
+    when capture succeeds.  The SAR loss side is plain PyTorch (mmdet code, restated, parity unpinned); everything else
+    runs on this package's kernels."""
+    import copy
+    import numpy as np
+    from sm3det_amd import detector  # noqa: F401
+    from sm3det_amd.optim import MultiTensorAdamW
+    from sm3det_amd.registry import MODELS
+    from tests import synth
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    m = copy.deepcopy(load_config(DEFAULT_CONFIG)['model'])
+    m['backbone'].pop('init_cfg', None)
+    torch.manual_seed(2)
+    det = MODELS.build(m).cuda().train()
+    for h in (det.rgb_rpn_head, det.rgb_roi_head, det.ifr_rpn_head, det.ifr_roi_head):
+        h.init_weights()
+    with torch.no_grad():
+        for n, p in det.backbone.named_parameters():
+            if n.endswith('gamma'):
+                p.fill_(1.0)
+    mix = dict(sar=2, rgb=1, ifr=1)
+    g = torch.Generator().manual_seed(3)
+    img = {s: torch.randn(n, 3, RES, RES, generator=g).cuda() for s, n in mix.items()}
+    metas = {s: [dict(img_shape=(RES, RES, 3), pad_shape=(RES, RES, 3)) for _ in range(n)] for s, n in mix.items()}
+    gtb = {s: [dev(synth.hboxes(8, 80 + i, extent=float(RES))) if s == 'sar' else dev(synth.rotated_boxes(8, 90 + i + 5 * (s == 'ifr')))
+               for i in range(n)] for s, n in mix.items()}
+    gtl = {s: [torch.randint(0, 26, (8,), generator=g).cuda() for _ in range(n)] for s, n in mix.items()}
+    params = [q for q in det.parameters() if q.requires_grad]
+    opt = MultiTensorAdamW([dict(params=[q]) for q in params], lr=1e-4, betas=(0.9, 0.999), weight_decay=0.05, max_grad_norm=35.0)
+    logs = {}
+
+    def fwd_bwd():
+        for q in params:
+            q.grad = None
+        losses = det.forward_train_gathered(img, metas, gtb, gtl)
+        total, lv = det.parse_losses(losses)
+        total.backward()
+        logs.update({k: v.detach() for k, v in lv.items()})
+
+    def step():
+        fwd_bwd()
+        opt.step()
+
+    def timeit(fn, n):
+        fn()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) / n * 1e3)
+        return sorted(ts)[1]
+
+    out = dict(images_per_step=sum(mix.values()), mix=mix, params_m=round(sum(q.numel() for q in params) / 1e6, 2))
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()
+        torch.cuda.synchronize()
+        first = {k: round(float(v), 5) for k, v in logs.items()}
+        out['ms_per_step_eager'] = round(timeit(step, 3), 3)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    ms = out['ms_per_step_eager']
+    try:
+        g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1):
+            fwd_bwd()
+        keep = [q.grad for q in params]  # noqa: F841
+        g1.replay()
+        opt.refresh_grad_pointers()
+        with torch.cuda.graph(g2, pool=g1.pool()):
+            opt.step()
+
+        def replay():
+            g1.replay()
+            g2.replay()
+        ms = out['ms_per_step_graph'] = round(timeit(replay, 5), 3)
+        out['hip_graph'] = True
+    except Exception as e:  # noqa: BLE001
+        print(f'[bench] full model: hipGraph capture failed ({type(e).__name__}: {e})', file=sys.stderr)
+        out['hip_graph'] = False
+    torch.cuda.synchronize()
+    out['losses_first_step'] = first
+    out['losses_last_step'] = {k: round(float(v), 5) for k, v in logs.items()}
+    out['imgs_per_sec'] = round(sum(mix.values()) / (ms * 1e-3), 2)
+    del det, opt, params
+    torch.cuda.empty_cache()
+    return out
+
+
 def _self_launch(n):
     """`python bench.py --gpus N` without a launcher: start N ranks of this very command line under torch.distributed.run
     (one process per GPU, rendezvous on 127.0.0.1 -- tools/dist_train.sh:8-19 of the reference does the same with
@@ -908,6 +1007,18 @@ def main():
                     'two-stage (RGB) branch of main_SM3Det.py as one training step at bs2 1024^2: backbone + MultitaskFPN + '
                     'OrientedRPNHead.forward_train (real targets + losses + proposals) + OrientedStandardRoIHead.forward_train '
                     '(real targets + losses) + backward + clip + AdamW; excludes the SAR GFL branch and the data pipeline')
+            if os.environ.get('SM3_BENCH_OPS') != 'slice':
+                try:
+                    fm = full_model_bench()
+                    result['full_model'] = fm
+                    result['full_model_imgs_per_sec'] = fm['imgs_per_sec']
+                    result['full_model_workload'] = (
+                        'TriSourceDetector of main_SM3Det.py built from the config dict, one training step at the native mix 2 SAR + '
+                        '1 RGB + 1 IR @1024^2: backbone (4 images) + MultitaskFPN x3 + GFLHead (ATSS, QFL/DFL/GIoU: plain PyTorch, '
+                        'unpinned) + 2 x (OrientedRPNHead + OrientedStandardRoIHead) with real targets / losses + backward + clip + '
+                        'AdamW over 178 M parameters; device-resident synthetic inputs, no data pipeline')
+                except Exception as e:  # noqa: BLE001  (never lose the headline line to the extra workload)
+                    result['full_model'] = dict(error=f'{type(e).__name__}: {e}'[:300])
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(args.config)
         else:

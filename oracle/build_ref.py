@@ -92,6 +92,7 @@ PY_UNITS = {  # module name in the shim package -> path under /root/reference/mm
     'mmcv.ops.deform_conv': 'ops/deform_conv.py',
 }
 PYC = os.path.join(OUT, 'pyc')
+BACKBONE_PYC = 'mmrotate.models.backbones.convnext_moe.pyc'
 
 
 def build_pyc():
@@ -105,6 +106,12 @@ def build_pyc():
         src, dst = os.path.join(root, rel), os.path.join(PYC, mod + '.pyc')
         if not os.path.exists(dst) or os.path.getmtime(dst) < os.path.getmtime(src):
             py_compile.compile(src, cfile=dst, dfile=f'<reference>/mmcv/mmcv/{rel}', doraise=True)
+    # the reference BACKBONE module itself (oracle/ref_moe.py loads it from this bytecode where /root/reference is absent:
+    # bench.py's cpu_baseline then times the reference's own code on the GPU box's host -- kind "reference")
+    src = os.path.join(REF_ROOT, 'mmrotate', 'models', 'backbones', 'convnext_moe.py')
+    dst = os.path.join(PYC, BACKBONE_PYC)
+    if os.path.exists(src) and (not os.path.exists(dst) or os.path.getmtime(dst) < os.path.getmtime(src)):
+        py_compile.compile(src, cfile=dst, dfile='<reference>/mmrotate/models/backbones/convnext_moe.py', doraise=True)
     return PYC
 
 

@@ -65,7 +65,15 @@ def _mod(name, **attrs):
     return m
 
 
+REF_PYC = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_ref', 'pyc', 'mmrotate.models.backbones.convnext_moe.pyc')
+
+
 def available():
+    """the reference source (build container) or its bytecode compiled by oracle/build_ref.py (travels to the GPU box)"""
+    return os.path.exists(REF_FILE) or os.path.exists(REF_PYC)
+
+
+def from_source():
     return os.path.exists(REF_FILE)
 
 
@@ -106,7 +114,12 @@ def load_reference_module():
     saved = {k: sys.modules.get(k) for k in shims}
     sys.modules.update(shims)
     try:
-        spec = importlib.util.spec_from_file_location(full, REF_FILE)
+        if from_source():
+            spec = importlib.util.spec_from_file_location(full, REF_FILE)
+        else:
+            import importlib.machinery
+            loader = importlib.machinery.SourcelessFileLoader(full, REF_PYC)
+            spec = importlib.util.spec_from_loader(full, loader)
         mod = importlib.util.module_from_spec(spec)
         sys.modules[full] = mod
         spec.loader.exec_module(mod)

@@ -22,8 +22,11 @@ ROT = 6 if '--cold' in sys.argv else 1
 FP32 = '--fp32' in sys.argv  # the same sweep over the fp32 GEMM family (all tensors fp32, no autocast)
 
 
+PERSIST = (1 << 17) if '--persist' in sys.argv else 0  # the opt-in persistent form of the NT / NN launches
+
+
 def tune(tile=None, bk=None, splits=0):
-    return ((tile + 1) if tile is not None else 0) | (BK[bk] << 4) | (splits << 8)
+    return ((tile + 1) if tile is not None else 0) | (BK[bk] << 4) | (splits << 8) | PERSIST
 
 
 def candidates(mode):

@@ -243,7 +243,7 @@ inline double quant_cost(long blocks) {
 //    slice.  Since the k-loop lost its vector-ALU work the 96-wide tiles are as fast per FLOP as 128x128.
 // d->tuning (benchmarking aid, 0 in production): bits 0-3 tile+1, 4-7 k-step (1 = 16, 2 = 32, 3 = 64: fp16 only), 8-15 slices,
 // bit 16: TN slices summed by the in-kernel fix-up instead of the second pass (so a literal 256 in the slices field
-// reads as `automatic + fix-up`: scripts/gemm_sweep2.py)
+// reads as `automatic + fix-up`: scripts/gemm_sweep2.py); bit 17: persistent form of the NT / NN launches (sm3_gemm_f32)
 Cfg choose_cfg(const sm3_gemm_desc* d) {
   Cfg c;
   memset(&c, 0, sizeof(c));
@@ -467,11 +467,15 @@ int sm3_gemm_f32(const sm3_gemm_desc* d, void* workspace, size_t workspace_bytes
   }
   if (d->M == 0) return SM3_OK;
   dim3 grid(c.ntn * c.ntm, 1, c.splits);
-  // Persistent form: with more tiles than the chip holds workgroups at once, launch exactly the resident set and let it
-  // walk the tiles (gemm_f32_kernel.h, "work items").  SM3_GEMM_PERSIST=0 keeps one workgroup per tile (A/B runs).
+  // Persistent form (gemm_f32_kernel.h, "work items"): with more tiles than the chip holds workgroups at once, launch
+  // exactly the resident set and let it walk the tiles.  OPT-IN through bit 17 of d->tuning: measured in round 4
+  // (profiles/r04/gemm_persistent_ab.txt) it is 2-35 % SLOWER than one workgroup per tile on every shape of the training
+  // step -- with 3-4 workgroups resident per CU the hardware already overlaps one workgroup's prologue and store drain
+  // with its neighbours' k-loops, the long "prologues" the per-workgroup trace shows are queueing for HBM, not idle
+  // pipes, and the persistent loop pays for its carried state with scratch traffic.  Kept as a tested measurement form.
   bool persist = false;
   {
-    static const int enabled = [] { const char* e = getenv("SM3_GEMM_PERSIST"); return (e && e[0] == '0') ? 0 : 1; }();
+    const int enabled = (int)(((unsigned)d->tuning >> 17) & 1u);
     const int resident = kNumCU * resident_per_cu(c.tile, c.bk, d->compute == 1);
     const bool have = d->compute == 1 ? (d->io != 0 && has_persistent_h16(d->mode, d->epilogue, c.tile, c.bk, d->io))
                                       : has_persistent_f32(c.tile, c.bk);

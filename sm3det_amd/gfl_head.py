@@ -180,13 +180,18 @@ class GFLHead(nn.Module):
         """AnchorGenerator(ratios [1.0], octave_base_scale 8, scales_per_octave 1).grid_priors: ONE square anchor of side
         8 * stride per position, centred on (x * stride, y * stride) (center_offset 0); level-major list of (H*W, 4)"""
         from .rpn_head import grid_anchors
+        key = (tuple(featmap_sizes), str(device))
+        cache = self.__dict__.setdefault('_anchor_cache', {})
+        if key in cache:  # built once per pyramid geometry: no host -> device copy on the training path (capturable)
+            return cache[key]
         ag = self.anchor_cfg
         if 'octave_base_scale' in ag:
             scales = [ag['octave_base_scale'] * 2 ** (i / ag.get('scales_per_octave', 1))
                       for i in range(ag.get('scales_per_octave', 1))]
         else:
             scales = list(ag.get('scales', [8]))
-        return grid_anchors(featmap_sizes, self.strides, scales, list(ag.get('ratios', [1.0])), device=device)
+        cache[key] = grid_anchors(featmap_sizes, self.strides, scales, list(ag.get('ratios', [1.0])), device=device)
+        return cache[key]
 
     def _valid_flags(self, featmap_sizes, pad_shape, device):
         """AnchorGenerator.valid_flags (anchor_generator.py:397-450): positions inside the padded image; allowed_border -1

@@ -41,12 +41,12 @@ def bbox_overlaps(b1, b2, mode='iou', is_aligned=False, eps=1e-6):
         if mode == 'giou':
             elt = torch.min(b1[:, None, :2], b2[None, :, :2])
             erb = torch.max(b1[:, None, 2:], b2[None, :, 2:])
-    union = torch.max(union, union.new_tensor(eps))
+    union = union.clamp(min=eps)  # max(union, eps) without a host scalar upload (hipGraph capture)
     ious = overlap / union
     if mode == 'iou':
         return ious
     ewh = (erb - elt).clamp(min=0)
-    earea = torch.max(ewh[..., 0] * ewh[..., 1], union.new_tensor(eps))
+    earea = (ewh[..., 0] * ewh[..., 1]).clamp(min=eps)
     return ious - (earea - union) / earea
 
 

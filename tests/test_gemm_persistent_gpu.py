@@ -1,7 +1,8 @@
 """GPU tier: the PERSISTENT form of the GEMM family (gemm_f32_kernel.h "work items"; gemm_f32_p.hip / gemm_h16_p.hip) --
-launched by sm3_gemm_f32 whenever a GEMM has more output tiles than the chip holds workgroups at once.  Every case here is
-sized past that threshold (> 1024 tiles), so the kernels under test walk a device-side item queue, prefetch the next item's
-first k-tile inside the current epilogue and leave the queue zeroed for the next launch.
+an opt-in measurement form (bit 17 of sm3_gemm_desc.tuning; slower than one workgroup per tile on this chip, see
+gemm_f32.hip) that sm3_gemm_f32 uses when a GEMM has more output tiles than the chip holds workgroups at once.  Every case
+here is sized past that threshold (> 1024 tiles), so the kernels under test walk a device-side item queue, prefetch the
+next item's first k-tile inside the current epilogue and leave the queue zeroed for the next launch.
 
 Reference: the fp64 product (tolerance 1e-4 of the result's scale for fp32 operands, fp16 cases against the product of the
 fp16-rounded operands at 2e-5 + output rounding).  Each case runs TWICE back to back (the second launch finds the queue the
@@ -11,6 +12,17 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+
+
+PERSIST_BIT = 1 << 17
+
+
+@pytest.fixture(autouse=True)
+def _persistent_form():
+    from sm3det_amd import _lib_backbone as LB
+    old, LB.TUNING = LB.TUNING, PERSIST_BIT
+    yield
+    LB.TUNING = old
 
 
 def _LB():
