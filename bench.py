@@ -108,6 +108,31 @@ def _cpu_worker(kind, cfg_name=DEFAULT_CONFIG):
     CPU operators (oracle/_ref, compiled from /root/reference by oracle/build_ref.py) on the shapes of `ops_us`."""
     out = {'threads': torch.get_num_threads()}
     if kind == 'step':
+        from oracle import ref_moe
+        if ref_moe.available():
+            # the REFERENCE backbone module itself (mmrotate/models/backbones/convnext_moe.py:794-820, imported unmodified
+            # by oracle/ref_moe.py: from /root/reference in the build container, from the bytecode oracle/build_ref.py
+            # compiled into oracle/_ref/pyc on the GPU box) doing the same training step: kind = "reference"
+            bcfg = backbone_cfg(cfg_name)
+            bcfg.pop('type', None)
+            torch.manual_seed(0)
+            ref = ref_moe.build_reference_backbone(**bcfg)
+            ref.train()  # (the reference's train() override returns None)
+            g = torch.Generator().manual_seed(0)
+
+            def run_ref(b, res):
+                x = torch.randn(b, 3, res, res, generator=g)
+                ref.zero_grad(set_to_none=True)
+                t0 = time.perf_counter()
+                r = ref(x, ['single'])
+                outs, gl = r if isinstance(r, tuple) and len(r) == 2 and not torch.is_tensor(r[0]) else (r, 0.0)
+                (sum((o * o).mean() for o in outs) + gl).backward()
+                return time.perf_counter() - t0
+            run_ref(1, 512)
+            out['step_seconds'] = [run_ref(1, RES) for _ in range(3)]
+            out['kind'] = 'reference'
+            print('CPUWORKER ' + json.dumps(out), flush=True)
+            return
         from oracle import moe_oracle as MO
         net = build_model(cfg_name)
         bcfg = backbone_cfg(cfg_name)
@@ -204,15 +229,19 @@ def cpu_baseline(cfg_name=DEFAULT_CONFIG):
             sec = sorted(w['step_seconds'])[1]  # median of the 3 timed steps
             per_threads[str(t)] = round(1.0 / sec, 4)
             if best is None or 1.0 / sec > best[0]:
-                best = (1.0 / sec, t, w['step_seconds'])
+                best = (1.0 / sec, t, w['step_seconds'], w.get('kind', 'port'))
         else:
             per_threads[str(t)] = w.get('error', 'failed')
     ops = worker('ops', best[1] if best else 8)
     if best is None:
         return dict(value=None, unit='imgs/sec', cores=0, kind='port', sample='cpu worker failed', detail=per_threads)
-    return dict(value=round(best[0], 4), unit='imgs/sec', cores=best[1], kind='port',
-                sample=f'oracle/moe_oracle.py (restatement of the reference backbone, pinned to it at this size by '
-                       f'tests/test_oracle_fullsize.py): training step fwd+bwd fp32 on 1x3x{RES}x{RES}, 1 warm-up + 3 timed '
+    kind = best[3]
+    what = ('the reference backbone module itself (mmrotate/models/backbones/convnext_moe.py, unmodified; loaded by '
+            'oracle/ref_moe.py from the bytecode oracle/build_ref.py compiled out of /root/reference, with stand-ins only for '
+            'the timm / mmengine / mmcv container classes)' if kind == 'reference' else
+            'oracle/moe_oracle.py (restatement of the reference backbone, pinned to it at this size by tests/test_oracle_fullsize.py)')
+    return dict(value=round(best[0], 4), unit='imgs/sec', cores=best[1], kind=kind,
+                sample=f'{what}: training step fwd+bwd fp32 on 1x3x{RES}x{RES}, 1 warm-up + 3 timed '
                        f'steps ({", ".join(f"{s:.1f}" for s in best[2])} s) per thread count, median, no scaling; best of '
                        f'OMP_NUM_THREADS in {list(per_threads)} on a {ncpu}-thread host',
                 imgs_per_sec_by_threads=per_threads,

@@ -117,8 +117,8 @@ def load_reference_module():
         if from_source():
             spec = importlib.util.spec_from_file_location(full, REF_FILE)
         else:
-            import importlib.machinery
-            loader = importlib.machinery.SourcelessFileLoader(full, REF_PYC)
+            from importlib.machinery import SourcelessFileLoader
+            loader = SourcelessFileLoader(full, REF_PYC)
             spec = importlib.util.spec_from_loader(full, loader)
         mod = importlib.util.module_from_spec(spec)
         sys.modules[full] = mod
