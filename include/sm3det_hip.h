@@ -123,6 +123,21 @@ int sm3_roi_align_rotated_multilevel_backward(const float* grad_output, const fl
                                               int channels, int pooled_h, int pooled_w, int sampling_ratio,
                                               int aligned, int clockwise, int layout, sm3_stream_t stream);
 
+/* RoIAlignRotated backward WITHOUT global atomics (round 4; NHWC maps, sampling_ratio > 0): the contributions are filed
+ * under 8 x 8-pixel tiles of the gradient maps by a counting sort and every tile is accumulated in LDS and added to
+ * grad_inputs[l] once.  Same semantics as sm3_roi_align_rotated{,_multilevel}_backward (`grad_input +=`,
+ * roi_align_rotated_cuda_kernel.cuh:129-200 / cpu/roi_align_rotated.cpp:272-372); num_levels == 1: a single map, the level
+ * rule is not evaluated.  `batch` = images per map.  workspace: tile counters / offsets, the entries, the transposed
+ * grad_output. */
+size_t sm3_roi_align_rotated_backward_tiled_workspace_bytes(int n_rois, int batch, int channels, int pooled_h, int pooled_w,
+                                                            int sampling_ratio, const int* heights, const int* widths,
+                                                            int num_levels);
+int sm3_roi_align_rotated_backward_tiled(const float* grad_output, const float* rois, float* const* grad_inputs,
+                                         const int* heights, const int* widths, const float* scales, int num_levels,
+                                         float finest_scale, int n_rois, int batch, int channels, int pooled_h,
+                                         int pooled_w, int sampling_ratio, int aligned, int clockwise, void* workspace,
+                                         size_t workspace_bytes, sm3_stream_t stream);
+
 /* =========================================================================================================
  * Backbone hot path (a): grid-level sparse-MoE ConvNeXt.  Reference: mmrotate/models/backbones/convnext_moe.py.
  * Activations are token-major (T, C) float32 = NHWC; T = B*H*W.

@@ -988,6 +988,80 @@ __global__ __launch_bounds__(ROI_THREADS) void roi_align_rotated_fwd_kernel(
   }
 }
 
+// NHWC forward with CHANNEL VECTORS (round 4).  The kernel above gathers one float per lane and corner: 64 four-byte
+// loads per output element, 12.5 k wave-load instructions of 256 B per RoI -- bound by the texture addresser's
+// instruction rate, not by bytes (0.73 TB/s on the 256 x 256 x 256 level).  Here a lane owns FOUR consecutive channels of
+// one bin: a pixel's channels are contiguous in NHWC, so one wave instruction moves a whole 1 KB pixel row (C = 256) and a
+// bin costs 16 of them (4 samples x 4 corners) instead of 256.  Same taps, same weights, same order of the fp32
+// operations per channel as the scalar kernel (and as cpu/roi_align_rotated.cpp:175-200), so the results are bit-identical
+// to it.  The (C x bins) result tile is assembled in LDS in OUTPUT order and leaves as contiguous 16-byte stores.
+// Requires C % 4 == 0 and C * bins * 4 B + the sample table within the LDS budget (host checks; else the scalar kernel).
+typedef float rf4 __attribute__((ext_vector_type(4)));
+template <int MULTI>
+__global__ __launch_bounds__(ROI_THREADS) void roi_align_rotated_fwd_vec_kernel(
+    const float* __restrict__ input, const float* __restrict__ rois, float* __restrict__ output, int channels,
+    int height, int width, int PH, int PW, float spatial_scale, int sampling_ratio, int aligned, int clockwise,
+    int tab_bytes, RoiLevels lv = RoiLevels()) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  Sample* tab = (Sample*)smem;
+  float* tile = (float*)(smem + tab_bytes);  // [channels][bins], the RoI's block of the output
+  const int n = blockIdx.x;
+  if (MULTI) {  // block-uniform: this RoI's pyramid level
+    const int l = roi_target_level(rois + 6 * (size_t)n, lv.finest, lv.n);
+    input = lv.in[l];
+    height = lv.h[l];
+    width = lv.w[l];
+    spatial_scale = lv.scale[l];
+    if (lv.levels_out && threadIdx.x == 0) lv.levels_out[n] = l;
+  }
+  const RoiGeom g = roi_geometry(rois + 6 * (size_t)n, spatial_scale, aligned, clockwise, PH, PW, sampling_ratio);
+  const int bins = PH * PW;
+  const int spb = g.grid_h * g.grid_w;  // samples per bin
+  const int nsamp = bins * spb;
+  const bool use_tab = nsamp * (int)sizeof(Sample) <= tab_bytes;
+  if (use_tab) {
+    for (int s = threadIdx.x; s < nsamp; s += ROI_THREADS) {
+      int bin = s / spb, r = s - bin * spb;
+      int iy = r / g.grid_w, ix = r - iy * g.grid_w;
+      tab[s] = make_sample(g, height, width, bin / PW, bin % PW, iy, ix);
+    }
+  }
+  __syncthreads();
+  const int cnt_i = spb < 1 ? 1 : spb;
+  const float count = (float)cnt_i;
+  const int CQ = channels >> 2;
+  const float* base = input + (size_t)g.batch * height * width * channels;
+  for (int u = threadIdx.x; u < bins * CQ; u += ROI_THREADS) {
+    const int bin = u / CQ, cq = u - bin * CQ;
+    const float* in = base + 4 * cq;
+    rf4 val = {0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < spb; r++) {
+      Sample s;
+      if (use_tab) s = tab[bin * spb + r];
+      else s = make_sample(g, height, width, bin / PW, bin % PW, r / g.grid_w, r % g.grid_w);
+      if (s.p1 < 0) {
+        // reference multiplies the zero weights with input[pos 0] (cpu/roi_align_rotated.cpp:52-66,189-192)
+        const rf4 v0 = *reinterpret_cast<const rf4*>(in);
+        val += 0.f * v0 + 0.f * v0 + 0.f * v0 + 0.f * v0;
+      } else {
+        const rf4 v1 = *reinterpret_cast<const rf4*>(in + (size_t)s.p1 * channels);
+        const rf4 v2 = *reinterpret_cast<const rf4*>(in + (size_t)s.p2 * channels);
+        const rf4 v3 = *reinterpret_cast<const rf4*>(in + (size_t)s.p3 * channels);
+        const rf4 v4 = *reinterpret_cast<const rf4*>(in + (size_t)s.p4 * channels);
+        val += s.w1 * v1 + s.w2 * v2 + s.w3 * v3 + s.w4 * v4;
+      }
+    }
+    val /= count;
+#pragma unroll
+    for (int e = 0; e < 4; e++) tile[(4 * cq + e) * bins + bin] = val[e];
+  }
+  __syncthreads();
+  const int total = channels * bins;  // a multiple of 4: the RoI's output block starts 16-byte aligned
+  rf4* out4 = reinterpret_cast<rf4*>(output + (size_t)n * total);
+  const rf4* t4 = reinterpret_cast<const rf4*>(tile);
+  for (int i = threadIdx.x; i < (total >> 2); i += ROI_THREADS) out4[i] = t4[i];
+}
+
 template <int LAYOUT, int MULTI = 0>
 __global__ __launch_bounds__(ROI_THREADS) void roi_align_rotated_bwd_kernel(
     const float* __restrict__ grad_output, const float* __restrict__ rois, float* __restrict__ grad_input,
@@ -1052,6 +1126,144 @@ __global__ __launch_bounds__(ROI_THREADS) void roi_align_rotated_bwd_kernel(
   }
 }
 
+
+// ---------------------------------------------------------------- RoIAlignRotated backward, TILED (round 4)
+// The kernel above scatters every (RoI, bin, sample, corner) contribution with a global fp32 atomic: 410 MB of atomic
+// traffic for 512 RoIs on the 256 x 256 x 256 level against 160 MB of algorithmic bytes, 0.05 of the HBM roofline.  The
+// tiled form inverts the loop: the gradient map is cut into 8 x 8-pixel tiles, a counting sort files every corner
+// contribution under the tile its pixel lies in (entry = RoI-bin index, pixel inside the tile, bilinear weight / count),
+// and one workgroup per tile accumulates its entries into a 64-pixel x C tile in LDS (ds_add_f32; lanes along the
+// channels, so an entry is one coalesced read of the bin's channel vector from the TRANSPOSED gradient (n, bins, C)) and
+// adds the tile to grad_input ONCE with plain loads and stores -- every pixel belongs to exactly one tile, so no global
+// atomic is left and `grad_input +=` semantics (the reference's atomicAdd form) are kept.  NHWC maps, sampling_ratio > 0.
+// Same samples and weights as the scatter kernels (make_sample); the sum order inside a pixel differs (as it does between
+// two runs of the atomic form): covered by the same 1e-4 tolerance.
+constexpr int RT = 8;                 // tile edge in pixels
+constexpr int RT_PX = RT * RT;
+constexpr int RT_CH = 256;            // channels per LDS pass (64 px x 256 ch x 4 B = 64 KiB)
+struct RoiTileLevels {
+  float* gin[ROI_MAX_LEVELS];
+  int h[ROI_MAX_LEVELS], w[ROI_MAX_LEVELS], tiles_x[ROI_MAX_LEVELS], tiles_y[ROI_MAX_LEVELS];
+  int tile_base[ROI_MAX_LEVELS + 1];  // first global tile index of each level (batch-major inside a level)
+  float scale[ROI_MAX_LEVELS];
+  int n;
+  float finest;
+};
+struct RoiEntry {
+  int rb;    // roi * bins + bin
+  int lpx;   // pixel inside the tile, row-major 8 x 8
+  float w;   // bilinear weight / samples per bin
+};
+
+// PASS 0: count the entries of every tile; PASS 1: file them (offsets from the scan, cursors zeroed)
+template <int PASS>
+__global__ __launch_bounds__(256) void roi_bwd_bin_kernel(const float* __restrict__ rois, int n_rois, int PH, int PW,
+                                                         int sampling_ratio, int aligned, int clockwise, RoiTileLevels lv,
+                                                         int* __restrict__ counts, const int* __restrict__ offsets,
+                                                         RoiEntry* __restrict__ entries) {
+  const int bins = PH * PW, spb = sampling_ratio * sampling_ratio;
+  const long total = (long)n_rois * bins * spb;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int n = (int)(i / (bins * spb));
+  const int r0 = (int)(i - (long)n * bins * spb);
+  const int bin = r0 / spb, r = r0 - bin * spb;
+  const float* roi = rois + 6 * (size_t)n;
+  const int l = lv.n > 1 ? roi_target_level(roi, lv.finest, lv.n) : 0;
+  const RoiGeom g = roi_geometry(roi, lv.scale[l], aligned, clockwise, PH, PW, sampling_ratio);
+  const int H = lv.h[l], W = lv.w[l];
+  const Sample s = make_sample(g, H, W, bin / PW, bin % PW, r / g.grid_w, r % g.grid_w);
+  if (s.p1 < 0) return;
+  const int ps[4] = {s.p1, s.p2, s.p3, s.p4};
+  const float ws[4] = {s.w1, s.w2, s.w3, s.w4};
+  const float count = (float)spb;
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    const int y = ps[c] / W, x = ps[c] - y * W;
+    const int tile = lv.tile_base[l] + (g.batch * lv.tiles_y[l] + y / RT) * lv.tiles_x[l] + x / RT;
+    if (PASS == 0) {
+      atomicAdd(counts + tile, 1);
+    } else {
+      const int slot = offsets[tile] + atomicAdd(counts + tile, 1);
+      entries[slot] = RoiEntry{n * bins + bin, (y % RT) * RT + (x % RT), ws[c] / count};
+    }
+  }
+}
+
+// exclusive scan of the tile counts (one workgroup; a few thousand tiles) + zero the cursors for pass 1
+__global__ __launch_bounds__(1024) void roi_bwd_scan_kernel(int* __restrict__ counts, int* __restrict__ offsets, int ntiles) {
+  __shared__ int part[1024];
+  const int per = (ntiles + 1023) / 1024;
+  const int b = threadIdx.x * per, e = min(ntiles, b + per);
+  int s = 0;
+  for (int i = b; i < e; i++) s += counts[i];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const int v = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  int run = threadIdx.x ? part[threadIdx.x - 1] : 0;
+  for (int i = b; i < e; i++) {
+    const int c = counts[i];
+    offsets[i] = run;
+    counts[i] = 0;
+    run += c;
+  }
+  if (threadIdx.x == 1023) offsets[ntiles] = part[1023];
+}
+
+// one workgroup per tile.  thread -> (channel tid % CW, entry stripe tid / CW), CW = min(C, 256) rounded to the chunk
+__global__ __launch_bounds__(256) void roi_bwd_tile_kernel(const float* __restrict__ goT, const int* __restrict__ offsets,
+                                                          const RoiEntry* __restrict__ entries, RoiTileLevels lv,
+                                                          int channels) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];  // [64 px][CW]
+  const int t = blockIdx.x;
+  const int e0 = offsets[t], e1 = offsets[t + 1];
+  if (e1 == e0) return;  // nothing lands here: grad_input keeps its values
+  int l = 0;
+  while (l + 1 < lv.n && t >= lv.tile_base[l + 1]) l++;
+  const int tl = t - lv.tile_base[l];
+  const int tx = tl % lv.tiles_x[l], t2 = tl / lv.tiles_x[l];
+  const int ty = t2 % lv.tiles_y[l], b = t2 / lv.tiles_y[l];
+  const int H = lv.h[l], W = lv.w[l];
+  float* gin = lv.gin[l] + (size_t)b * H * W * channels;
+  for (int c0 = 0; c0 < channels; c0 += RT_CH) {
+    const int CW = min(RT_CH, channels - c0);
+    for (int i = threadIdx.x; i < RT_PX * CW; i += 256) tile[i] = 0.f;
+    __syncthreads();
+    const int stripes = 256 / CW > 0 ? 256 / CW : 1;
+    const int c = threadIdx.x % CW, st = threadIdx.x / CW;
+    if (st < stripes) {
+      // CW < 256: several stripes walk the list interleaved; CW == 256: one stripe, one channel per thread
+      for (int cc = c; cc < CW; cc += 256) {
+        int e = e0 + st;
+        for (; e + 3 * stripes < e1; e += 4 * stripes) {  // four independent channel-vector reads in flight
+          const RoiEntry a0 = entries[e], a1 = entries[e + stripes], a2 = entries[e + 2 * stripes], a3 = entries[e + 3 * stripes];
+          const float g0 = goT[(size_t)a0.rb * channels + c0 + cc], g1 = goT[(size_t)a1.rb * channels + c0 + cc];
+          const float g2 = goT[(size_t)a2.rb * channels + c0 + cc], g3 = goT[(size_t)a3.rb * channels + c0 + cc];
+          atomicAdd(tile + a0.lpx * CW + cc, g0 * a0.w);
+          atomicAdd(tile + a1.lpx * CW + cc, g1 * a1.w);
+          atomicAdd(tile + a2.lpx * CW + cc, g2 * a2.w);
+          atomicAdd(tile + a3.lpx * CW + cc, g3 * a3.w);
+        }
+        for (; e < e1; e += stripes) {
+          const RoiEntry a = entries[e];
+          atomicAdd(tile + a.lpx * CW + cc, goT[(size_t)a.rb * channels + c0 + cc] * a.w);
+        }
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < RT_PX * CW; i += 256) {
+      const int px = i / CW, cc = i - px * CW;
+      const int y = ty * RT + px / RT, x = tx * RT + px % RT;
+      if (y < H && x < W) gin[((size_t)y * W + x) * channels + c0 + cc] += tile[i];
+    }
+    __syncthreads();
+  }
+}
 
 // ---------------------------------------------------------------- MaxIoU assignment
 // mmdet MaxIoUAssigner.assign_wrt_overlaps (the assigner of `rpn` and `rcnn` in local_configs/main_SM3Det.py:165-196,
@@ -1268,7 +1480,9 @@ static int nms_common(bool rotated, const float* boxes, int stride, const float*
     nms_rotated_mask_kernel<<<(int)ntiles, 256, 0, st>>>(boxes, stride, order, n, nblk, thr, multi_label, mask, diagt);
   else
     nms_mask_kernel<<<(int)ntiles, 64, 0, st>>>(boxes, order, n, nblk, thr, (float)offset, mask, diagt);
-  if ((size_t)nblk * 8 <= 96 * 1024)  // removal vector in LDS, next block row prefetched (N <= 786 432)
+  // removal vector in LDS, next block row prefetched; the request must stay within the 64 KiB a launch may ask for without
+  // hipFuncSetAttribute (N <= 524 032), beyond that the global-memory sweep runs
+  if ((size_t)(nblk + 4) * 8 <= 64 * 1024)
     nms_sweep_lds_kernel<<<1, SWEEP_THREADS, (size_t)(nblk + 4) * 8, st>>>(mask, diagt, order, n, nblk, keep, num_keep);
   else
     nms_sweep_kernel<<<1, SWEEP_THREADS, 0, st>>>(mask, order, n, nblk, (uint64_t*)(w + o_remv), keep, num_keep);
@@ -1296,6 +1510,17 @@ static size_t roi_lds_bytes(int pooled_h, int pooled_w, int sampling_ratio) {
   return (size_t)(ns > 0 ? ns : 1) * sizeof(Sample);
 }
 
+// the channel-vector forward (NHWC): LDS = sample table + the (C x bins) output tile; 0 -> does not fit / not applicable
+static size_t roi_vec_lds_bytes(int channels, int ph, int pw, int sampling_ratio, size_t* tab_bytes) {
+  if (channels & 3) return 0;
+  size_t tb = roi_lds_bytes(ph, pw, sampling_ratio);
+  tb = align_up(tb, 16);
+  const size_t tile = (size_t)channels * ph * pw * sizeof(float);
+  if (tb + tile > 64 * 1024) return 0;  // the default dynamic-LDS limit of a launch; two RoIs per CU
+  *tab_bytes = tb;
+  return tb + tile;
+}
+
 int sm3_roi_align_rotated_forward(const float* input, const float* rois, float* output, int n_rois, int batch,
                                   int channels, int height, int width, int pooled_h, int pooled_w,
                                   float spatial_scale, int sampling_ratio, int aligned, int clockwise, int layout,
@@ -1307,10 +1532,16 @@ int sm3_roi_align_rotated_forward(const float* input, const float* rois, float* 
   if (!input || !rois || !output) return SM3_ERR_INVALID_ARG;
   size_t lds = roi_lds_bytes(pooled_h, pooled_w, sampling_ratio);
   hipStream_t st = (hipStream_t)stream;
+  size_t tb = 0;
+  const size_t vlds = layout == 1 ? roi_vec_lds_bytes(channels, pooled_h, pooled_w, sampling_ratio, &tb) : 0;
   if (layout == 0)
     roi_align_rotated_fwd_kernel<0><<<n_rois, ROI_THREADS, lds, st>>>(input, rois, output, channels, height, width,
                                                                       pooled_h, pooled_w, spatial_scale,
                                                                       sampling_ratio, aligned, clockwise);
+  else if (vlds)
+    roi_align_rotated_fwd_vec_kernel<0><<<n_rois, ROI_THREADS, vlds, st>>>(input, rois, output, channels, height, width,
+                                                                           pooled_h, pooled_w, spatial_scale,
+                                                                           sampling_ratio, aligned, clockwise, (int)tb);
   else
     roi_align_rotated_fwd_kernel<1><<<n_rois, ROI_THREADS, lds, st>>>(input, rois, output, channels, height, width,
                                                                       pooled_h, pooled_w, spatial_scale,
@@ -1375,10 +1606,16 @@ int sm3_roi_align_rotated_multilevel_forward(const float* const* inputs, const i
   if (rc) return rc;
   size_t lds = roi_lds_bytes(pooled_h, pooled_w, sampling_ratio);
   hipStream_t st = (hipStream_t)stream;
+  size_t tb = 0;
+  const size_t vlds = layout == 1 ? roi_vec_lds_bytes(channels, pooled_h, pooled_w, sampling_ratio, &tb) : 0;
   if (layout == 0)
     roi_align_rotated_fwd_kernel<0, 1><<<n_rois, ROI_THREADS, lds, st>>>(nullptr, rois, output, channels, 0, 0,
                                                                          pooled_h, pooled_w, 0.f, sampling_ratio,
                                                                          aligned, clockwise, lv);
+  else if (vlds)
+    roi_align_rotated_fwd_vec_kernel<1><<<n_rois, ROI_THREADS, vlds, st>>>(nullptr, rois, output, channels, 0, 0, pooled_h,
+                                                                           pooled_w, 0.f, sampling_ratio, aligned,
+                                                                           clockwise, (int)tb, lv);
   else
     roi_align_rotated_fwd_kernel<1, 1><<<n_rois, ROI_THREADS, lds, st>>>(nullptr, rois, output, channels, 0, 0,
                                                                          pooled_h, pooled_w, 0.f, sampling_ratio,
@@ -1408,6 +1645,85 @@ int sm3_roi_align_rotated_multilevel_backward(const float* grad_output, const fl
     roi_align_rotated_bwd_kernel<1, 1><<<n_rois, ROI_THREADS, lds, st>>>(grad_output, rois, nullptr, channels, 0, 0,
                                                                          pooled_h, pooled_w, 0.f, sampling_ratio,
                                                                          aligned, clockwise, lv);
+  return launch_status();
+}
+
+
+static int fill_tile_levels(RoiTileLevels& tl, float* const* grad_inputs, const int* heights, const int* widths,
+                            const float* scales, int nlev, float finest, int batch) {
+  if (nlev < 1 || nlev > ROI_MAX_LEVELS || !heights || !widths || !scales || batch <= 0) return -1;
+  int base = 0;
+  for (int i = 0; i < nlev; i++) {
+    if (heights[i] <= 0 || widths[i] <= 0 || (grad_inputs && !grad_inputs[i])) return -1;
+    tl.gin[i] = grad_inputs ? grad_inputs[i] : nullptr;
+    tl.h[i] = heights[i];
+    tl.w[i] = widths[i];
+    tl.tiles_x[i] = (widths[i] + RT - 1) / RT;
+    tl.tiles_y[i] = (heights[i] + RT - 1) / RT;
+    tl.scale[i] = scales[i];
+    tl.tile_base[i] = base;
+    base += batch * tl.tiles_x[i] * tl.tiles_y[i];
+  }
+  tl.tile_base[nlev] = base;
+  tl.n = nlev;
+  tl.finest = finest;
+  return base;
+}
+
+size_t sm3_roi_align_rotated_backward_tiled_workspace_bytes(int n_rois, int batch, int channels, int pooled_h, int pooled_w,
+                                                            int sampling_ratio, const int* heights, const int* widths,
+                                                            int num_levels) {
+  if (n_rois <= 0 || batch <= 0 || channels <= 0 || pooled_h <= 0 || pooled_w <= 0 || sampling_ratio <= 0 || !heights ||
+      !widths || num_levels < 1 || num_levels > ROI_MAX_LEVELS)
+    return 0;
+  long tiles = 0;
+  for (int i = 0; i < num_levels; i++)
+    tiles += (long)batch * ((heights[i] + RT - 1) / RT) * ((widths[i] + RT - 1) / RT);
+  const long bins = (long)pooled_h * pooled_w;
+  const long ents = (long)n_rois * bins * sampling_ratio * sampling_ratio * 4;
+  return align_up((size_t)(2 * tiles + 2) * sizeof(int), 256) + align_up((size_t)ents * sizeof(RoiEntry), 256) +
+         align_up((size_t)n_rois * bins * channels * sizeof(float), 256);
+}
+
+int sm3_roi_align_rotated_backward_tiled(const float* grad_output, const float* rois, float* const* grad_inputs,
+                                         const int* heights, const int* widths, const float* scales, int num_levels,
+                                         float finest_scale, int n_rois, int batch, int channels, int pooled_h,
+                                         int pooled_w, int sampling_ratio, int aligned, int clockwise, void* workspace,
+                                         size_t workspace_bytes, sm3_stream_t stream) {
+  if (n_rois < 0 || batch <= 0 || channels <= 0 || pooled_h <= 0 || pooled_w <= 0 || !grad_inputs) return SM3_ERR_INVALID_ARG;
+  if (sampling_ratio <= 0) return SM3_ERR_UNSUPPORTED;  // adaptive sampling grids: the scatter form
+  if (n_rois == 0) return SM3_OK;
+  if (!rois || !grad_output || (num_levels > 1 && !(finest_scale > 0.f))) return SM3_ERR_INVALID_ARG;
+  RoiTileLevels tl;
+  const int ntiles = fill_tile_levels(tl, grad_inputs, heights, widths, scales, num_levels, finest_scale, batch);
+  if (ntiles <= 0) return SM3_ERR_INVALID_ARG;
+  const size_t need = sm3_roi_align_rotated_backward_tiled_workspace_bytes(n_rois, batch, channels, pooled_h, pooled_w,
+                                                                          sampling_ratio, heights, widths, num_levels);
+  if (!workspace || workspace_bytes < need) return SM3_ERR_WORKSPACE;
+  if (n_rois > 65535) return SM3_ERR_UNSUPPORTED;  // batch dimension of the transpose launch
+  hipStream_t st = (hipStream_t)stream;
+  const long bins = (long)pooled_h * pooled_w;
+  const long ents = (long)n_rois * bins * sampling_ratio * sampling_ratio * 4;
+  char* w = (char*)workspace;
+  int* counts = (int*)w;
+  int* offsets = counts + ntiles;
+  w += align_up((size_t)(2 * ntiles + 2) * sizeof(int), 256);
+  RoiEntry* entries = (RoiEntry*)w;
+  w += align_up((size_t)ents * sizeof(RoiEntry), 256);
+  float* goT = (float*)w;
+  sm3_zero_async(counts, (size_t)ntiles * sizeof(int), st);
+  // (n, C, bins) -> (n, bins, C): an entry then reads one contiguous channel vector
+  int rc = sm3_transpose_f32(grad_output, goT, n_rois, channels, (int)bins, stream);
+  if (rc) return rc;
+  const long samples = (long)n_rois * bins * sampling_ratio * sampling_ratio;
+  const int nb = (int)((samples + 255) / 256);
+  roi_bwd_bin_kernel<0><<<nb, 256, 0, st>>>(rois, n_rois, pooled_h, pooled_w, sampling_ratio, aligned, clockwise, tl, counts,
+                                            nullptr, nullptr);
+  roi_bwd_scan_kernel<<<1, 1024, 0, st>>>(counts, offsets, ntiles);
+  roi_bwd_bin_kernel<1><<<nb, 256, 0, st>>>(rois, n_rois, pooled_h, pooled_w, sampling_ratio, aligned, clockwise, tl, counts,
+                                            offsets, entries);
+  const int cw = channels < RT_CH ? channels : RT_CH;
+  roi_bwd_tile_kernel<<<ntiles, 256, (size_t)RT_PX * cw * sizeof(float), st>>>(goT, offsets, entries, tl, channels);
   return launch_status();
 }
 

@@ -15,6 +15,7 @@ wrappers (``mmcv/mmcv/ops/{roi_align_rotated,box_iou_rotated,nms,deform_conv}.py
 Errors: device mismatch / wrong dtype / wrong shape raise ``RuntimeError`` like the reference's ``TORCH_CHECK``
 (pytorch_device_registry.hpp:111-124).  CPU tensors are REJECTED: there is no CPU implementation here.
 """
+import os
 import sys
 
 import torch
@@ -182,11 +183,26 @@ def roi_align_rotated_backward(grad_output, rois, grad_input, pooled_height, poo
             # scratch map and transpose it into the caller's tensor: one extra pass over the map.
             target = torch.zeros(B, H, W, C, device=grad_input.device, dtype=torch.float32)
             layout, via_nhwc = 1, True
-        check(lib().sm3_roi_align_rotated_backward(ptr(grad_output), ptr(rois), ptr(target), rois.size(0), B, C,
-                                                   H, W, int(pooled_height), int(pooled_width),
-                                                   float(spatial_scale), int(sampling_ratio), int(bool(aligned)),
-                                                   int(bool(clockwise)), layout, stream_ptr()),
-              'roi_align_rotated_backward')
+        n = rois.size(0)
+        if layout == 1 and n > 0 and int(sampling_ratio) > 0 and n <= 65535 and os.environ.get('SM3_ROI_BWD', 'tiled') == 'tiled':
+            # NHWC map: counting sort of the contributions by 8 x 8-pixel tile + one LDS accumulation per tile, no global
+            # atomics (ops_rotated.hip "RoIAlignRotated backward, TILED"); SM3_ROI_BWD=atomic keeps the scatter form (A/B)
+            import ctypes
+            hs, ws_, sc = (ctypes.c_int * 1)(H), (ctypes.c_int * 1)(W), (ctypes.c_float * 1)(float(spatial_scale))
+            gp = (ctypes.c_void_p * 1)(target.data_ptr())
+            nb = lib().sm3_roi_align_rotated_backward_tiled_workspace_bytes(n, B, C, int(pooled_height), int(pooled_width),
+                                                                           int(sampling_ratio), hs, ws_, 1)
+            wsp = workspace(nb, grad_input.device)
+            check(lib().sm3_roi_align_rotated_backward_tiled(ptr(grad_output), ptr(rois), gp, hs, ws_, sc, 1, 1.0, n, B, C,
+                                                             int(pooled_height), int(pooled_width), int(sampling_ratio),
+                                                             int(bool(aligned)), int(bool(clockwise)), ptr(wsp), nb,
+                                                             stream_ptr()), 'roi_align_rotated_backward_tiled')
+        else:
+            check(lib().sm3_roi_align_rotated_backward(ptr(grad_output), ptr(rois), ptr(target), n, B, C,
+                                                       H, W, int(pooled_height), int(pooled_width),
+                                                       float(spatial_scale), int(sampling_ratio), int(bool(aligned)),
+                                                       int(bool(clockwise)), layout, stream_ptr()),
+                  'roi_align_rotated_backward')
         if via_nhwc:  # grad_input (B, C, H*W) += scratch (B, H*W, C)^T
             check(lib().sm3_transpose_add_f32(ptr(target), ptr(grad_input), B, H * W, C, stream_ptr()),
                   'transpose_add_f32')

@@ -14,6 +14,7 @@ extractor and the box head's fully-connected stack.
 No CPU fallback.
 """
 import ctypes
+import os
 
 import torch
 import torch.nn as nn
@@ -72,7 +73,19 @@ class _MultiLevelRoIAlign(Function):
         fmt = torch.channels_last if ctx.layout == 1 else torch.contiguous_format
         grads = [torch.zeros(s, device=gout.device).contiguous(memory_format=fmt) for s in ctx.shapes]
         n = rois.shape[0]
-        if n:
+        if n and ctx.layout == 1 and int(sampling_ratio) > 0 and n <= 65535 and os.environ.get('SM3_ROI_BWD', 'tiled') == 'tiled':
+            # counting sort by 8 x 8-pixel tile + LDS accumulation, no global atomics (ops_rotated.hip, round 4)
+            ptrs = (ctypes.c_void_p * L)(*[g.data_ptr() for g in grads])
+            hs, ws, sc = ctx.geom
+            B, C = ctx.shapes[0][0], ctx.shapes[0][1]
+            lib = _lib.lib()
+            nb = lib.sm3_roi_align_rotated_backward_tiled_workspace_bytes(n, B, C, out_h, out_w, int(sampling_ratio), hs, ws, L)
+            wsp = _lib.workspace(nb, gout.device)
+            _lib.check(lib.sm3_roi_align_rotated_backward_tiled(
+                gout.contiguous().data_ptr(), rois.data_ptr(), ptrs, hs, ws, sc, L, float(finest), n, B, C, out_h, out_w,
+                int(sampling_ratio), int(bool(aligned)), int(bool(clockwise)), wsp.data_ptr(), nb, _lib.stream_ptr()),
+                'roi_align_rotated_backward_tiled')
+        elif n:
             ptrs = (ctypes.c_void_p * L)(*[g.data_ptr() for g in grads])
             hs, ws, sc = ctx.geom
             _lib.check(_lib.lib().sm3_roi_align_rotated_multilevel_backward(

@@ -388,3 +388,37 @@ def test_nms_rotated_threshold_equality_follows_cpu_path():
     ref = _ref_or_none()
     if ref is not None:
         assert ref.nms_rotated_cpu(torch.from_numpy(d), torch.from_numpy(s), 1.0).tolist() == [0, 1, 2, 4]
+
+
+# ----------------------------------------------------------------------------------- round 4: tiled backward, vector forward
+@pytest.mark.parametrize('C,hw', [(256, 64), (64, 40), (96, 33), (320, 24)])
+def test_roi_align_rotated_tiled_backward_equals_the_atomic_form(C, hw, monkeypatch):
+    """SM3_ROI_BWD=tiled (counting sort by 8x8 tile + LDS accumulation, the default on NHWC maps) against SM3_ROI_BWD=atomic
+    (the scatter kernel) and the oracle, batch 2, map sizes that are not multiples of the tile, channel counts below / at /
+    above the 256-channel LDS pass; accumulation into a non-zero grad_input."""
+    from sm3det_amd import mmcv_ext
+    O = _oracle()
+    B = 2
+    rois = synth.rois_for_level(300, 21, batch=B, extent=hw * 4.0, wh=(4.0, hw * 2.0))
+    go = np.random.RandomState(5).randn(300, C, 7, 7).astype(np.float32)
+    base = np.random.RandomState(6).randn(B, C, hw, hw).astype(np.float32)
+    exp = base + O.roi_align_rotated_backward(go, rois, base.shape, 7, 7, 0.25, 2, True, True)
+    outs = {}
+    for mode in ('tiled', 'atomic'):
+        monkeypatch.setenv('SM3_ROI_BWD', mode)
+        gi = dev(base).contiguous(memory_format=torch.channels_last)
+        mmcv_ext.roi_align_rotated_backward(dev(go), dev(rois), gi, 7, 7, 0.25, 2, True, True)
+        outs[mode] = gi.cpu().numpy()
+        assert np.allclose(outs[mode], exp, rtol=1e-4, atol=1e-4), (mode, np.abs(outs[mode] - exp).max())
+    assert np.allclose(outs['tiled'], outs['atomic'], rtol=1e-4, atol=1e-4)
+
+
+def test_roi_align_rotated_vector_forward_is_bit_identical_to_the_scalar_kernel():
+    """NHWC channel-vector forward (C % 4 == 0, 16-byte gathers) vs the NCHW scalar kernel on the same taps: same fp32
+    operation order per channel -> identical bits (small RoI count keeps the NCHW call on the scalar path)."""
+    ops = _ops()
+    x = torch.randn(2, 256, 48, 48, device='cuda')
+    rois = dev(synth.rois_for_level(5, 22, batch=2, extent=192.0, wh=(4.0, 120.0)))  # 5 RoIs: the NCHW call stays scalar
+    y_nchw = ops.roi_align_rotated(x, rois, 7, 0.25, 2, True, True)
+    y_nhwc = ops.roi_align_rotated(x.contiguous(memory_format=torch.channels_last), rois, 7, 0.25, 2, True, True)
+    assert torch.equal(y_nchw, y_nhwc)
