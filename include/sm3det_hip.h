@@ -477,6 +477,16 @@ int sm3_moe_combine_bwd(const float* dout, const float* yslot, const int32_t* to
 int sm3_moe_gather_add(const float* dxslot, const int32_t* token_slot, float* dx, long T, int C, int k,
                        int accumulate, sm3_stream_t stream);
 
+/* DeformConv2d forward WITHOUT the column matrix (round 4): the bilinear sampling of deformable_im2col
+ * (common/cuda/deform_conv_cuda_kernel.cuh:190-241) runs inside the A-operand producer of an MFMA GEMM whose column tile
+ * lives in LDS only.  x_nhwc (B,H,W,Cin); offset (B, 2*kh*kw, Ho, Wo) as the reference passes it; w_t = the weight
+ * (Cout,Cin,kh,kw) re-laid out as (kh*kw*Cin, Cout); out (B,Cout,Ho,Wo) -- replaces deform_conv_forward's im2col + addmm
+ * loop (pytorch/deform_conv.cpp:140-258) for groups = deformable_groups = 1 and Cin % 16 == 0 (`_supported` says so). */
+int sm3_deform_conv_fwd_fused_supported(int channels, int out_channels, int kh, int kw, int group, int deformable_group);
+int sm3_deform_conv_fwd_fused(const float* x_nhwc, const float* offset, const float* w_t, float* out, int batch, int channels,
+                              int height, int width, int out_channels, int kh, int kw, int pad_h, int pad_w, int stride_h,
+                              int stride_w, int dil_h, int dil_w, sm3_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * DeformConv2d sampling kernels (the device half of deform_conv_{forward,backward_input,backward_parameters},
  * pybind.cpp:38-57,501-522; semantics of pytorch/cpu/deform_conv.cpp:114-290).  Reference layouts: im

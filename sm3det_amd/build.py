@@ -22,6 +22,7 @@ FILE_FLAGS = {
     'ops_rotated.hip': ['-ffp-contract=off'],
     'deform_conv.hip': ['-ffp-contract=off'],
     'rpn.hip': ['-ffp-contract=off'],
+    'deform_fused.hip': ['-ffp-contract=off'],
 }
 
 

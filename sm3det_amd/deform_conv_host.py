@@ -12,6 +12,8 @@ up to 32 floats so that it feeds the GEMM kernels without a copy; the tiny re-la
 (step, C, H, W) and (C, step*H*W) views are torch glue on O(output) tensors, exactly where the reference does
 ``transpose_`` + ``copy_``.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -102,6 +104,19 @@ def deform_conv_forward(input, weight, offset, output, columns, ones, kW, kH, dW
     step = im2col_step
     if B % step:
         raise SM3Error('batch size must be divisible by im2col_step')
+    L = _lib.lib()
+    if (os.environ.get('SM3_DEFORM_FUSED', '1') != '0' and
+            L.sm3_deform_conv_fwd_fused_supported(nIn, nOut, kH, kW, group, deformable_group)):
+        # no column matrix: the sampling runs inside the MFMA GEMM's operand producer (csrc/deform_fused.hip).  The result
+        # does not depend on im2col_step (the reference only chunks the batch with it).
+        with torch.cuda.device(input.device):
+            x_nhwc = torch.empty(B, H, W, nIn, device=input.device)
+            _lib.check(L.sm3_transpose_f32(input.data_ptr(), x_nhwc.data_ptr(), B, nIn, H * W, _lib.stream_ptr()),
+                       'transpose_f32')
+            w_t = weight.permute(2, 3, 1, 0).reshape(kH * kW * nIn, nOut).contiguous()
+            LB.call('deform_conv_fwd_fused', x_nhwc, offset, w_t, output, B, nIn, H, W, nOut, kH, kW, padH, padW, dH, dW,
+                    dilationH, dilationW, flops=2.0 * B * Ho * Wo * nOut * nIn * kH * kW)
+        return
     ncols = step * Ho * Wo
     ld = _rup(ncols, 32)
     Kg = nIn // group * kH * kW

@@ -151,3 +151,29 @@ def test_deform_conv_bench_shape_2x256x128x128_vs_compiled_reference():
     ext.deform_conv_backward_parameters(xc, oc, goc, gw, e, e, *args, 1.0, 2)
     assert rel(out, out_r) < 1e-4
     assert rel(gi, gi_r) < 1e-3 and rel(goff, goff_r) < 1e-3 and rel(gw, gw_r) < 1e-3
+
+
+@pytest.mark.parametrize('B,Cin,Cout,H,W,k,stride,pad,dil', [(3, 48, 20, 37, 29, 3, 2, 1, 1), (2, 16, 132, 19, 23, 3, 1, 2, 2),
+                                                             (1, 64, 256, 40, 40, 3, 1, 1, 1), (2, 32, 8, 9, 7, 2, 1, 0, 1)])
+def test_fused_forward_equals_the_im2col_gemm_path(B, Cin, Cout, H, W, k, stride, pad, dil, monkeypatch):
+    """round 4: the forward without the column matrix (csrc/deform_fused.hip: sampling inside the GEMM's operand producer)
+    against the im2col + GEMM path on the same inputs -- identical column values by construction, only the fp32
+    accumulation order over K differs: 2e-5 of the output scale; strides / dilations / channel counts off the tile sizes,
+    sampling points far outside the image included (offsets randn * 3)."""
+    from sm3det_amd import mmcv_ext as ext
+    g = torch.Generator().manual_seed(B * 100 + Cin)
+    Ho = (H + 2 * pad - (dil * (k - 1) + 1)) // stride + 1
+    Wo = (W + 2 * pad - (dil * (k - 1) + 1)) // stride + 1
+    x = torch.randn(B, Cin, H, W, generator=g).cuda()
+    off = (torch.randn(B, 2 * k * k, Ho, Wo, generator=g) * 3).cuda()
+    w = (torch.randn(Cout, Cin, k, k, generator=g) * 0.2).cuda()
+    args = (k, k, stride, stride, pad, pad, dil, dil, 1, 1)
+    e = torch.zeros(0, device='cuda')
+    outs = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('SM3_DEFORM_FUSED', mode)
+        out = torch.full((B, Cout, Ho, Wo), float('nan'), device='cuda')
+        ext.deform_conv_forward(x, w, off, out, e, e, *args, B)
+        outs[mode] = out
+    assert bool(torch.isfinite(outs['1']).all())
+    assert rel(outs['1'], outs['0']) < 2e-5
