@@ -8,13 +8,15 @@
 //   out[pos, cout] = sum_{tap, cin} sample(x, pos, tap)[cin] * W[cout, cin, tap]        M = B*Ho*Wo, N = Cout, K = 9*Cin
 //
 // * x is read as NHWC (one transpose pass by the host wrapper): the four bilinear corners of (position, tap) are the same
-//   for every input channel, so a thread fetches them as 16-byte channel vectors (8 channels of a 16-channel k-tile),
+//   for every input channel, so a thread fetches them as 16-byte channel vectors (4 channels of a 16-channel k-tile),
 //   blends them with the reference's own expression (w1*v1 + w2*v2 + w3*v3 + w4*v4, -ffp-contract=off: the column values
 //   are bit-identical to deformable_im2col's) and writes them k-major into LDS -- the column tile never leaves the CU;
 // * the 2 x 9 offsets of a position are loaded once into registers (deformable_group = 1); the corner addresses and
 //   weights are recomputed only when the tap changes (every Cin/16 k-steps);
-// * weights come as W^T (taps*Cin, Cout) (a 2.4 MB re-layout by the wrapper), staged k-major as well; 128 x 128 tile,
-//   4 waves x (2 x 2) v_mfma_f32_32x32x2_f32, double-buffered LDS, one barrier per 16-deep k-step;
+// * weights come as W^T (taps*Cin, Cout) (a 2.4 MB re-layout by the wrapper), staged k-major as well; 64 x 256 tile
+//   (positions x output channels: with 128 x 128 tiles two workgroups sampled every position, 516 us; the producer is the
+//   bottleneck, not the matrix pipe), 4 waves side by side along the channels, each 2 x 2 v_mfma_f32_32x32x2_f32,
+//   double-buffered LDS, one barrier per 16-deep k-step;
 // * the output goes straight to the reference layout (B, Cout, Ho, Wo): a lane owns one position, so the 32 lanes of a
 //   half-wave write 128 contiguous bytes per output channel.
 // Restrictions (else the wrapper keeps the im2col + GEMM path): groups = 1, deformable_groups = 1, Cin % 16 == 0.
@@ -25,7 +27,7 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int BM = 64, BN = 256, BK = 16;  // 64 positions x all 256 output channels: a position is sampled ONCE per tap
 constexpr int LDA = BM + 2, LDB = BN + 4;
 constexpr int MAX_TAPS = 9;
 
@@ -42,20 +44,18 @@ __global__ __launch_bounds__(256, 3) void deform_conv_fwd_fused_kernel(const flo
   __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
-  const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+  const int wm0 = 0, wn0 = wave * 64;
   const int taps = g.kh * g.kw;
   const long HoWo = (long)g.Ho * g.Wo;
   const long M = (long)g.B * HoWo;
-  // both column tiles of a row tile on one XCD (hardware block b runs on XCD b % 8): the sampled pixels are shared in L2
   const int ntn = (g.Cout + BN - 1) / BN;
-  const int bx = blockIdx.x;
-  const int tile_n = (bx / 8) % ntn, tile_m = (bx / (8 * ntn)) * 8 + (bx & 7);
+  const int tile_n = blockIdx.x % ntn, tile_m = blockIdx.x / ntn;
   const long m0 = (long)tile_m * BM;
   if (m0 >= M) return;
   const int n0 = tile_n * BN;
 
-  // ---- A producer: thread -> (position p, 8-channel half of the k-tile)
-  const int p = tid >> 1, half = tid & 1;
+  // ---- A producer: thread -> (position p, 4-channel quarter of the k-tile)
+  const int p = tid >> 2, quarter = tid & 3;
   const long m = m0 + p;
   const bool pvalid = m < M;
   const long mc = pvalid ? m : M - 1;
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256, 3) void deform_conv_fwd_fused_kernel(const flo
       ow[t] = op[HoWo];
     }
   }
-  const float* xb = x + (long)b * g.H * g.W * g.Cin + 8 * half;
+  const float* xb = x + (long)b * g.H * g.W * g.Cin + 4 * quarter;
   // geometry of the current tap (deformable_im2col + im2col_bilinear, deform_conv_cuda_kernel.cuh:190-241 / :60-101)
   long c1 = 0, c2 = 0, c3 = 0, c4 = 0;  // element offsets of the four corners' pixel rows
   float w1 = 0.f, w2 = 0.f, w3 = 0.f, w4 = 0.f;
@@ -112,40 +112,37 @@ __global__ __launch_bounds__(256, 3) void deform_conv_fwd_fused_kernel(const flo
   };
   const int kt_per_tap = g.Cin / BK;
   const int nk = taps * kt_per_tap;
-  f32x4 cv[4][2];  // corner channel vectors of the k-tile in flight
-  f32x4 bv[2];     // weight rows of the k-tile in flight
-  const int b_row = tid >> 5, b_cq = tid & 31;
+  f32x4 cv[4];  // corner channel vectors of the k-tile in flight
+  f32x4 bv[4];  // weight rows of the k-tile in flight
+  const int b_row = tid >> 6, b_cq = tid & 63;
   const int b_col = min(n0 + 4 * b_cq, g.Cout - 4);
   auto issue = [&](int kt) {
     const int t = kt / kt_per_tap, c0 = (kt - t * kt_per_tap) * BK;
     if (kt % kt_per_tap == 0) tap_geometry(t);
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
     const float* q = xb + c0;
-#pragma unroll
-    for (int u = 0; u < 2; u++) {
+    {
       // clamped address + select (no branch around the loads: the whole batch stays in flight)
-      const f32x4 a1 = *reinterpret_cast<const f32x4*>(q + c1 + 4 * u), a2 = *reinterpret_cast<const f32x4*>(q + c2 + 4 * u);
-      const f32x4 a3 = *reinterpret_cast<const f32x4*>(q + c3 + 4 * u), a4 = *reinterpret_cast<const f32x4*>(q + c4 + 4 * u);
-      cv[0][u] = k1 ? a1 : z;
-      cv[1][u] = k2 ? a2 : z;
-      cv[2][u] = k3 ? a3 : z;
-      cv[3][u] = k4 ? a4 : z;
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(q + c1), a2 = *reinterpret_cast<const f32x4*>(q + c2);
+      const f32x4 a3 = *reinterpret_cast<const f32x4*>(q + c3), a4 = *reinterpret_cast<const f32x4*>(q + c4);
+      cv[0] = k1 ? a1 : z;
+      cv[1] = k2 ? a2 : z;
+      cv[2] = k3 ? a3 : z;
+      cv[3] = k4 ? a4 : z;
     }
 #pragma unroll
-    for (int u = 0; u < 2; u++)
-      bv[u] = *reinterpret_cast<const f32x4*>(wT + ((long)kt * BK + b_row + 8 * u) * g.Cout + b_col);
+    for (int u = 0; u < 4; u++)
+      bv[u] = *reinterpret_cast<const f32x4*>(wT + ((long)kt * BK + b_row + 4 * u) * g.Cout + b_col);
   };
   auto stage = [&](int buf) {
 #pragma unroll
-    for (int u = 0; u < 2; u++)
+    for (int e = 0; e < 4; e++) {
+      // the reference's expression, term order kept (contraction off for this file): identical column values
+      const float v = w1 * cv[0][e] + w2 * cv[1][e] + w3 * cv[2][e] + w4 * cv[3][e];
+      As[buf][4 * quarter + e][p] = v;
+    }
 #pragma unroll
-      for (int e = 0; e < 4; e++) {
-        // the reference's expression, term order kept (contraction off for this file): identical column values
-        const float v = w1 * cv[0][u][e] + w2 * cv[1][u][e] + w3 * cv[2][u][e] + w4 * cv[3][u][e];
-        As[buf][8 * half + 4 * u + e][p] = v;
-      }
-#pragma unroll
-    for (int u = 0; u < 2; u++) *reinterpret_cast<f32x4*>(&Bs[buf][b_row + 8 * u][4 * b_cq]) = bv[u];
+    for (int u = 0; u < 4; u++) *reinterpret_cast<f32x4*>(&Bs[buf][b_row + 4 * u][4 * b_cq]) = bv[u];
   };
 
   f32x16 acc[2][2];
@@ -224,9 +221,8 @@ int sm3_deform_conv_fwd_fused(const float* x_nhwc, const float* offset, const fl
   if (g.Ho < 1 || g.Wo < 1) return SM3_ERR_INVALID_ARG;
   const long M = (long)batch * g.Ho * g.Wo;
   const long ntm = (M + BM - 1) / BM, ntn = (out_channels + BN - 1) / BN;
-  const long ntm8 = (ntm + 7) / 8 * 8;  // the tile map hands out row tiles in groups of 8 (one per XCD)
-  if (ntm8 * ntn > 0x7fffffffl) return SM3_ERR_UNSUPPORTED;
-  deform_conv_fwd_fused_kernel<<<(unsigned)(ntm8 * ntn), 256, 0, (hipStream_t)stream>>>(x_nhwc, offset, w_t, out, g);
+  if (ntm * ntn > 0x7fffffffl) return SM3_ERR_UNSUPPORTED;
+  deform_conv_fwd_fused_kernel<<<(unsigned)(ntm * ntn), 256, 0, (hipStream_t)stream>>>(x_nhwc, offset, w_t, out, g);
   return launch_status();
 }
 

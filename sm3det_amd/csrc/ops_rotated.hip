@@ -1140,7 +1140,7 @@ __global__ __launch_bounds__(ROI_THREADS) void roi_align_rotated_bwd_kernel(
 // two runs of the atomic form): covered by the same 1e-4 tolerance.
 constexpr int RT = 8;                 // tile edge in pixels
 constexpr int RT_PX = RT * RT;
-constexpr int RT_CH = 256;            // channels per LDS pass (64 px x 256 ch x 4 B = 64 KiB)
+constexpr int RT_CH = 128;            // channels per workgroup (64 px x 128 ch x 4 B = 32 KiB of LDS)
 struct RoiTileLevels {
   float* gin[ROI_MAX_LEVELS];
   int h[ROI_MAX_LEVELS], w[ROI_MAX_LEVELS], tiles_x[ROI_MAX_LEVELS], tiles_y[ROI_MAX_LEVELS];
@@ -1215,11 +1215,17 @@ __global__ __launch_bounds__(1024) void roi_bwd_scan_kernel(int* __restrict__ co
   if (threadIdx.x == 1023) offsets[ntiles] = part[1023];
 }
 
-// one workgroup per tile.  thread -> (channel tid % CW, entry stripe tid / CW), CW = min(C, 256) rounded to the chunk
+// one workgroup per (tile, 128-channel chunk).  The tile's entry list is brought into LDS in chunks (coalesced), then two
+// stripes of 128 channel-lanes walk it with 8 independent channel-vector reads in flight each (the first version read
+// every entry from global memory just before the gradient it addresses: two dependent round trips per entry, 1.15 ms on
+// the bench shape against 0.31 ms for the atomic form).
+constexpr int RT_ENT = 680;  // entries per LDS chunk (8 KiB)
 __global__ __launch_bounds__(256) void roi_bwd_tile_kernel(const float* __restrict__ goT, const int* __restrict__ offsets,
                                                           const RoiEntry* __restrict__ entries, RoiTileLevels lv,
                                                           int channels) {
-  extern __shared__ __attribute__((aligned(16))) float tile[];  // [64 px][CW]
+  __shared__ __attribute__((aligned(16))) float tile[RT_PX * RT_CH];  // [64 px][CW]
+  __shared__ int ent_rb[RT_ENT], ent_px[RT_ENT];
+  __shared__ float ent_w[RT_ENT];
   const int t = blockIdx.x;
   const int e0 = offsets[t], e1 = offsets[t + 1];
   if (e1 == e0) return;  // nothing lands here: grad_input keeps its values
@@ -1230,38 +1236,39 @@ __global__ __launch_bounds__(256) void roi_bwd_tile_kernel(const float* __restri
   const int ty = t2 % lv.tiles_y[l], b = t2 / lv.tiles_y[l];
   const int H = lv.h[l], W = lv.w[l];
   float* gin = lv.gin[l] + (size_t)b * H * W * channels;
-  for (int c0 = 0; c0 < channels; c0 += RT_CH) {
-    const int CW = min(RT_CH, channels - c0);
-    for (int i = threadIdx.x; i < RT_PX * CW; i += 256) tile[i] = 0.f;
+  const int c0 = blockIdx.y * RT_CH;
+  const int CW = min(RT_CH, channels - c0);
+  for (int i = threadIdx.x; i < RT_PX * CW; i += 256) tile[i] = 0.f;
+  const int stripes = 256 / CW > 0 ? 256 / CW : 1;  // CW = 128: 2 stripes; smaller chunks: more stripes
+  const int c = threadIdx.x % CW, st = threadIdx.x / CW;
+  const float* gcol = goT + c0 + c;
+  for (int base = e0; base < e1; base += RT_ENT) {
+    const int cnt = min(RT_ENT, e1 - base);
+    __syncthreads();  // tile zeroed / previous chunk consumed
+    for (int i = threadIdx.x; i < cnt; i += 256) {
+      const RoiEntry a = entries[base + i];
+      ent_rb[i] = a.rb;
+      ent_px[i] = a.lpx;
+      ent_w[i] = a.w;
+    }
     __syncthreads();
-    const int stripes = 256 / CW > 0 ? 256 / CW : 1;
-    const int c = threadIdx.x % CW, st = threadIdx.x / CW;
     if (st < stripes) {
-      // CW < 256: several stripes walk the list interleaved; CW == 256: one stripe, one channel per thread
-      for (int cc = c; cc < CW; cc += 256) {
-        int e = e0 + st;
-        for (; e + 3 * stripes < e1; e += 4 * stripes) {  // four independent channel-vector reads in flight
-          const RoiEntry a0 = entries[e], a1 = entries[e + stripes], a2 = entries[e + 2 * stripes], a3 = entries[e + 3 * stripes];
-          const float g0 = goT[(size_t)a0.rb * channels + c0 + cc], g1 = goT[(size_t)a1.rb * channels + c0 + cc];
-          const float g2 = goT[(size_t)a2.rb * channels + c0 + cc], g3 = goT[(size_t)a3.rb * channels + c0 + cc];
-          atomicAdd(tile + a0.lpx * CW + cc, g0 * a0.w);
-          atomicAdd(tile + a1.lpx * CW + cc, g1 * a1.w);
-          atomicAdd(tile + a2.lpx * CW + cc, g2 * a2.w);
-          atomicAdd(tile + a3.lpx * CW + cc, g3 * a3.w);
-        }
-        for (; e < e1; e += stripes) {
-          const RoiEntry a = entries[e];
-          atomicAdd(tile + a.lpx * CW + cc, goT[(size_t)a.rb * channels + c0 + cc] * a.w);
-        }
+      int e = st;
+      for (; e + 7 * stripes < cnt; e += 8 * stripes) {
+        float g[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) g[u] = gcol[(size_t)ent_rb[e + u * stripes] * channels];
+#pragma unroll
+        for (int u = 0; u < 8; u++) atomicAdd(tile + ent_px[e + u * stripes] * CW + c, g[u] * ent_w[e + u * stripes]);
       }
+      for (; e < cnt; e += stripes) atomicAdd(tile + ent_px[e] * CW + c, gcol[(size_t)ent_rb[e] * channels] * ent_w[e]);
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < RT_PX * CW; i += 256) {
-      const int px = i / CW, cc = i - px * CW;
-      const int y = ty * RT + px / RT, x = tx * RT + px % RT;
-      if (y < H && x < W) gin[((size_t)y * W + x) * channels + c0 + cc] += tile[i];
-    }
-    __syncthreads();
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < RT_PX * CW; i += 256) {
+    const int px = i / CW, cc = i - px * CW;
+    const int y = ty * RT + px / RT, x = tx * RT + px % RT;
+    if (y < H && x < W) gin[((size_t)y * W + x) * channels + c0 + cc] += tile[i];
   }
 }
 
@@ -1722,8 +1729,8 @@ int sm3_roi_align_rotated_backward_tiled(const float* grad_output, const float* 
   roi_bwd_scan_kernel<<<1, 1024, 0, st>>>(counts, offsets, ntiles);
   roi_bwd_bin_kernel<1><<<nb, 256, 0, st>>>(rois, n_rois, pooled_h, pooled_w, sampling_ratio, aligned, clockwise, tl, counts,
                                             offsets, entries);
-  const int cw = channels < RT_CH ? channels : RT_CH;
-  roi_bwd_tile_kernel<<<ntiles, 256, (size_t)RT_PX * cw * sizeof(float), st>>>(goT, offsets, entries, tl, channels);
+  dim3 tgrid((unsigned)ntiles, (unsigned)((channels + RT_CH - 1) / RT_CH));
+  roi_bwd_tile_kernel<<<tgrid, 256, 0, st>>>(goT, offsets, entries, tl, channels);
   return launch_status();
 }
 

@@ -208,8 +208,11 @@ class _RCNNLoss(Function):
                   'rcnn_loss_forward')
         ctx.desc, ctx.keep = d, (labels, valid, rois, gts, label_w, targets)
         ctx.save_for_backward(cls_score, bbox_pred, counts)
-        ctx.mark_non_differentiable(out[2])
-        return out[0], out[1], out[2]
+        # three independent scalars (clones, not views of `out`: an in-place op on one returned loss must not alias the
+        # others), and the SAME `acc` object is marked and returned -- marking a temporary view had no effect
+        l_cls, l_box, acc = out[0].clone(), out[1].clone(), out[2].clone()
+        ctx.mark_non_differentiable(acc)
+        return l_cls, l_box, acc
 
     @staticmethod
     def backward(ctx, g_cls, g_bbox, _g_acc):

@@ -430,6 +430,10 @@ def param_groups_from_cfg(modules, optimizer_cfg):
             back[0.0] = None
             per_field[field] = {}
             for name, q in shadow.named_parameters():
+                if bool(torch.isnan(q.detach()).any()):
+                    # still holds the NaN fill: no reference key reached it through load_state_dict (a parameter this
+                    # package adds, or a key the hooks do not map) -- say so instead of reporting mixed options
+                    raise KeyError(f'{prefix}.{name}: no reference parameter covers it (state_dict schema mismatch)')
                 lo, hi = float(q.detach().min()), float(q.detach().max())
                 if lo != hi or lo not in back:
                     raise NotImplementedError(f'{prefix}.{name}: its reference parameters carry different `{field}` options; '

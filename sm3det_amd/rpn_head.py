@@ -202,8 +202,15 @@ class OrientedRPNHead(nn.Module):
         if train_cfg is not None:
             from .assign import BBOX_ASSIGNERS, BBOX_SAMPLERS
             self.assigner = BBOX_ASSIGNERS.build(train_cfg['assigner'])
-            self.sampler = BBOX_SAMPLERS.build(train_cfg.get('sampler', dict(type='RandomSampler', num=256,
-                                                                             pos_fraction=0.5)))
+            if 'sampler' not in train_cfg:
+                # mmdet's AnchorHead falls back to PseudoSampler (every anchor is a sample) when the config names no
+                # sampler; every SM3Det config names RandomSampler(num=256, pos_fraction=0.5).  Not guessed here.
+                raise NotImplementedError('OrientedRPNHead: train_cfg without `sampler` (mmdet would use PseudoSampler)')
+            if train_cfg['sampler'].get('add_gt_as_proposals', False):
+                # mmdet's RandomSampler defaults this flag to True; the SM3Det rpn configs set it to False
+                # (local_configs/main_SM3Det.py:174) and the anchor loss below does not implement the True form
+                raise NotImplementedError('OrientedRPNHead: rpn sampler with add_gt_as_proposals=True')
+            self.sampler = BBOX_SAMPLERS.build(train_cfg['sampler'])
         self._anchor_cache = {}
         self._init_layers()
 
@@ -420,6 +427,14 @@ class OrientedRPNHead(nn.Module):
             return losses
         with torch.no_grad():
             if fixed_size:
+                # the fixed-size path decodes the whole batch against ONE image extent (one anchor set, one clamp); with
+                # keep-ratio resize + padding the images of a batch may differ: refuse instead of clamping image i > 0 to
+                # image 0's extent (the reference decodes each image with its own img_meta['img_shape'])
+                if any(tuple(m['img_shape'][:2]) != tuple(img_metas[0]['img_shape'][:2]) or
+                       tuple(m.get('pad_shape', m['img_shape'])[:2]) != tuple(img_metas[0].get('pad_shape', img_metas[0]['img_shape'])[:2])
+                       for m in img_metas):
+                    raise NotImplementedError('OrientedRPNHead.forward_train(fixed_size=True): the images of a batch must '
+                                              'share img_shape / pad_shape; pass fixed_size=False for mixed extents')
                 shape = img_metas[0]['img_shape']
                 lvl, _, _ = self._train_anchors([tuple(c.shape[-2:]) for c in cls_scores],
                                                 img_metas[0].get('pad_shape', shape), shape, cls_scores[0].device)
