@@ -390,6 +390,10 @@ int sm3_stem_patchify(const float* x, float* a, int B, int H, int W, sm3_stream_
  * accumulate_dx != 0 adds into dx. */
 int sm3_layernorm_fwd(const float* x, const float* w, const float* b, float eps, float* y, float* mean, float* rstd,
                       long T, int C, int out_mode, int H, int W, sm3_stream_t stream);
+/* dst (n halves) = round-to-nearest-even fp16 of src (n floats, n % 4 == 0): the fp16 shadow of a weight tensor that the
+ * fp16-operand GEMMs read as their B operand (io bit 2 on NT / NN) -- the half model `wrap_fp16_model` keeps next to the
+ * fp32 master weights (mmcv/mmcv/runner/fp16_utils.py, hooks/optimizer.py:245-261 copy_params_to_fp16). */
+int sm3_cast_f32_f16(const float* src, void* dst, long n, sm3_stream_t stream);
 /* scratch for the column reductions of layernorm_bwd / scale_bwd_prep / moe_combine_bwd (per-block partials) */
 size_t sm3_row_reduce_workspace_bytes(int C);
 /* The three kernels reduce their partials themselves unless their reduction output (dwdb / dgamma_db / dgamma) is NULL;

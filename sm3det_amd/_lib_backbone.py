@@ -36,6 +36,7 @@ def signatures():
         'sm3_colsum_f32': (I, [P, I, I, I, P, I, P, P]),
         'sm3_stem_patchify': (I, [P, P, I, I, I, P]),
         'sm3_layernorm_fwd': (I, [P, P, P, F, P, P, P, LL, I, I, I, I, P]),
+        'sm3_cast_f32_f16': (I, [P, P, LL, P]),
         'sm3_row_reduce_workspace_bytes': (S, [I]),
         'sm3_layernorm_bwd': (I, [P, P, P, P, P, P, P, LL, I, I, I, I, I, P, S, P]),
         'sm3_dwconv7_fwd': (I, [P, P, P, P, P, I, I, I, I, I, P]),

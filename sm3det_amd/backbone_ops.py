@@ -244,6 +244,21 @@ def _half():
 
 
 AMP_HALF_STORAGE = os.environ.get('SM3_AMP_STORAGE', 'fp16') != 'fp32'
+# fp16 SHADOWS of the FFN / expert weights as the B operand of the four GEMMs of a block (what the half model of
+# `wrap_fp16_model` holds next to the fp32 master weights): a third fewer operand bytes through the L1, which bounds the
+# fp16-operand launches.  SM3_AMP_W16=1 turns it on (bit-identical results: the loader rounds the fp32 weights to the
+# same halves); default off until it measures faster inside the step.
+AMP_W16 = os.environ.get('SM3_AMP_W16', '0') == '1'
+
+
+def _shadow(w):
+    """the tensor the fp16-operand GEMMs read for weight `w`: `w` itself, or its fp16 shadow (cast each forward, inside the
+    captured graph; the backward of the same step reuses it)"""
+    if not (LB.COMPUTE == 1 and AMP_HALF_STORAGE and AMP_W16):
+        return w
+    s = torch.empty(w.shape, dtype=torch.float16, device=w.device)
+    call('cast_f32_f16', w, s, w.numel(), nbytes=6.0 * w.numel())
+    return s
 
 
 def _dw_ln_forward(x, w49, bdw, lnw, lnb, eps, B, H, W, C):
@@ -285,6 +300,7 @@ class _DenseBlock(Function):
         Hd = w1.shape[0]
         u, xn, mean, rstd = _dw_ln_forward(x, w49, bdw, lnw, lnb, eps, B, H, W, C)
         hpre, act = _e(T, Hd, like=x, dtype=xn.dtype), _e(T, Hd, like=x, dtype=xn.dtype)
+        w1, w2 = _shadow(w1), _shadow(w2)
         gemm(LB.NT, xn, w1, act, T, Hd, C, epilogue=LB.EPI_BIAS_GELU, bias=b1, aux_out=hpre)  # hpre := gelu'(h)
         y, out = _e(T, C, like=x), _e(T, C, like=x)
         gemm(LB.NT, act, w2, out, T, C, Hd, epilogue=LB.EPI_BIAS_SCALE_RES, bias=b2, aux_in=x, aux_out=y,
@@ -399,6 +415,7 @@ class _MoEBlock(Function):
             call('moe_dispatch', xn, slot_token, xslot, S, C, nbytes=8.0 * S * C)
         # experts: grouped GEMM pair over the expert-major slots
         hpre, act = _e(S, Hd, like=x, dtype=xn.dtype), _e(S, Hd, like=x, dtype=xn.dtype)
+        w1, w2 = _shadow(w1), _shadow(w2)
         gemm(LB.NT, xslot, w1, act, S, Hd, C, epilogue=LB.EPI_BIAS_GELU, bias=b1, aux_out=hpre, offsets=offsets,
              num_groups=E)
         yslot = _e(S, C, like=x)

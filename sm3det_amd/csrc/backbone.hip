@@ -673,6 +673,27 @@ int sm3_stem_patchify(const float* x, float* a, int B, int H, int W, sm3_stream_
   return launch_status();
 }
 
+namespace {
+// fp16 shadow of an fp32 tensor (round-to-nearest-even, like a torch .half() cast): the half weights of the AMP data path
+__global__ __launch_bounds__(256) void cast_f32_f16_kernel(const float* __restrict__ x, _Float16* __restrict__ y, long n4) {
+  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    reinterpret_cast<f16x4*>(y)[i] = f16x4{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+  }
+}
+}  // namespace
+
+int sm3_cast_f32_f16(const float* src, void* dst, long n, sm3_stream_t stream) {
+  if (n < 0 || (n & 3)) return SM3_ERR_INVALID_ARG;
+  if (n == 0) return SM3_OK;
+  if (!src || !dst) return SM3_ERR_INVALID_ARG;
+  long blocks = (n / 4 + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  cast_f32_f16_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(src, reinterpret_cast<_Float16*>(dst), n / 4);
+  return launch_status();
+}
+
 int sm3_layernorm_fwd(const float* x, const float* w, const float* b, float eps, float* y, float* mean, float* rstd,
                       long T, int C, int out_mode, int H, int W, sm3_stream_t stream) {
   if (!x || !w || !b || !y || T < 0 || C <= 0 || (C & 3) || out_mode < 0 || out_mode > 2) return SM3_ERR_INVALID_ARG;

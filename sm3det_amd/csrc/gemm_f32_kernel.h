@@ -191,7 +191,7 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
   constexpr int BM = TL::BM, BN = TL::BN, TI = TL::TI, TJ = TL::TJ, WN = TL::WN, WM = TL::WM;
   constexpr bool A16 = (IO & IO_A16) != 0, B16 = (IO & IO_B16) != 0, C16 = (IO & IO_C16) != 0, X16 = (IO & IO_X16) != 0;
   static_assert(IO == 0 || (F16 && !GATHER), "fp16 storage only with fp16 operands");
-  static_assert(!B16 || MODE == MODE_TN, "fp16 B operand: only the weight-gradient form (weights stay fp32)");
+  // B16 in NT / NN: the B operand is an fp16 SHADOW of the weights (what wrap_fp16_model's half model holds), see gemm_h16.hip
   static_assert(!X16 || EPI == EPI_BIAS_GELU || EPI == EPI_GELU_BWD, "fp16 auxiliary tensor = GELU' only");
   constexpr int EA = A16 ? 2 : 4, EB = B16 ? 2 : 4;  // bytes per element in HBM
   // A tile is written transposed (k-contiguous source) in NT/NN, directly (k-major source) in TN; B transposed in NT.
@@ -455,7 +455,8 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
       m0 = row0;
     }
     n0 = tile_n * BN;
-    Bg = p.B + (MODE == MODE_TN ? 0 : (long)g * p.strideB);
+    Bg = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.B) +
+                                        (MODE == MODE_TN ? 0 : (long)g * p.strideB * (B16 ? 2 : 4)));
     kbase = 0;
     if (MODE == MODE_TN) {
       nk = (max(row_end - row0, 0) + BK - 1) / BK;
@@ -535,7 +536,7 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
         const int rl = t_r + T_ROWS * i;
         const int n = min(n0 + min(rl, BN - 1), p.N - 1);
         pb[i] = Bg + (long)n * p.ldb + 4 * t_kq + (long)kbase * BK;
-        ob[i] = (unsigned)(((long)(n - n0) * p.ldb + 4 * t_kq) * 4);
+        ob[i] = (unsigned)(((long)(n - n0) * p.ldb + 4 * t_kq) * EB);
       } else {
         constexpr int QR = BN / 4;
         const int idx = tid + NTHREADS * i;
@@ -568,8 +569,8 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
         }
       }
     }
-    if (MODE == MODE_NT) b_base = reinterpret_cast<const char*>(Bg + (long)n0 * p.ldb + (long)kbase * BK);
-    else if (MODE == MODE_NN) b_base = reinterpret_cast<const char*>(Bg + (GATHER ? 0 : (long)kbase * BK * p.ldb));
+    if (MODE == MODE_NT) b_base = reinterpret_cast<const char*>(Bg) + ((long)n0 * p.ldb + (long)kbase * BK) * EB;
+    else if (MODE == MODE_NN) b_base = reinterpret_cast<const char*>(Bg) + (GATHER ? 0 : (long)kbase * BK * p.ldb) * EB;
     else if (GATHER == 2) b_base = reinterpret_cast<const char*>(Bg) - (long)(p.sW + 1) * p.cC * 4;
     else b_base = reinterpret_cast<const char*>(Bg) + (long)row0 * p.ldb * EB;
     long a_valid, b_valid;
@@ -687,7 +688,8 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
           rb[i] = kr < row_end ? v : zero4;
         }
       } else if (MODE == MODE_NT) {
-        rb[i] = ldg(b_rsrc, (long)kt * BK * 4, ob[i]);
+        if (B16) rb[i] = ldg2(b_rsrc, (long)kt * BK * 2, ob[i]);  // four stored halves of one weight row
+        else rb[i] = ldg(b_rsrc, (long)kt * BK * 4, ob[i]);
       } else if (GATHER) {
         // NN gather (input gradient): B row k = (tap, co) lives at W[co][tap][:]  (ldb = 9 * Cin, + tap * N columns)
         const int kg = kt + kbase;
@@ -696,7 +698,7 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
         rb[i] = ldg(b_rsrc, ((long)c0 * p.ldb + (long)tap * p.N) * 4, ob[i]);
       } else if (F16) {  // NN: B rows are k
 #pragma unroll
-        for (int kk = 0; kk < 4; kk++) rb[i][kk] = ldg1(b_rsrc, ((long)kt * BK + kk) * p.ldb * 4, ob[i]);
+        for (int kk = 0; kk < 4; kk++) rb[i][kk] = ldg1(b_rsrc, ((long)kt * BK + kk) * p.ldb * EB, ob[i]);
       } else {
         rb[i] = ldg(b_rsrc, (long)kt * BK * p.ldb * 4, ob[i]);
       }
@@ -752,7 +754,10 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
       }
     } else {
       const int i = q - PA;
-      if (F16 && B16) {
+      if (F16 && B16 && B_TRANS) {
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<u32x2*>(Bw + buf * B_ST16 + hb[i]) = u32x2{bits(rb[i][0]), bits(rb[i][1])};  // already halves
+      } else if (F16 && B16) {
         typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
         uint32_t* d = Bw + buf * B_ST16 + hb[i];
         *reinterpret_cast<u32x2*>(d) = u32x2{lo2(rb[i][0], rb[i][1]), lo2(rb[i][2], rb[i][3])};

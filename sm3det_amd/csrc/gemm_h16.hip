@@ -7,7 +7,9 @@
 //   NN  A16            dh(f16) . W             -> fp32                                      (FC1 input gradient)
 //   TN  B16            dy(fp32)^T . act(f16)   -> fp32                                      (FC2 / gate weight gradient)
 //   TN  A16|B16        dh(f16)^T . x(f16)      -> fp32                                      (FC1 weight gradient)
-// Weights, biases, the residual stream and all C-wide gradients stay fp32.
+// Weights, biases, the residual stream and all C-wide gradients stay fp32.  With `| B16` on an NT / NN form the B operand is
+// read from an fp16 SHADOW of the (fp32 master) weights: what the half model of wrap_fp16_model holds -- a third fewer
+// operand bytes through the L1 (opt-in: SM3_AMP_W16=1, backbone_ops._shadow).
 #include "gemm_f32_kernel.h"
 
 namespace sm3gemm {
@@ -36,6 +38,13 @@ int launch_nt_h16(const GemmParams& p, int epi, int tile, int bk, int io, dim3 g
     if (epi == EPI_BIAS_SCALE_RES) return by_tile_h<MODE_NT, EPI_BIAS_SCALE_RES, IO_A16>(p, tile, bk, grid, st);
   } else if (io == (IO_A16 | IO_C16 | IO_X16)) {
     if (epi == EPI_BIAS_GELU) return by_tile_h<MODE_NT, EPI_BIAS_GELU, IO_A16 | IO_C16 | IO_X16>(p, tile, bk, grid, st);
+  } else if (io == (IO_A16 | IO_B16)) {  // weights read from their fp16 shadow
+    if (epi == EPI_NONE) return by_tile_h<MODE_NT, EPI_NONE, IO_A16 | IO_B16>(p, tile, bk, grid, st);
+    if (epi == EPI_BIAS) return by_tile_h<MODE_NT, EPI_BIAS, IO_A16 | IO_B16>(p, tile, bk, grid, st);
+    if (epi == EPI_BIAS_SCALE_RES) return by_tile_h<MODE_NT, EPI_BIAS_SCALE_RES, IO_A16 | IO_B16>(p, tile, bk, grid, st);
+  } else if (io == (IO_A16 | IO_B16 | IO_C16 | IO_X16)) {
+    if (epi == EPI_BIAS_GELU)
+      return by_tile_h<MODE_NT, EPI_BIAS_GELU, IO_A16 | IO_B16 | IO_C16 | IO_X16>(p, tile, bk, grid, st);
   }
   return SM3_ERR_UNSUPPORTED;
 }
@@ -44,6 +53,9 @@ int launch_nn_h16(const GemmParams& p, int epi, int tile, int bk, int io, dim3 g
   if (io == IO_A16 && epi == EPI_NONE) return by_tile_h<MODE_NN, EPI_NONE, IO_A16>(p, tile, bk, grid, st);
   if (io == (IO_C16 | IO_X16) && epi == EPI_GELU_BWD)
     return by_tile_h<MODE_NN, EPI_GELU_BWD, IO_C16 | IO_X16>(p, tile, bk, grid, st);
+  if (io == (IO_A16 | IO_B16) && epi == EPI_NONE) return by_tile_h<MODE_NN, EPI_NONE, IO_A16 | IO_B16>(p, tile, bk, grid, st);
+  if (io == (IO_B16 | IO_C16 | IO_X16) && epi == EPI_GELU_BWD)
+    return by_tile_h<MODE_NN, EPI_GELU_BWD, IO_B16 | IO_C16 | IO_X16>(p, tile, bk, grid, st);
   return SM3_ERR_UNSUPPORTED;
 }
 

@@ -184,6 +184,104 @@ def test_gemm_fp16_storage_grouped_experts():
         assert rel_err(dW2, refw2) < 3e-5
 
 
+@pytest.mark.parametrize('M,N,K', [(1000, 384, 96), (2050, 96, 384), (515, 768, 192), (700, 256, 3072)])
+def test_gemm_fp16_weight_shadows_nt_nn(M, N, K):
+    """fp16 SHADOWS of the weights as the B operand (io bit 2 on the NT / NN forms): every combination the blocks use,
+    against the fp64 product of the same half operands -- identical arithmetic to reading the fp32 weights and rounding them
+    in the loader, so also bit-identical to that path; k-steps 32 and 64, every tile."""
+    from sm3det_amd import _lib_backbone as LB
+    from sm3det_amd import amp
+    A = (_rand(M, K, seed=1) * 0.5).half()
+    W = _rand(N, K, seed=2) * 0.1
+    Wh = W.half()
+    bias = _rand(N, seed=3)
+    ref = A.double() @ Wh.double().t() + bias.double()
+    with amp.autocast():
+        for tune in (0, (2 << 4) | 1, (3 << 4) | 1, (2 << 4) | 2, (3 << 4) | 6):
+            LB.TUNING = tune
+            try:
+                C0, C1 = torch.zeros(M, N, device='cuda'), torch.full((M, N), float('nan'), device='cuda')
+                LB.gemm(LB.NT, A, W, C0, M, N, K, epilogue=LB.EPI_BIAS, bias=bias)
+                LB.gemm(LB.NT, A, Wh, C1, M, N, K, epilogue=LB.EPI_BIAS, bias=bias)
+                assert rel_err(C1, ref) < 2e-5 and torch.equal(C0, C1), tune
+                act, dact = (torch.zeros(M, N, device='cuda', dtype=torch.half) for _ in range(2))
+                act0, dact0 = (torch.zeros(M, N, device='cuda', dtype=torch.half) for _ in range(2))
+                LB.gemm(LB.NT, A, W, act0, M, N, K, epilogue=LB.EPI_BIAS_GELU, bias=bias, aux_out=dact0)
+                LB.gemm(LB.NT, A, Wh, act, M, N, K, epilogue=LB.EPI_BIAS_GELU, bias=bias, aux_out=dact)
+                assert torch.equal(act, act0) and torch.equal(dact, dact0), tune
+                res, gam = _rand(M, N, seed=4), _rand(N, seed=5)
+                y, out = torch.zeros(M, N, device='cuda'), torch.zeros(M, N, device='cuda')
+                LB.gemm(LB.NT, A, Wh, out, M, N, K, epilogue=LB.EPI_BIAS_SCALE_RES, bias=bias, aux_in=res, aux_out=y,
+                        gamma=gam)
+                assert rel_err(y, ref) < 2e-5 and rel_err(out, res.double() + gam.double() * ref) < 2e-5, tune
+                # NN, dh (half) @ W (half shadow, (N, K) row-major = k-major for this form)
+                dh = (_rand(M, N, seed=6) * 0.3).half()
+                dx = torch.full((M, K), float('nan'), device='cuda')
+                LB.gemm(LB.NN, dh, Wh, dx, M, K, N)
+                assert rel_err(dx, dh.double() @ Wh.double()) < 2e-5, tune
+                # NN, dy (fp32) @ W2 (half shadow) x GELU' (half) -> dh (half) + column sums
+                dy = _rand(M, K, seed=7) * 0.2
+                W2h = (_rand(K, N, seed=8) * 0.1).half()
+                gp = (_rand(M, N, seed=9).abs() * 0.5).half()
+                dh2, db = torch.zeros(M, N, device='cuda', dtype=torch.half), torch.zeros(N, device='cuda')
+                LB.gemm(LB.NN, dy, W2h, dh2, M, N, K, epilogue=LB.EPI_GELU_BWD, aux_in=gp, colsum_out=db)
+                r2 = (dy.half().double() @ W2h.double()) * gp.double()
+                assert rel_err(dh2, r2) < 1.5e-3 and rel_err(db, r2.sum(0)) < 1e-4, tune
+            finally:
+                LB.TUNING = 0
+
+
+def test_gemm_fp16_weight_shadows_grouped_experts():
+    from sm3det_amd import _lib_backbone as LB
+    from sm3det_amd import amp
+    E, C_, Hd = 4, 192, 768
+    counts = torch.tensor([300, 0, 515, 209])
+    offs = torch.cat([torch.zeros(1, dtype=torch.long), counts.cumsum(0)]).int().cuda()
+    S = int(counts.sum())
+    X = (_rand(S, C_, seed=1) * 0.5).half()
+    W1, b1 = _rand(E, Hd, C_, seed=2) * 0.05, _rand(E, Hd, seed=3)
+    with amp.autocast():
+        a0, d0 = (torch.zeros(S, Hd, device='cuda', dtype=torch.half) for _ in range(2))
+        a1, d1 = (torch.zeros(S, Hd, device='cuda', dtype=torch.half) for _ in range(2))
+        LB.gemm(LB.NT, X, W1, a0, S, Hd, C_, epilogue=LB.EPI_BIAS_GELU, bias=b1, aux_out=d0, offsets=offs, num_groups=E)
+        LB.gemm(LB.NT, X, W1.half(), a1, S, Hd, C_, epilogue=LB.EPI_BIAS_GELU, bias=b1, aux_out=d1, offsets=offs,
+                num_groups=E)
+        assert torch.equal(a0, a1) and torch.equal(d0, d1)
+        dh = (_rand(S, Hd, seed=4) * 0.3).half()
+        x0, x1 = torch.zeros(S, C_, device='cuda'), torch.zeros(S, C_, device='cuda')
+        LB.gemm(LB.NN, dh, W1, x0, S, C_, Hd, offsets=offs, num_groups=E)
+        LB.gemm(LB.NN, dh, W1.half(), x1, S, C_, Hd, offsets=offs, num_groups=E)
+        assert torch.equal(x0, x1)
+
+
+@pytest.mark.parametrize('name', ['moe_e4k2', 'moe_e8k3'])
+def test_backbone_with_weight_shadows_equals_the_loader_rounding_path(name):
+    """SM3_AMP_W16: the blocks read fp16 shadows of the FFN / expert weights -- the same rounded values the loader produces
+    from the fp32 weights, so outputs and every gradient are bit-identical to the default AMP data path."""
+    from sm3det_amd import amp
+    from sm3det_amd import backbone_ops as BO
+    from sm3det_amd.convnext_moe import ConvNeXt_moe_MultiInput
+    from tests.test_backbone_gpu import _ref_key_grads
+    fx = load_fixture(name)
+    res = []
+    for w16 in (False, True):
+        BO.AMP_W16 = w16
+        try:
+            net = ConvNeXt_moe_MultiInput(**fx['cfg'])
+            net.load_state_dict(fx['state_dict'], strict=True)
+            net = amp.wrap_fp16_model(net.cuda()).train()
+            outs, gl = net(fx['x'].cuda(), ['single'], noise=[n.cuda() for n in fx['noise']],
+                           drop_scale=[d.cuda() for d in fx['drop_scale']])
+            loss_of(outs, gl).backward()
+            res.append(([o.detach().clone() for o in outs], {k: v.detach().clone() for k, v in _ref_key_grads(net).items()}))
+        finally:
+            BO.AMP_W16 = False
+    for a, b in zip(res[0][0], res[1][0]):
+        assert torch.equal(a, b)
+    for k in res[0][1]:
+        assert torch.equal(res[0][1][k], res[1][1][k]), k
+
+
 def test_layernorm_fp16_output_and_unsupported_io_fails_loudly():
     from sm3det_amd import _lib_backbone as LB
     from sm3det_amd import amp
@@ -196,9 +294,9 @@ def test_layernorm_fp16_output_and_unsupported_io_fails_loudly():
     ref = torch.nn.functional.layer_norm(x.double(), (C,), w.double(), b.double(), 1e-6)
     assert (y.double() - ref).abs().max().item() <= 1e-3 * ref.abs().max().item()
     assert torch.equal(y, ref.float().half()) or (y.double() - ref.float().half().double()).abs().max() <= 2e-3
-    with amp.autocast():  # fp16 WEIGHTS are not a supported storage form
+    with amp.autocast():  # an fp16 weight shadow next to an fp32 activation operand is not a supported storage form
         with pytest.raises(SM3Error):
-            LB.gemm(LB.NT, _rand(64, 96).half(), _rand(96, 96).half(), torch.zeros(64, 96, device='cuda'), 64, 96, 96)
+            LB.gemm(LB.NT, _rand(64, 96), _rand(96, 96).half(), torch.zeros(64, 96, device='cuda'), 64, 96, 96)
     with pytest.raises(SM3Error):  # half tensors outside autocast
         LB.gemm(LB.NT, _rand(64, 96).half(), _rand(96, 96), torch.zeros(64, 96, device='cuda'), 64, 96, 96)
 
