@@ -933,7 +933,10 @@ __global__ __launch_bounds__(ROI_THREADS) void roi_align_rotated_fwd_kernel(
     spatial_scale = lv.scale[l];
     if (lv.levels_out && threadIdx.x == 0) lv.levels_out[n] = l;
   }
-  const RoiGeom g = roi_geometry(rois + 6 * (size_t)n, spatial_scale, aligned, clockwise, PH, PW, sampling_ratio);
+  __shared__ RoiGeom g_sh;  // the RoI's geometry (two double-precision sincos) once per workgroup, not once per thread
+  if (threadIdx.x == 0) g_sh = roi_geometry(rois + 6 * (size_t)n, spatial_scale, aligned, clockwise, PH, PW, sampling_ratio);
+  __syncthreads();
+  const RoiGeom g = g_sh;
   const int bins = PH * PW;
   const int spb = g.grid_h * g.grid_w;  // samples per bin
   const int nsamp = bins * spb;
@@ -1014,7 +1017,11 @@ __global__ __launch_bounds__(ROI_THREADS) void roi_align_rotated_fwd_vec_kernel(
     spatial_scale = lv.scale[l];
     if (lv.levels_out && threadIdx.x == 0) lv.levels_out[n] = l;
   }
-  const RoiGeom g = roi_geometry(rois + 6 * (size_t)n, spatial_scale, aligned, clockwise, PH, PW, sampling_ratio);
+  // the RoI's geometry (two double-precision sincos) once per workgroup, not once per thread
+  __shared__ RoiGeom g_sh;
+  if (threadIdx.x == 0) g_sh = roi_geometry(rois + 6 * (size_t)n, spatial_scale, aligned, clockwise, PH, PW, sampling_ratio);
+  __syncthreads();
+  const RoiGeom g = g_sh;
   const int bins = PH * PW;
   const int spb = g.grid_h * g.grid_w;  // samples per bin
   const int nsamp = bins * spb;
@@ -1077,7 +1084,10 @@ __global__ __launch_bounds__(ROI_THREADS) void roi_align_rotated_bwd_kernel(
     width = lv.w[l];
     spatial_scale = lv.scale[l];
   }
-  const RoiGeom g = roi_geometry(rois + 6 * (size_t)n, spatial_scale, aligned, clockwise, PH, PW, sampling_ratio);
+  __shared__ RoiGeom g_sh;  // the RoI's geometry (two double-precision sincos) once per workgroup, not once per thread
+  if (threadIdx.x == 0) g_sh = roi_geometry(rois + 6 * (size_t)n, spatial_scale, aligned, clockwise, PH, PW, sampling_ratio);
+  __syncthreads();
+  const RoiGeom g = g_sh;
   const int bins = PH * PW;
   const int spb = g.grid_h * g.grid_w;
   const int nsamp = bins * spb;
@@ -1155,37 +1165,45 @@ struct RoiEntry {
   float w;   // bilinear weight / samples per bin
 };
 
-// PASS 0: count the entries of every tile; PASS 1: file them (offsets from the scan, cursors zeroed)
+// PASS 0: count the entries of every tile; PASS 1: file them (offsets from the scan, cursors zeroed).  One workgroup per
+// RoI: its geometry (two double-precision sincos) is computed once and shared (one thread per sample each evaluating it
+// took 115 us per pass on the bench shape).
 template <int PASS>
 __global__ __launch_bounds__(256) void roi_bwd_bin_kernel(const float* __restrict__ rois, int n_rois, int PH, int PW,
                                                          int sampling_ratio, int aligned, int clockwise, RoiTileLevels lv,
                                                          int* __restrict__ counts, const int* __restrict__ offsets,
                                                          RoiEntry* __restrict__ entries) {
   const int bins = PH * PW, spb = sampling_ratio * sampling_ratio;
-  const long total = (long)n_rois * bins * spb;
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= total) return;
-  const int n = (int)(i / (bins * spb));
-  const int r0 = (int)(i - (long)n * bins * spb);
-  const int bin = r0 / spb, r = r0 - bin * spb;
+  const int n = blockIdx.x;
   const float* roi = rois + 6 * (size_t)n;
-  const int l = lv.n > 1 ? roi_target_level(roi, lv.finest, lv.n) : 0;
-  const RoiGeom g = roi_geometry(roi, lv.scale[l], aligned, clockwise, PH, PW, sampling_ratio);
+  __shared__ RoiGeom g_sh;
+  __shared__ int l_sh;
+  if (threadIdx.x == 0) {
+    const int l0 = lv.n > 1 ? roi_target_level(roi, lv.finest, lv.n) : 0;
+    l_sh = l0;
+    g_sh = roi_geometry(roi, lv.scale[l0], aligned, clockwise, PH, PW, sampling_ratio);
+  }
+  __syncthreads();
+  const RoiGeom g = g_sh;
+  const int l = l_sh;
   const int H = lv.h[l], W = lv.w[l];
-  const Sample s = make_sample(g, H, W, bin / PW, bin % PW, r / g.grid_w, r % g.grid_w);
-  if (s.p1 < 0) return;
-  const int ps[4] = {s.p1, s.p2, s.p3, s.p4};
-  const float ws[4] = {s.w1, s.w2, s.w3, s.w4};
   const float count = (float)spb;
+  for (int r0 = threadIdx.x; r0 < bins * spb; r0 += 256) {
+    const int bin = r0 / spb, r = r0 - bin * spb;
+    const Sample s = make_sample(g, H, W, bin / PW, bin % PW, r / g.grid_w, r % g.grid_w);
+    if (s.p1 < 0) continue;
+    const int ps[4] = {s.p1, s.p2, s.p3, s.p4};
+    const float ws[4] = {s.w1, s.w2, s.w3, s.w4};
 #pragma unroll
-  for (int c = 0; c < 4; c++) {
-    const int y = ps[c] / W, x = ps[c] - y * W;
-    const int tile = lv.tile_base[l] + (g.batch * lv.tiles_y[l] + y / RT) * lv.tiles_x[l] + x / RT;
-    if (PASS == 0) {
-      atomicAdd(counts + tile, 1);
-    } else {
-      const int slot = offsets[tile] + atomicAdd(counts + tile, 1);
-      entries[slot] = RoiEntry{n * bins + bin, (y % RT) * RT + (x % RT), ws[c] / count};
+    for (int c = 0; c < 4; c++) {
+      const int y = ps[c] / W, x = ps[c] - y * W;
+      const int tile = lv.tile_base[l] + (g.batch * lv.tiles_y[l] + y / RT) * lv.tiles_x[l] + x / RT;
+      if (PASS == 0) {
+        atomicAdd(counts + tile, 1);
+      } else {
+        const int slot = offsets[tile] + atomicAdd(counts + tile, 1);
+        entries[slot] = RoiEntry{n * bins + bin, (y % RT) * RT + (x % RT), ws[c] / count};
+      }
     }
   }
 }
@@ -1254,21 +1272,36 @@ __global__ __launch_bounds__(256) void roi_bwd_tile_kernel(const float* __restri
     __syncthreads();
     if (st < stripes) {
       int e = st;
-      for (; e + 7 * stripes < cnt; e += 8 * stripes) {
-        float g[8];
+      for (; e + 15 * stripes < cnt; e += 16 * stripes) {
+        float g[16];
 #pragma unroll
-        for (int u = 0; u < 8; u++) g[u] = gcol[(size_t)ent_rb[e + u * stripes] * channels];
+        for (int u = 0; u < 16; u++) g[u] = gcol[(size_t)ent_rb[e + u * stripes] * channels];
 #pragma unroll
-        for (int u = 0; u < 8; u++) atomicAdd(tile + ent_px[e + u * stripes] * CW + c, g[u] * ent_w[e + u * stripes]);
+        for (int u = 0; u < 16; u++) atomicAdd(tile + ent_px[e + u * stripes] * CW + c, g[u] * ent_w[e + u * stripes]);
       }
       for (; e < cnt; e += stripes) atomicAdd(tile + ent_px[e] * CW + c, gcol[(size_t)ent_rb[e] * channels] * ent_w[e]);
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < RT_PX * CW; i += 256) {
-    const int px = i / CW, cc = i - px * CW;
-    const int y = ty * RT + px / RT, x = tx * RT + px % RT;
-    if (y < H && x < W) gin[((size_t)y * W + x) * channels + c0 + cc] += tile[i];
+  // flush: grad_input += tile, eight independent read-modify-writes in flight per thread (a rolled loop waited for every
+  // load before issuing the next: 32 dependent HBM round trips per workgroup)
+  const int total = RT_PX * CW;
+  for (int i0 = threadIdx.x; i0 < total; i0 += 8 * 256) {
+    float* ptr[8];
+    float old[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int i = i0 + 256 * u;
+      const int ic = min(i, total - 1);
+      const int px = ic / CW, cc = ic - px * CW;
+      const int y = ty * RT + px / RT, x = tx * RT + px % RT;
+      const bool ok = i < total && y < H && x < W;
+      ptr[u] = ok ? gin + ((size_t)y * W + x) * channels + c0 + cc : nullptr;
+      old[u] = ok ? *ptr[u] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+      if (ptr[u]) *ptr[u] = old[u] + tile[min(i0 + 256 * u, total - 1)];
   }
 }
 
@@ -1722,8 +1755,7 @@ int sm3_roi_align_rotated_backward_tiled(const float* grad_output, const float* 
   // (n, C, bins) -> (n, bins, C): an entry then reads one contiguous channel vector
   int rc = sm3_transpose_f32(grad_output, goT, n_rois, channels, (int)bins, stream);
   if (rc) return rc;
-  const long samples = (long)n_rois * bins * sampling_ratio * sampling_ratio;
-  const int nb = (int)((samples + 255) / 256);
+  const int nb = n_rois;  // one workgroup per RoI
   roi_bwd_bin_kernel<0><<<nb, 256, 0, st>>>(rois, n_rois, pooled_h, pooled_w, sampling_ratio, aligned, clockwise, tl, counts,
                                             nullptr, nullptr);
   roi_bwd_scan_kernel<<<1, 1024, 0, st>>>(counts, offsets, ntiles);
