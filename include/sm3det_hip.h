@@ -123,20 +123,22 @@ int sm3_roi_align_rotated_multilevel_backward(const float* grad_output, const fl
                                               int channels, int pooled_h, int pooled_w, int sampling_ratio,
                                               int aligned, int clockwise, int layout, sm3_stream_t stream);
 
-/* RoIAlignRotated backward WITHOUT global atomics (round 4; NHWC maps, sampling_ratio > 0): the contributions are filed
- * under 8 x 8-pixel tiles of the gradient maps by a counting sort and every tile is accumulated in LDS and added to
- * grad_inputs[l] once.  Same semantics as sm3_roi_align_rotated{,_multilevel}_backward (`grad_input +=`,
- * roi_align_rotated_cuda_kernel.cuh:129-200 / cpu/roi_align_rotated.cpp:272-372); num_levels == 1: a single map, the level
- * rule is not evaluated.  `batch` = images per map.  workspace: tile counters / offsets, the entries, the transposed
- * grad_output. */
+/* RoIAlignRotated backward as a GATHER (round 4; NHWC maps, sampling_ratio > 0, channels % 4 == 0): a counting sort files
+ * every corner contribution under the pixel it lands on, and one wave per 16 pixels of an 8 x 8-pixel tile sums a pixel's
+ * contributions in registers and adds them to grad_inputs[l] once -- no atomic accumulation.  Same semantics as
+ * sm3_roi_align_rotated{,_multilevel}_backward (`grad_input +=`, roi_align_rotated_cuda_kernel.cuh:129-200 /
+ * cpu/roi_align_rotated.cpp:272-372) with overwrite == 0; overwrite != 0: the maps need NOT be zero-filled, every pixel is
+ * written (the result of the reference's `new_zeros` + kernel, mmcv/ops/roi_align_rotated.py:88-103, without the fill
+ * pass).  num_levels == 1: a single map, the level rule is not evaluated.  `batch` = images per map.  workspace: pixel
+ * counters / offsets, the entries, the transposed grad_output. */
 size_t sm3_roi_align_rotated_backward_tiled_workspace_bytes(int n_rois, int batch, int channels, int pooled_h, int pooled_w,
                                                             int sampling_ratio, const int* heights, const int* widths,
                                                             int num_levels);
 int sm3_roi_align_rotated_backward_tiled(const float* grad_output, const float* rois, float* const* grad_inputs,
                                          const int* heights, const int* widths, const float* scales, int num_levels,
                                          float finest_scale, int n_rois, int batch, int channels, int pooled_h,
-                                         int pooled_w, int sampling_ratio, int aligned, int clockwise, void* workspace,
-                                         size_t workspace_bytes, sm3_stream_t stream);
+                                         int pooled_w, int sampling_ratio, int aligned, int clockwise, int overwrite,
+                                         void* workspace, size_t workspace_bytes, sm3_stream_t stream);
 
 /* =========================================================================================================
  * Backbone hot path (a): grid-level sparse-MoE ConvNeXt.  Reference: mmrotate/models/backbones/convnext_moe.py.

@@ -49,7 +49,7 @@ def _declare(lib):
         'sm3_roi_align_rotated_multilevel_forward': (I, [P, P, P, P, I, F, P, P, P, I, I, I, I, I, I, I, I, P]),
         'sm3_roi_align_rotated_multilevel_backward': (I, [P, P, P, P, P, P, I, F, I, I, I, I, I, I, I, I, P]),
         'sm3_roi_align_rotated_backward_tiled_workspace_bytes': (S, [I, I, I, I, I, I, P, P, I]),
-        'sm3_roi_align_rotated_backward_tiled': (I, [P, P, P, P, P, P, I, F, I, I, I, I, I, I, I, I, P, S, P]),
+        'sm3_roi_align_rotated_backward_tiled': (I, [P, P, P, P, P, P, I, F, I, I, I, I, I, I, I, I, I, P, S, P]),
     }
     from . import _lib_backbone, det_losses
     sig.update(_lib_backbone.signatures())

@@ -13,6 +13,8 @@
 #include <stdint.h>
 
 #include "../../include/sm3det_hip.h"
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -1140,17 +1142,20 @@ __global__ __launch_bounds__(ROI_THREADS) void roi_align_rotated_bwd_kernel(
 // ---------------------------------------------------------------- RoIAlignRotated backward, TILED (round 4)
 // The kernel above scatters every (RoI, bin, sample, corner) contribution with a global fp32 atomic: 410 MB of atomic
 // traffic for 512 RoIs on the 256 x 256 x 256 level against 160 MB of algorithmic bytes, 0.05 of the HBM roofline.  The
-// tiled form inverts the loop: the gradient map is cut into 8 x 8-pixel tiles, a counting sort files every corner
-// contribution under the tile its pixel lies in (entry = RoI-bin index, pixel inside the tile, bilinear weight / count),
-// and one workgroup per tile accumulates its entries into a 64-pixel x C tile in LDS (ds_add_f32; lanes along the
-// channels, so an entry is one coalesced read of the bin's channel vector from the TRANSPOSED gradient (n, bins, C)) and
-// adds the tile to grad_input ONCE with plain loads and stores -- every pixel belongs to exactly one tile, so no global
-// atomic is left and `grad_input +=` semantics (the reference's atomicAdd form) are kept.  NHWC maps, sampling_ratio > 0.
-// Same samples and weights as the scatter kernels (make_sample); the sum order inside a pixel differs (as it does between
-// two runs of the atomic form): covered by the same 1e-4 tolerance.
+// tiled form inverts the loop into a GATHER: a counting sort files every corner contribution under the PIXEL it lands on
+// (key = 8 x 8-pixel tile * 64 + pixel inside the tile; entry = RoI-bin index, bilinear weight / count), and one wave per
+// 16 pixels of a tile walks their entries in pixel order with the lanes along the channels: an entry is one coalesced
+// 1 KiB read of the bin's channel vector from the TRANSPOSED gradient (n, bins, C), a pixel's sum lives in registers and
+// is added to grad_input once -- no atomic of any kind (a first version accumulated unsorted entries of a tile with
+// ds_add_f32: 0.77 ms, 0.74 of them the LDS float atomics; its counting sort on 2048 tile counters spent 0.11 ms per
+// pass on same-line global atomics, 0.02 ms on the 131 k pixel keys), and `grad_input +=` semantics (the reference's
+// atomicAdd form) are kept because
+// every pixel belongs to exactly one workgroup.  NHWC maps, sampling_ratio > 0.  Same samples and weights as the scatter
+// kernels (make_sample); the sum order inside a pixel differs (as it does between two runs of the atomic form): covered
+// by the same 1e-4 tolerance.
 constexpr int RT = 8;                 // tile edge in pixels
 constexpr int RT_PX = RT * RT;
-constexpr int RT_CH = 128;            // channels per workgroup (64 px x 128 ch x 4 B = 32 KiB of LDS)
+constexpr int RT_CH = 256;            // channels per workgroup (a float4 per lane)
 struct RoiTileLevels {
   float* gin[ROI_MAX_LEVELS];
   int h[ROI_MAX_LEVELS], w[ROI_MAX_LEVELS], tiles_x[ROI_MAX_LEVELS], tiles_y[ROI_MAX_LEVELS];
@@ -1161,13 +1166,11 @@ struct RoiTileLevels {
 };
 struct RoiEntry {
   int rb;    // roi * bins + bin
-  int lpx;   // pixel inside the tile, row-major 8 x 8
   float w;   // bilinear weight / samples per bin
 };
 
-// PASS 0: count the entries of every tile; PASS 1: file them (offsets from the scan, cursors zeroed).  One workgroup per
-// RoI: its geometry (two double-precision sincos) is computed once and shared (one thread per sample each evaluating it
-// took 115 us per pass on the bench shape).
+// PASS 0: count the entries of every (tile, pixel) key; PASS 1: file them (offsets from the scan, cursors zeroed).  One
+// workgroup per RoI: its geometry (two double-precision sincos) is computed once and shared.
 template <int PASS>
 __global__ __launch_bounds__(256) void roi_bwd_bin_kernel(const float* __restrict__ rois, int n_rois, int PH, int PW,
                                                          int sampling_ratio, int aligned, int clockwise, RoiTileLevels lv,
@@ -1198,55 +1201,85 @@ __global__ __launch_bounds__(256) void roi_bwd_bin_kernel(const float* __restric
     for (int c = 0; c < 4; c++) {
       const int y = ps[c] / W, x = ps[c] - y * W;
       const int tile = lv.tile_base[l] + (g.batch * lv.tiles_y[l] + y / RT) * lv.tiles_x[l] + x / RT;
+      const int key = tile * RT_PX + (y % RT) * RT + (x % RT);
       if (PASS == 0) {
-        atomicAdd(counts + tile, 1);
+        atomicAdd(counts + key, 1);
       } else {
-        const int slot = offsets[tile] + atomicAdd(counts + tile, 1);
-        entries[slot] = RoiEntry{n * bins + bin, (y % RT) * RT + (x % RT), ws[c] / count};
+        const int slot = offsets[key] + atomicAdd(counts + key, 1);
+        entries[slot] = RoiEntry{n * bins + bin, ws[c] / count};
       }
     }
   }
 }
 
-// exclusive scan of the tile counts (one workgroup; a few thousand tiles) + zero the cursors for pass 1
-__global__ __launch_bounds__(1024) void roi_bwd_scan_kernel(int* __restrict__ counts, int* __restrict__ offsets, int ntiles) {
-  __shared__ int part[1024];
-  const int per = (ntiles + 1023) / 1024;
-  const int b = threadIdx.x * per, e = min(ntiles, b + per);
-  int s = 0;
-  for (int i = b; i < e; i++) s += counts[i];
-  part[threadIdx.x] = s;
+// exclusive scan of the key counts in two launches of nkeys / 1024 workgroups: (1) the sum of every 1024-key block,
+// (2) each block adds up the sums of the blocks before it (a few hundred words), scans its own keys and zeroes them
+// (they become the cursors of the filing pass).  A single-workgroup scan took 138 us over the 131 k keys of a 256 x 256 map.
+constexpr int RS_KEYS = 1024;
+__device__ __forceinline__ int block_sum_256(int v, int* red) {
+  for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1) {
-    const int v = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
-    __syncthreads();
-    part[threadIdx.x] += v;
-    __syncthreads();
+  const int s = red[0] + red[1] + red[2] + red[3];
+  __syncthreads();
+  return s;
+}
+__global__ __launch_bounds__(256) void roi_bwd_blocksum_kernel(const int* __restrict__ counts, int* __restrict__ bsum, int nkeys) {
+  __shared__ int red[4];
+  const int i = blockIdx.x * RS_KEYS + threadIdx.x * 4;
+  int v = 0;
+#pragma unroll
+  for (int u = 0; u < 4; u++) v += i + u < nkeys ? counts[i + u] : 0;
+  const int s = block_sum_256(v, red);
+  if (threadIdx.x == 0) bsum[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void roi_bwd_scan_kernel(int* __restrict__ counts, int* __restrict__ offsets,
+                                                          const int* __restrict__ bsum, int nkeys) {
+  __shared__ int red[4];
+  __shared__ int wsum[4];
+  int before = 0;
+  for (int j = threadIdx.x; j < (int)blockIdx.x; j += 256) before += bsum[j];
+  const int base = block_sum_256(before, red);
+  const int i = blockIdx.x * RS_KEYS + threadIdx.x * 4;
+  int c[4], v = 0;
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    c[u] = i + u < nkeys ? counts[i + u] : 0;
+    v += c[u];
   }
-  int run = threadIdx.x ? part[threadIdx.x - 1] : 0;
-  for (int i = b; i < e; i++) {
-    const int c = counts[i];
-    offsets[i] = run;
-    counts[i] = 0;
-    run += c;
+  // inclusive scan of the per-thread sums: inside the wave by shuffles, across the four waves through LDS
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int inc = v;
+  for (int o = 1; o < 64; o <<= 1) {
+    const int n = __shfl_up(inc, o);
+    if (lane >= o) inc += n;
   }
-  if (threadIdx.x == 1023) offsets[ntiles] = part[1023];
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  int run = base + inc - v;
+  for (int w = 0; w < wave; w++) run += wsum[w];
+#pragma unroll
+  for (int u = 0; u < 4; u++)
+    if (i + u < nkeys) {
+      offsets[i + u] = run;
+      counts[i + u] = 0;
+      run += c[u];
+    }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) offsets[nkeys] = run;
 }
 
-// one workgroup per (tile, 128-channel chunk).  The tile's entry list is brought into LDS in chunks (coalesced), then two
-// stripes of 128 channel-lanes walk it with 8 independent channel-vector reads in flight each (the first version read
-// every entry from global memory just before the gradient it addresses: two dependent round trips per entry, 1.15 ms on
-// the bench shape against 0.31 ms for the atomic form).
-constexpr int RT_ENT = 680;  // entries per LDS chunk (8 KiB)
+// one workgroup per (tile, 256-channel chunk), one WAVE per 16 pixels of the tile, a lane per four channels: an entry is
+// one 1 KiB wave read of the bin's channel vector.  A wave pulls 64 entries at a time into registers (lane i holds entry
+// i; v_readlane hands them round as scalars), keeps 16 vector reads in flight, carries the running sum of the current
+// pixel in registers and adds it to grad_input once per pixel -- a plain read-add-write, the pixel is this wave's alone.
 __global__ __launch_bounds__(256) void roi_bwd_tile_kernel(const float* __restrict__ goT, const int* __restrict__ offsets,
                                                           const RoiEntry* __restrict__ entries, RoiTileLevels lv,
-                                                          int channels) {
-  __shared__ __attribute__((aligned(16))) float tile[RT_PX * RT_CH];  // [64 px][CW]
-  __shared__ int ent_rb[RT_ENT], ent_px[RT_ENT];
-  __shared__ float ent_w[RT_ENT];
+                                                          int channels, int overwrite) {
+  __shared__ int po[RT_PX + 1];
   const int t = blockIdx.x;
-  const int e0 = offsets[t], e1 = offsets[t + 1];
-  if (e1 == e0) return;  // nothing lands here: grad_input keeps its values
+  if (threadIdx.x <= RT_PX) po[threadIdx.x] = offsets[(size_t)t * RT_PX + threadIdx.x];
+  __syncthreads();
+  if (!overwrite && po[RT_PX] == po[0]) return;  // nothing lands here: grad_input keeps its values
   int l = 0;
   while (l + 1 < lv.n && t >= lv.tile_base[l + 1]) l++;
   const int tl = t - lv.tile_base[l];
@@ -1254,55 +1287,66 @@ __global__ __launch_bounds__(256) void roi_bwd_tile_kernel(const float* __restri
   const int ty = t2 % lv.tiles_y[l], b = t2 / lv.tiles_y[l];
   const int H = lv.h[l], W = lv.w[l];
   float* gin = lv.gin[l] + (size_t)b * H * W * channels;
-  const int c0 = blockIdx.y * RT_CH;
-  const int CW = min(RT_CH, channels - c0);
-  for (int i = threadIdx.x; i < RT_PX * CW; i += 256) tile[i] = 0.f;
-  const int stripes = 256 / CW > 0 ? 256 / CW : 1;  // CW = 128: 2 stripes; smaller chunks: more stripes
-  const int c = threadIdx.x % CW, st = threadIdx.x / CW;
-  const float* gcol = goT + c0 + c;
-  for (int base = e0; base < e1; base += RT_ENT) {
-    const int cnt = min(RT_ENT, e1 - base);
-    __syncthreads();  // tile zeroed / previous chunk consumed
-    for (int i = threadIdx.x; i < cnt; i += 256) {
-      const RoiEntry a = entries[base + i];
-      ent_rb[i] = a.rb;
-      ent_px[i] = a.lpx;
-      ent_w[i] = a.w;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int p0 = wave * (RT_PX / 4);
+  const int C4 = channels >> 2;
+  const int c4 = blockIdx.y * 64 + lane;
+  const bool lane_on = c4 < C4;
+  const float4* gcol = (const float4*)goT + (lane_on ? c4 : 0);
+  const int e0 = __builtin_amdgcn_readfirstlane(po[p0]), e1 = __builtin_amdgcn_readfirstlane(po[p0 + RT_PX / 4]);
+  int cur = -1;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto pixel = [&](int px) {
+    const int y = ty * RT + px / RT, x = tx * RT + px % RT;
+    return y < H && x < W ? (float4*)(gin + ((size_t)y * W + x) * channels) + c4 : nullptr;
+  };
+  // overwrite mode: the caller's maps are NOT zero-filled; every in-bounds pixel is written, zeros where nothing lands
+  auto zeros = [&](int from, int to) {
+    if (overwrite && lane_on)
+      for (int px = from; px < to; px++)
+        if (float4* dst = pixel(px)) *dst = make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  auto flush = [&]() {
+    if (cur >= 0 && lane_on) {
+      float4* dst = pixel(cur);  // (entries only exist for in-bounds pixels)
+      float4 o = overwrite ? make_float4(0.f, 0.f, 0.f, 0.f) : *dst;
+      o.x += acc.x, o.y += acc.y, o.z += acc.z, o.w += acc.w;
+      *dst = o;
     }
-    __syncthreads();
-    if (st < stripes) {
-      int e = st;
-      for (; e + 15 * stripes < cnt; e += 16 * stripes) {
-        float g[16];
+  };
+  for (int base = e0; base < e1; base += 64) {
+    const int cnt = min(64, e1 - base);
+    RoiEntry a = RoiEntry{0, 0.f};
+    if (lane < cnt) a = entries[base + lane];
+    int px_v = p0;  // the pixel of my entry: p0 + the number of later pixels of this wave that start at or before it
 #pragma unroll
-        for (int u = 0; u < 16; u++) g[u] = gcol[(size_t)ent_rb[e + u * stripes] * channels];
+    for (int p = 1; p < RT_PX / 4; p++) px_v += po[p0 + p] <= base + lane;
+    const int w_bits = __float_as_int(a.w);
+    for (int u0 = 0; u0 < cnt; u0 += 16) {
+      float4 g[16];
 #pragma unroll
-        for (int u = 0; u < 16; u++) atomicAdd(tile + ent_px[e + u * stripes] * CW + c, g[u] * ent_w[e + u * stripes]);
+      for (int u = 0; u < 16; u++) {
+        const int rb = __builtin_amdgcn_readlane(a.rb, u0 + u);  // (lanes >= cnt hold entry 0 of the gradient: in bounds)
+        g[u] = gcol[(size_t)rb * C4];
       }
-      for (; e < cnt; e += stripes) atomicAdd(tile + ent_px[e] * CW + c, gcol[(size_t)ent_rb[e] * channels] * ent_w[e]);
+#pragma unroll
+      for (int u = 0; u < 16; u++) {
+        if (u0 + u < cnt) {
+          const int px = __builtin_amdgcn_readlane(px_v, u0 + u);
+          const float w = __int_as_float(__builtin_amdgcn_readlane(w_bits, u0 + u));
+          if (px != cur) {
+            flush();
+            zeros(cur < 0 ? p0 : cur + 1, px);
+            cur = px;
+            acc = make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+          acc.x += g[u].x * w, acc.y += g[u].y * w, acc.z += g[u].z * w, acc.w += g[u].w * w;
+        }
+      }
     }
   }
-  __syncthreads();
-  // flush: grad_input += tile, eight independent read-modify-writes in flight per thread (a rolled loop waited for every
-  // load before issuing the next: 32 dependent HBM round trips per workgroup)
-  const int total = RT_PX * CW;
-  for (int i0 = threadIdx.x; i0 < total; i0 += 8 * 256) {
-    float* ptr[8];
-    float old[8];
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-      const int i = i0 + 256 * u;
-      const int ic = min(i, total - 1);
-      const int px = ic / CW, cc = ic - px * CW;
-      const int y = ty * RT + px / RT, x = tx * RT + px % RT;
-      const bool ok = i < total && y < H && x < W;
-      ptr[u] = ok ? gin + ((size_t)y * W + x) * channels + c0 + cc : nullptr;
-      old[u] = ok ? *ptr[u] : 0.f;
-    }
-#pragma unroll
-    for (int u = 0; u < 8; u++)
-      if (ptr[u]) *ptr[u] = old[u] + tile[min(i0 + 256 * u, total - 1)];
-  }
+  flush();
+  zeros(cur < 0 ? p0 : cur + 1, p0 + RT_PX / 4);
 }
 
 // ---------------------------------------------------------------- MaxIoU assignment
@@ -1721,18 +1765,24 @@ size_t sm3_roi_align_rotated_backward_tiled_workspace_bytes(int n_rois, int batc
     tiles += (long)batch * ((heights[i] + RT - 1) / RT) * ((widths[i] + RT - 1) / RT);
   const long bins = (long)pooled_h * pooled_w;
   const long ents = (long)n_rois * bins * sampling_ratio * sampling_ratio * 4;
-  return align_up((size_t)(2 * tiles + 2) * sizeof(int), 256) + align_up((size_t)ents * sizeof(RoiEntry), 256) +
+  return align_up((size_t)(2 * tiles * RT_PX + 2 + tiles * RT_PX / RS_KEYS + 1) * sizeof(int), 256) +
+         align_up((size_t)ents * sizeof(RoiEntry), 256) +
          align_up((size_t)n_rois * bins * channels * sizeof(float), 256);
 }
 
 int sm3_roi_align_rotated_backward_tiled(const float* grad_output, const float* rois, float* const* grad_inputs,
                                          const int* heights, const int* widths, const float* scales, int num_levels,
                                          float finest_scale, int n_rois, int batch, int channels, int pooled_h,
-                                         int pooled_w, int sampling_ratio, int aligned, int clockwise, void* workspace,
-                                         size_t workspace_bytes, sm3_stream_t stream) {
+                                         int pooled_w, int sampling_ratio, int aligned, int clockwise, int overwrite,
+                                         void* workspace, size_t workspace_bytes, sm3_stream_t stream) {
   if (n_rois < 0 || batch <= 0 || channels <= 0 || pooled_h <= 0 || pooled_w <= 0 || !grad_inputs) return SM3_ERR_INVALID_ARG;
-  if (sampling_ratio <= 0) return SM3_ERR_UNSUPPORTED;  // adaptive sampling grids: the scatter form
-  if (n_rois == 0) return SM3_OK;
+  if (sampling_ratio <= 0 || channels % 4) return SM3_ERR_UNSUPPORTED;  // adaptive grids, odd widths: the scatter form
+  if (n_rois == 0) {
+    if (overwrite)
+      for (int i = 0; i < num_levels; i++)
+        sm3_zero_async(grad_inputs[i], (size_t)batch * heights[i] * widths[i] * channels * sizeof(float), (hipStream_t)stream);
+    return overwrite ? launch_status() : SM3_OK;
+  }
   if (!rois || !grad_output || (num_levels > 1 && !(finest_scale > 0.f))) return SM3_ERR_INVALID_ARG;
   RoiTileLevels tl;
   const int ntiles = fill_tile_levels(tl, grad_inputs, heights, widths, scales, num_levels, finest_scale, batch);
@@ -1745,24 +1795,29 @@ int sm3_roi_align_rotated_backward_tiled(const float* grad_output, const float* 
   const long bins = (long)pooled_h * pooled_w;
   const long ents = (long)n_rois * bins * sampling_ratio * sampling_ratio * 4;
   char* w = (char*)workspace;
+  const long nkeys = (long)ntiles * RT_PX;
+  if (nkeys > 0x7ffffff0l) return SM3_ERR_UNSUPPORTED;
   int* counts = (int*)w;
-  int* offsets = counts + ntiles;
-  w += align_up((size_t)(2 * ntiles + 2) * sizeof(int), 256);
+  int* offsets = counts + nkeys;
+  int* bsum = offsets + nkeys + 1;
+  const int nblocks = (int)((nkeys + RS_KEYS - 1) / RS_KEYS);
+  w += align_up((size_t)(2 * nkeys + 2 + nkeys / RS_KEYS + 1) * sizeof(int), 256);
   RoiEntry* entries = (RoiEntry*)w;
   w += align_up((size_t)ents * sizeof(RoiEntry), 256);
   float* goT = (float*)w;
-  sm3_zero_async(counts, (size_t)ntiles * sizeof(int), st);
+  sm3_zero_async(counts, (size_t)nkeys * sizeof(int), st);
   // (n, C, bins) -> (n, bins, C): an entry then reads one contiguous channel vector
   int rc = sm3_transpose_f32(grad_output, goT, n_rois, channels, (int)bins, stream);
   if (rc) return rc;
   const int nb = n_rois;  // one workgroup per RoI
   roi_bwd_bin_kernel<0><<<nb, 256, 0, st>>>(rois, n_rois, pooled_h, pooled_w, sampling_ratio, aligned, clockwise, tl, counts,
                                             nullptr, nullptr);
-  roi_bwd_scan_kernel<<<1, 1024, 0, st>>>(counts, offsets, ntiles);
+  roi_bwd_blocksum_kernel<<<nblocks, 256, 0, st>>>(counts, bsum, (int)nkeys);
+  roi_bwd_scan_kernel<<<nblocks, 256, 0, st>>>(counts, offsets, bsum, (int)nkeys);
   roi_bwd_bin_kernel<1><<<nb, 256, 0, st>>>(rois, n_rois, pooled_h, pooled_w, sampling_ratio, aligned, clockwise, tl, counts,
                                             offsets, entries);
   dim3 tgrid((unsigned)ntiles, (unsigned)((channels + RT_CH - 1) / RT_CH));
-  roi_bwd_tile_kernel<<<tgrid, 256, 0, st>>>(goT, offsets, entries, tl, channels);
+  roi_bwd_tile_kernel<<<tgrid, 256, 0, st>>>(goT, offsets, entries, tl, channels, overwrite != 0);
   return launch_status();
 }
 

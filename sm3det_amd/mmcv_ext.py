@@ -181,12 +181,16 @@ def roi_align_rotated_backward(grad_output, rois, grad_input, pooled_height, poo
             # NCHW gradient maps scatter one float per (RoI, channel, sample) across C planes; on NHWC memory a lane owns
             # a channel and the same scatter is coalesced (10x faster on the 256x256x256 level).  Accumulate into an NHWC
             # scratch map and transpose it into the caller's tensor: one extra pass over the map.
-            target = torch.zeros(B, H, W, C, device=grad_input.device, dtype=torch.float32)
             layout, via_nhwc = 1, True
         n = rois.size(0)
-        if layout == 1 and n > 0 and int(sampling_ratio) > 0 and n <= 65535 and os.environ.get('SM3_ROI_BWD', 'tiled') == 'tiled':
-            # NHWC map: counting sort of the contributions by 8 x 8-pixel tile + one LDS accumulation per tile, no global
-            # atomics (ops_rotated.hip "RoIAlignRotated backward, TILED"); SM3_ROI_BWD=atomic keeps the scatter form (A/B)
+        tiled = (layout == 1 and n > 0 and int(sampling_ratio) > 0 and n <= 65535 and C % 4 == 0
+                 and os.environ.get('SM3_ROI_BWD', 'tiled') == 'tiled')
+        if via_nhwc:  # (the gather form writes every pixel of its own scratch map: no fill pass)
+            target = (torch.empty if tiled else torch.zeros)(B, H, W, C, device=grad_input.device, dtype=torch.float32)
+        if tiled:
+            # NHWC map: counting sort of the contributions by pixel + one gather pass per 8 x 8-pixel tile, no atomics in
+            # the accumulation (ops_rotated.hip "RoIAlignRotated backward, TILED"); SM3_ROI_BWD=atomic keeps the scatter
+            # form (A/B)
             import ctypes
             hs, ws_, sc = (ctypes.c_int * 1)(H), (ctypes.c_int * 1)(W), (ctypes.c_float * 1)(float(spatial_scale))
             gp = (ctypes.c_void_p * 1)(target.data_ptr())
@@ -195,8 +199,8 @@ def roi_align_rotated_backward(grad_output, rois, grad_input, pooled_height, poo
             wsp = workspace(nb, grad_input.device)
             check(lib().sm3_roi_align_rotated_backward_tiled(ptr(grad_output), ptr(rois), gp, hs, ws_, sc, 1, 1.0, n, B, C,
                                                              int(pooled_height), int(pooled_width), int(sampling_ratio),
-                                                             int(bool(aligned)), int(bool(clockwise)), ptr(wsp), nb,
-                                                             stream_ptr()), 'roi_align_rotated_backward_tiled')
+                                                             int(bool(aligned)), int(bool(clockwise)), int(via_nhwc),
+                                                             ptr(wsp), nb, stream_ptr()), 'roi_align_rotated_backward_tiled')
         else:
             check(lib().sm3_roi_align_rotated_backward(ptr(grad_output), ptr(rois), ptr(target), n, B, C,
                                                        H, W, int(pooled_height), int(pooled_width),

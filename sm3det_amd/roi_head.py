@@ -71,10 +71,14 @@ class _MultiLevelRoIAlign(Function):
         out_h, out_w, sampling_ratio, aligned, clockwise, strides, finest = ctx.cfg
         L = len(ctx.shapes)
         fmt = torch.channels_last if ctx.layout == 1 else torch.contiguous_format
-        grads = [torch.zeros(s, device=gout.device).contiguous(memory_format=fmt) for s in ctx.shapes]
         n = rois.shape[0]
-        if n and ctx.layout == 1 and int(sampling_ratio) > 0 and n <= 65535 and os.environ.get('SM3_ROI_BWD', 'tiled') == 'tiled':
-            # counting sort by 8 x 8-pixel tile + LDS accumulation, no global atomics (ops_rotated.hip, round 4)
+        tiled = (n and ctx.layout == 1 and int(sampling_ratio) > 0 and n <= 65535 and ctx.shapes[0][1] % 4 == 0
+                 and os.environ.get('SM3_ROI_BWD', 'tiled') == 'tiled')
+        # (the gather form writes every pixel of the maps itself: no fill pass over 0.18 GB of pyramid gradients)
+        grads = [(torch.empty if tiled else torch.zeros)(s, device=gout.device).contiguous(memory_format=fmt)
+                 for s in ctx.shapes]
+        if tiled:
+            # counting sort by pixel + one gather pass per 8 x 8-pixel tile, no atomic accumulation (ops_rotated.hip, round 4)
             ptrs = (ctypes.c_void_p * L)(*[g.data_ptr() for g in grads])
             hs, ws, sc = ctx.geom
             B, C = ctx.shapes[0][0], ctx.shapes[0][1]
@@ -83,7 +87,7 @@ class _MultiLevelRoIAlign(Function):
             wsp = _lib.workspace(nb, gout.device)
             _lib.check(lib.sm3_roi_align_rotated_backward_tiled(
                 gout.contiguous().data_ptr(), rois.data_ptr(), ptrs, hs, ws, sc, L, float(finest), n, B, C, out_h, out_w,
-                int(sampling_ratio), int(bool(aligned)), int(bool(clockwise)), wsp.data_ptr(), nb, _lib.stream_ptr()),
+                int(sampling_ratio), int(bool(aligned)), int(bool(clockwise)), 1, wsp.data_ptr(), nb, _lib.stream_ptr()),
                 'roi_align_rotated_backward_tiled')
         elif n:
             ptrs = (ctypes.c_void_p * L)(*[g.data_ptr() for g in grads])

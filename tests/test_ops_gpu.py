@@ -393,9 +393,9 @@ def test_nms_rotated_threshold_equality_follows_cpu_path():
 # ----------------------------------------------------------------------------------- round 4: tiled backward, vector forward
 @pytest.mark.parametrize('C,hw', [(256, 64), (64, 40), (96, 33), (320, 24)])
 def test_roi_align_rotated_tiled_backward_equals_the_atomic_form(C, hw, monkeypatch):
-    """SM3_ROI_BWD=tiled (counting sort by 8x8 tile + LDS accumulation, the default on NHWC maps) against SM3_ROI_BWD=atomic
+    """SM3_ROI_BWD=tiled (counting sort by pixel + gather per 8x8 tile, the default on NHWC maps) against SM3_ROI_BWD=atomic
     (the scatter kernel) and the oracle, batch 2, map sizes that are not multiples of the tile, channel counts below / at /
-    above the 256-channel LDS pass; accumulation into a non-zero grad_input."""
+    above the 256-channel pass of a wave; accumulation into a non-zero grad_input."""
     from sm3det_amd import mmcv_ext
     O = _oracle()
     B = 2
@@ -411,6 +411,46 @@ def test_roi_align_rotated_tiled_backward_equals_the_atomic_form(C, hw, monkeypa
         outs[mode] = gi.cpu().numpy()
         assert np.allclose(outs[mode], exp, rtol=1e-4, atol=1e-4), (mode, np.abs(outs[mode] - exp).max())
     assert np.allclose(outs['tiled'], outs['atomic'], rtol=1e-4, atol=1e-4)
+
+
+def test_roi_align_rotated_tiled_backward_overwrite_mode_writes_every_pixel():
+    """overwrite != 0 (what the pyramid extractor and the NCHW wrapper use: no zero-fill pass): two levels whose sizes are
+    not multiples of the tile, maps poisoned with NaN beforehand -> exactly the oracle's gradient of zero-filled maps,
+    zeros included; the RoI set leaves whole tiles (and one whole level of batch 1) untouched."""
+    import ctypes
+    from sm3det_amd import _lib
+    O = _oracle()
+    B, C, n = 2, 64, 120
+    shapes = [(B, C, 52, 44), (B, C, 26, 22)]
+    strides = [4.0, 8.0]
+    rois = synth.rois_for_level(n, 23, batch=1, extent=120.0, wh=(6.0, 200.0))  # batch index 0 only, upper-left corner
+    go = np.random.RandomState(7).randn(n, C, 7, 7).astype(np.float32)
+    # the oracle, level by level (map_roi_levels, finest_scale 56: single_level_roi_extractor.py:66-84)
+    scale = np.sqrt(rois[:, 3] * rois[:, 4])
+    lvl = np.clip(np.floor(np.log2(scale / 56.0 + 1e-6)), 0, 1).astype(int)
+    assert set(lvl.tolist()) == {0, 1}
+    exp = [O.roi_align_rotated_backward(go[lvl == l], rois[lvl == l], shapes[l], 7, 7, 1.0 / strides[l], 2, True, True)
+           for l in range(2)]
+    maps = [torch.full((B, s[2], s[3], C), float('nan'), device='cuda') for s in shapes]  # NHWC memory
+    L = lib = _lib.lib()
+    hs, ws = (ctypes.c_int * 2)(52, 26), (ctypes.c_int * 2)(44, 22)
+    sc = (ctypes.c_float * 2)(0.25, 0.125)
+    ptrs = (ctypes.c_void_p * 2)(*[m.data_ptr() for m in maps])
+    nb = lib.sm3_roi_align_rotated_backward_tiled_workspace_bytes(n, B, C, 7, 7, 2, hs, ws, 2)
+    wsp = _lib.workspace(nb, maps[0].device)
+    g, r = dev(go), dev(rois)
+    _lib.check(L.sm3_roi_align_rotated_backward_tiled(g.data_ptr(), r.data_ptr(), ptrs, hs, ws, sc, 2, 56.0, n, B, C, 7, 7, 2,
+                                                      1, 1, 1, wsp.data_ptr(), nb, _lib.stream_ptr()), 'tiled')
+    for l in range(2):
+        got = maps[l].permute(0, 3, 1, 2).cpu().numpy()
+        assert np.isfinite(got).all()
+        assert np.allclose(got, exp[l], rtol=1e-4, atol=1e-4), np.abs(got - exp[l]).max()
+        assert (got[1] == 0).all()  # no RoI on image 1
+    # n_rois == 0 in overwrite mode: the maps are zeroed
+    maps[0].fill_(float('nan'))
+    _lib.check(L.sm3_roi_align_rotated_backward_tiled(g.data_ptr(), r.data_ptr(), ptrs, hs, ws, sc, 2, 56.0, 0, B, C, 7, 7, 2,
+                                                      1, 1, 1, wsp.data_ptr(), nb, _lib.stream_ptr()), 'tiled')
+    assert (maps[0] == 0).all()
 
 
 def test_roi_align_rotated_vector_forward_is_bit_identical_to_the_scalar_kernel():
