@@ -533,10 +533,13 @@ int sm3_deform_col2im_coord(const float* col, const float* im, const float* offs
  * reference's Fp16OptimizerHook (mmcv/mmcv/runner/hooks/optimizer.py:283-300) without a host sync -- gradients are
  * unscaled inside the update, a non-finite gradient norm skips the step (nothing is written, `step` does not advance)
  * and multiplies the scale by backoff_factor, growth_interval clean steps multiply it by growth_factor;
- * growth_interval <= 0 keeps the scale static. */
+ * growth_interval <= 0 keeps the scale static.
+ * h_ptrs (may be NULL; entries may be 0): _Float16* of a tensor's fp16 SHADOW -- the operand copy the AMP GEMMs read
+ * (what the half model of wrap_fp16_model holds, mmcv/mmcv/runner/fp16_utils.py:71-149): the update writes the rounded
+ * new value next to the fp32 master, so no cast pass runs in the forward. */
 int sm3_optim_chunk_elems(void);
 int sm3_adamw_multi(const uint64_t* p_ptrs, const uint64_t* g_ptrs, const uint64_t* m_ptrs, const uint64_t* v_ptrs,
-                    const int64_t* numel, const int32_t* chunk_tab, int n_chunks, const float* lr, const float* wd,
+                    const uint64_t* h_ptrs, const int64_t* numel, const int32_t* chunk_tab, int n_chunks, const float* lr, const float* wd,
                     float beta1, float beta2, float eps, float max_grad_norm, float* step, float* clip_coef,
                     float* grad_norm, float* partials, float* scaler, float growth_factor, float backoff_factor,
                     int growth_interval, sm3_stream_t stream);

@@ -247,17 +247,29 @@ AMP_HALF_STORAGE = os.environ.get('SM3_AMP_STORAGE', 'fp16') != 'fp32'
 # fp16 SHADOWS of the FFN / expert weights as the B operand of the four GEMMs of a block (what the half model of
 # `wrap_fp16_model` holds next to the fp32 master weights): a third fewer operand bytes through the L1, which bounds the
 # fp16-operand launches.  SM3_AMP_W16=1 turns it on (bit-identical results: the loader rounds the fp32 weights to the
-# same halves -- tests/test_amp_gpu.py), 11.85 -> 11.71 ms per AMP step (profiles/r04); SM3_AMP_W16=0 reads the fp32 weights.
+# same halves -- tests/test_amp_gpu.py), 11.85 -> 11.71 ms per AMP step with a cast per forward, less with the shadows kept by
+# the optimizer (profiles/r04); SM3_AMP_W16=0 reads the fp32 weights.
 AMP_W16 = os.environ.get('SM3_AMP_W16', '1') == '1'
 
 
 def _shadow(w):
-    """the tensor the fp16-operand GEMMs read for weight `w`: `w` itself, or its fp16 shadow (cast each forward, inside the
-    captured graph; the backward of the same step reuses it)"""
+    """the tensor the fp16-operand GEMMs read for weight `w`: `w` itself, or its fp16 shadow.  The shadow is a persistent
+    tensor hung on the parameter (`w._sm3_shadow`): cast here when it does not exist yet or `w` was modified by a torch op
+    since (`w._version` moved: a checkpoint load, an initialiser, another optimizer), and from then on kept current by
+    MultiTensorAdamW, whose update writes the rounded new value next to the fp32 master (optim.hip) -- the training step
+    carries no cast pass (0.44 ms per step on config #3 when every forward cast its weights)."""
     if not (LB.COMPUTE == 1 and AMP_HALF_STORAGE and AMP_W16):
         return w
-    s = torch.empty(w.shape, dtype=torch.float16, device=w.device)
+    s = getattr(w, '_sm3_shadow', None)
+    if s is not None and w._sm3_shadow_version == w._version and s.device == w.device:
+        return s
+    if s is None or s.shape != w.shape or s.device != w.device:
+        s = torch.empty(w.shape, dtype=torch.float16, device=w.device)
     call('cast_f32_f16', w, s, w.numel(), nbytes=6.0 * w.numel())
+    try:
+        w._sm3_shadow, w._sm3_shadow_version = s, w._version
+    except AttributeError:  # (not a plain tensor object: keep casting per call)
+        pass
     return s
 
 

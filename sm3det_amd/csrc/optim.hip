@@ -26,6 +26,7 @@ struct TensorTable {
   const uint64_t* m;
   const uint64_t* v;
   const int64_t* numel;
+  const uint64_t* h;   // _Float16* fp16 shadows of the parameters (0 = none), or NULL: AMP operand copies, written here
 };
 
 // partial[c] = sum of squares of chunk c of the gradient of tensor chunk_tab[c].x
@@ -134,6 +135,7 @@ __global__ __launch_bounds__(OPT_THREADS) void adamw_multi_kernel(TensorTable tt
   const float* __restrict__ g = reinterpret_cast<const float*>(tt.g[tid]);
   float* __restrict__ m = reinterpret_cast<float*>(tt.m[tid]);
   float* __restrict__ v = reinterpret_cast<float*>(tt.v[tid]);
+  _Float16* __restrict__ h = tt.h ? reinterpret_cast<_Float16*>(tt.h[tid]) : nullptr;
   const int64_t n = tt.numel[tid];
   const int64_t base = (int64_t)ck * OPT_CHUNK;
   const int64_t end = min(n, base + OPT_CHUNK);
@@ -170,6 +172,10 @@ __global__ __launch_bounds__(OPT_THREADS) void adamw_multi_kernel(TensorTable tt
     m4[i] = mo;
     v4[i] = vo;
     p4[i] = po;
+    if (h) {  // the fp16 operand copy of the new value (round to nearest even, what sm3_cast_f32_f16 writes): 8 more bytes
+      typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));  // (chunks are 16384 elements: 8-byte aligned halves)
+      *reinterpret_cast<f16x4*>(h + base + 4 * i) = f16x4{(_Float16)po[0], (_Float16)po[1], (_Float16)po[2], (_Float16)po[3]};
+    }
   }
   for (int64_t i = base + 4 * nv + threadIdx.x; i < end; i += OPT_THREADS) {
     const float gi = g[i] * coef;
@@ -178,7 +184,9 @@ __global__ __launch_bounds__(OPT_THREADS) void adamw_multi_kernel(TensorTable tt
     m[i] = mi;
     v[i] = vi;
     const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
-    p[i] = p[i] * decay - step_size * (mi / denom);
+    const float pn = p[i] * decay - step_size * (mi / denom);
+    p[i] = pn;
+    if (h) h[i] = (_Float16)pn;
   }
 }
 
@@ -189,7 +197,7 @@ extern "C" {
 int sm3_optim_chunk_elems(void) { return OPT_CHUNK; }
 
 int sm3_adamw_multi(const uint64_t* p_ptrs, const uint64_t* g_ptrs, const uint64_t* m_ptrs, const uint64_t* v_ptrs,
-                    const int64_t* numel, const int32_t* chunk_tab, int n_chunks, const float* lr, const float* wd,
+                    const uint64_t* h_ptrs, const int64_t* numel, const int32_t* chunk_tab, int n_chunks, const float* lr, const float* wd,
                     float beta1, float beta2, float eps, float max_grad_norm, float* step, float* clip_coef,
                     float* grad_norm, float* partials, float* scaler, float growth_factor, float backoff_factor,
                     int growth_interval, sm3_stream_t stream) {
@@ -197,7 +205,7 @@ int sm3_adamw_multi(const uint64_t* p_ptrs, const uint64_t* g_ptrs, const uint64
     return SM3_ERR_INVALID_ARG;
   if (n_chunks <= 0) return SM3_OK;
   hipStream_t st = (hipStream_t)stream;
-  TensorTable tt{p_ptrs, g_ptrs, m_ptrs, v_ptrs, numel};
+  TensorTable tt{p_ptrs, g_ptrs, m_ptrs, v_ptrs, numel, h_ptrs};
   if (max_grad_norm > 0.f || scaler) {  // the overflow check of the loss scaler needs the same pass as the clip norm
     if (!partials) return SM3_ERR_WORKSPACE;
     grad_sumsq_kernel<<<n_chunks, OPT_THREADS, 0, st>>>(tt, chunk_tab, partials);

@@ -181,6 +181,10 @@ class MultiTensorAdamW(torch.optim.Optimizer):
         self._v_ptrs = as_u64([self.state[p]['exp_avg_sq'] for _, p in ps])
         self._g_ptrs = as_u64([p.grad for _, p in ps])
         self._g_addr = [p.grad.data_ptr() for _, p in ps]
+        # fp16 shadows of AMP operand weights (backbone_ops._shadow hangs them on the parameters): the update keeps them
+        # current, so the forward never casts.  0 = the parameter has none.
+        self._h_addr = self._shadow_addrs()
+        self._h_ptrs = torch.tensor(self._h_addr, dtype=torch.int64, device=dev)
         self._numel = torch.tensor([p.numel() for _, p in ps], dtype=torch.int64, device=dev)
         self._chunks = torch.tensor(tab, dtype=torch.int32, device=dev).contiguous()
         self._n_chunks = len(tab)
@@ -202,6 +206,15 @@ class MultiTensorAdamW(torch.optim.Optimizer):
         self._hyper_slot = 0
         self.update_hyperparams(force=True)
 
+    def _shadow_addrs(self):
+        out = []
+        for _, p in self._params:
+            s = getattr(p, '_sm3_shadow', None)
+            # only a shadow that is current (cast from this value of p) may be maintained incrementally
+            ok = s is not None and getattr(p, '_sm3_shadow_version', None) == p._version and s.is_contiguous()
+            out.append(s.data_ptr() if ok else 0)
+        return out
+
     def refresh_grad_pointers(self):
         """Re-read the addresses of ``p.grad`` (they move when gradients are dropped with set_to_none and re-created
         by autograd).  ``step()`` does it itself when not capturing; call it once, outside the capture, before capturing
@@ -219,6 +232,10 @@ class MultiTensorAdamW(torch.optim.Optimizer):
         if addr != self._g_addr:
             self._g_ptrs.copy_(torch.tensor(addr, dtype=torch.int64))
             self._g_addr = addr
+        haddr = self._shadow_addrs()  # shadows appear with the first AMP forward, and go stale when a torch op writes p
+        if haddr != self._h_addr:
+            self._h_ptrs.copy_(torch.tensor(haddr, dtype=torch.int64))
+            self._h_addr = haddr
 
     def update_hyperparams(self, force=False):
         """Push the groups' lr / weight_decay to the device vectors (call before replaying a captured graph whenever a
@@ -258,7 +275,7 @@ class MultiTensorAdamW(torch.optim.Optimizer):
         self._n_steps_host += 1
         sc = self._ensure_scaler(self._step.device)
         cfg = self._scaler_cfg or dict(growth_factor=2.0, backoff_factor=0.5, growth_interval=0)
-        LB.call('adamw_multi', self._p_ptrs, self._g_ptrs, self._m_ptrs, self._v_ptrs, self._numel, self._chunks,
+        LB.call('adamw_multi', self._p_ptrs, self._g_ptrs, self._m_ptrs, self._v_ptrs, self._h_ptrs, self._numel, self._chunks,
                 self._n_chunks, self._lr, self._wd, float(b1), float(b2), float(g0['eps']), float(self.max_grad_norm),
                 self._step, self._coef, self.grad_norm, self._partials, sc, float(cfg['growth_factor']),
                 float(cfg['backoff_factor']), int(cfg['growth_interval']),
