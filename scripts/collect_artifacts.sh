@@ -43,6 +43,10 @@ profile() {  # profile <suffix> <bench args...>: stats (serial [+ overlap]) and 
   rm -rf /tmp/pmc_m1
   rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d /tmp/pmc_m1 -o p -- python $R/bench.py "$@" --steps 2 --warmup 1 --no-cpu-baseline --no-ops --no-graph > $O/${TAG}_mfma_bench$SFX.log 2>&1
   D=$(dirname $(find /tmp/pmc_m1 -name "*counter_collection.csv" | head -1)); python $R/scripts/pmc_summary.py $D > $O/${TAG}_mfma_bench_top$SFX.txt 2>&1; cp $D/summary.json $O/${TAG}_mfma_bench_summary$SFX.json
+  # L2 hit rate and memory-side requests per kernel (does the split-K slab round trip leave the L2?)
+  rm -rf /tmp/pmc_tcc
+  rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum --kernel-trace --output-format csv -d /tmp/pmc_tcc -o p -- python $R/bench.py "$@" --steps 2 --warmup 1 --no-cpu-baseline --no-ops --no-graph > $O/${TAG}_pmc_tcc$SFX.log 2>&1
+  D=$(dirname $(find /tmp/pmc_tcc -name "*counter_collection.csv" | head -1)); python $R/scripts/pmc_summary.py $D > $O/${TAG}_pmc_tcc_top$SFX.txt 2>&1; cp $D/summary.json $O/${TAG}_pmc_tcc_summary$SFX.json
   unset SM3_WGRAD_STREAM
 }
 profile ""

@@ -19,13 +19,21 @@ def kernel_key(name):
     return n[:60] or name[:60]
 
 
+GEMM_MODE = {'0': 'nt', '1': 'nn', '2': 'tn'}
+
+
 def summarise(d):
     f = glob.glob(d + '/*counter_collection.csv')[0]
     agg = {}
     for r in csv.DictReader(open(f)):
-        a = agg.setdefault((kernel_key(r['Kernel_Name']), r['Counter_Name']), [0, 0.0])
-        a[0] += 1
-        a[1] += float(r['Counter_Value'])
+        keys = [kernel_key(r['Kernel_Name'])]
+        m = re.search(r'gemm_f32_kernel<(\d)', r['Kernel_Name'])
+        if m:  # the pooled family AND the family split by operand form (first template argument)
+            keys.append('gemm_f32_kernel/' + GEMM_MODE.get(m.group(1), m.group(1)))
+        for key in keys:
+            a = agg.setdefault((key, r['Counter_Name']), [0, 0.0])
+            a[0] += 1
+            a[1] += float(r['Counter_Value'])
     out = {}
     for (k, c), (n, s) in agg.items():
         out.setdefault(k, {})[c] = dict(launches=n, mean=s / n, total=s)
