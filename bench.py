@@ -614,13 +614,15 @@ def ops_roofline(us):
     """achieved-vs-roofline of the hot path (b) operators from their `ops_us` timings.  Algorithmic work per call is
     SURVEY.md 8(d)'s: RoIAlignRotated = HBM gather / scatter (output + each touched feature map once, backward zero-fill +
     accumulate), box_iou_rotated / NMS = VALU (pair tests; the instruction count per pair is measured with rocprofv3
-    SQ_INSTS_VALU and committed under profiles/r03/ops_pmc.json), DeformConv2d forward = MFMA GEMM + HBM-bound sampling."""
+    SQ_INSTS_VALU and committed under profiles/r04/ops_pmc.json), DeformConv2d forward = MFMA GEMM + HBM-bound sampling."""
     pmc = {}
-    try:
-        with open(os.path.join(ROOT, 'profiles', 'r03', 'ops_pmc.json')) as f:
-            pmc = json.load(f)
-    except Exception:
-        pass
+    for rnd in ('r04', 'r03'):  # the newest committed per-operator counter passes
+        try:
+            with open(os.path.join(ROOT, 'profiles', rnd, 'ops_pmc.json')) as f:
+                pmc = json.load(f)
+            break
+        except Exception:
+            continue
     out = {}
 
     def hbm(name, key, nbytes):
@@ -963,7 +965,7 @@ def main():
         # passes exist for the headline workload (fp32 and AMP), other configs report null
         traffic = traffic_file = None
         if args.config == DEFAULT_CONFIG or (args.amp and args.config == 'SM3Det_convnext_t'):  # the same backbone
-            for rnd in ('r03', 'r02'):
+            for rnd in ('r04', 'r03', 'r02'):
                 cand = os.path.join('profiles', rnd, 'pmc_traffic_amp.json' if args.amp else 'pmc_traffic.json')
                 try:
                     with open(os.path.join(ROOT, cand)) as f:

@@ -1,9 +1,9 @@
-"""profiles/r03/ops_pmc.json from the per-operator rocprofv3 passes of scripts/gpu_r03_ops_profile.sh
+"""profiles/<round>/ops_pmc.json from the per-operator rocprofv3 passes of scripts/gpu_r03_ops_profile.sh
 (gpurun_out/<tag>_ops/<op>_{stats.csv,sq.json,fetch.json,write.json}): per operator the dominant kernels with their
 average duration, the VALU lane-instructions per pair test (SQ_INSTS_VALU x 64 lanes / pairs), the counted HBM bytes
 (FETCH_SIZE x 2 + WRITE_SIZE, KB: MI355X_MICROARCH.md) and, for the NMS operators, the serial sweep's duration.
 
-    python scripts/ops_pmc_summary.py gpurun_out/<tag>_ops > profiles/r03/ops_pmc.json
+    python scripts/ops_pmc_summary.py gpurun_out/<tag>_ops > profiles/<round>/ops_pmc.json
 """
 import csv
 import json
@@ -14,7 +14,8 @@ d = sys.argv[1]
 PAIRS = {'box_iou_rotated_2000x512': 2000 * 512, 'box_iou_rotated_2000x64': 2000 * 64,
          'nms_rotated_2000': 2000 * 1999 / 2, 'nms_rotated_10000': 10000 * 9999 / 2, 'nms_8768': 8768 * 8767 / 2}
 PAIR_KERNELS = ('box_iou_rotated_kernel', 'nms_rotated_mask_kernel', 'nms_mask_kernel')
-OURS = ('box_iou', 'nms_', 'roi_align', 'deform_', 'gemm_f32_kernel', 'transpose_f32', 'sort_')
+OURS = ('box_iou', 'nms_', 'roi_align', 'roi_bwd', 'deform_', 'gemm_f32_kernel', 'transpose_f32', 'sort_', 'sm3_zero',
+        'at::native::vectorized_elementwise_kernel')  # (the torch fill of the gradient map is part of a backward call)
 
 
 def key(name):
