@@ -523,6 +523,19 @@ int sm3_deform_col2im_coord(const float* col, const float* im, const float* offs
                             int dil_h, int dil_w, int imgs, int deformable_group, long ld_col, sm3_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * RandomSampler / RRandomSampler as a fixed-size selection (mmdet `RandomSampler._sample_pos /
+ * _sample_neg` as `train_cfg.{rpn,rcnn}.sampler` of local_configs/main_SM3Det.py:98-107,128-133 configure it,
+ * mmrotate/core/bbox/samplers/rotate_random_sampler.py:10).  gt_inds (n) int64 from the assigner (> 0 positive, 0 negative,
+ * < 0 ignored), key (n) uniform random floats in [0, 1).  Slots [0, n_pos) receive the min(exp_pos, #positives) positives
+ * with the smallest keys in key order, slots [n_pos, n_pos + n_neg) the negatives with the smallest keys, n_neg =
+ * min(#negatives, num - n_pos[, neg_pos_ub * max(n_pos, 1) when neg_pos_ub >= 0]); the other slots get valid = 0.
+ * num <= 2048.  workspace: sm3_random_sample_workspace_bytes() bytes, the first 16 ZERO on entry (left zero on exit). */
+size_t sm3_random_sample_workspace_bytes(void);
+int sm3_random_sample_fixed(const int64_t* gt_inds, const float* key, int n, int num, int exp_pos, float neg_pos_ub,
+                            int64_t* idx_out, uint8_t* is_pos_out, uint8_t* valid_out, int64_t* n_pos_out,
+                            int64_t* n_neg_out, void* workspace, size_t workspace_bytes, sm3_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * Optimizer step: clip_grad_norm_(max_norm) + AdamW over all tensors, one param group per
  * tensor (mmcv/mmcv/runner/hooks/optimizer.py:55-73, optimizer/default_constructor.py:180-227; per-group lr written by
  * mmrotate/core/hook/dynamic_lr.py:197-218).  Device tables: *_ptrs[t] = float* of tensor t (param, grad, exp_avg,

@@ -25,6 +25,18 @@ from .registry import Registry
 BBOX_ASSIGNERS = Registry('bbox_assigner')
 BBOX_SAMPLERS = Registry('bbox_sampler')
 
+_SAMPLER_WS = {}
+
+
+def _sampler_workspace(device):
+    """the sampler kernels' scratch (counters + candidate lists), zeroed once per (device, stream): every call leaves the
+    counters zero again, and calls on one stream are ordered"""
+    k = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _SAMPLER_WS.get(k)
+    if ws is None:
+        ws = _SAMPLER_WS[k] = torch.zeros(lib().sm3_random_sample_workspace_bytes(), dtype=torch.uint8, device=device)
+    return ws
+
 
 class AssignResult:
     """mmdet AssignResult: num_gts, gt_inds (n,) [-1 ignore, 0 negative, i+1 gt], max_overlaps (n,), labels (n,)|None"""
@@ -122,20 +134,47 @@ class RandomSampler:
         self.num, self.pos_fraction, self.neg_pos_ub = int(num), float(pos_fraction), neg_pos_ub
         self.add_gt_as_proposals = bool(add_gt_as_proposals)
 
-    def sample_fixed(self, gt_inds, generator=None):
+    def sample_fixed(self, gt_inds, generator=None, key=None):
         """Sync-free core.  gt_inds (n,) as produced by the assigner (after add_gt_ when applicable).  Returns
         (idx (num,) long, is_pos (num,) bool, valid (num,) bool, n_pos, n_neg device scalars): up to
         int(num*pos_fraction) uniformly chosen positives first, then uniformly chosen negatives filling ``num``
-        (capped at neg_pos_ub * max(n_pos, 1) when neg_pos_ub >= 0); unused slots have valid = False."""
+        (capped at neg_pos_ub * max(n_pos, 1) when neg_pos_ub >= 0); unused slots have valid = False (their idx is
+        unspecified but in range).  ``key``: the uniform random keys (drawn here when None).
+
+        On the GPU this is three launches of ``sampler.hip`` (count, list the candidates under a key threshold, sort the
+        short lists in LDS and write the slots) instead of two full sorts of the n keys plus ~25 elementwise launches;
+        ``sample_fixed_host`` below is the definition in plain torch that the kernel reproduces on the same keys
+        (tests/test_assign_gpu.py) and that is itself compared with the reference's sampler class
+        (tests/test_oracle_heads_live.py)."""
+        if not gt_inds.is_cuda:
+            return self.sample_fixed_host(gt_inds, generator, key)
+        n, dev, num = gt_inds.numel(), gt_inds.device, self.num
+        if key is None:
+            key = torch.rand(n, device=dev, generator=generator)
+        idx = torch.empty(num, dtype=torch.long, device=dev)
+        flags = torch.empty(2, num, dtype=torch.uint8, device=dev)
+        cnt = torch.empty(2, dtype=torch.long, device=dev)
+        with torch.cuda.device(dev):
+            ws = _sampler_workspace(dev)
+            check(lib().sm3_random_sample_fixed(ptr(gt_inds.long().contiguous()), ptr(key.float().contiguous()), n, num,
+                                                int(num * self.pos_fraction), float(self.neg_pos_ub), ptr(idx), ptr(flags[0]),
+                                                ptr(flags[1]), ptr(cnt[0:1]), ptr(cnt[1:2]), ptr(ws), ws.numel(),
+                                                stream_ptr()), 'random_sample_fixed')
+        fb = flags.bool()
+        return idx, fb[0], fb[1], cnt[0], cnt[1]
+
+    def sample_fixed_host(self, gt_inds, generator=None, key=None):
+        """the rule of ``sample_fixed`` in plain torch (any device): two argsorts of the masked keys + slot arithmetic"""
         n = gt_inds.numel()
         dev = gt_inds.device
         num = self.num
         exp_pos = int(num * self.pos_fraction)
-        key = torch.rand(n, device=dev, generator=generator)
+        if key is None:
+            key = torch.rand(n, device=dev, generator=generator)
         pos, neg = gt_inds > 0, gt_inds == 0
         big = torch.full_like(key, 2.0)
-        pos_order = torch.argsort(torch.where(pos, key, big))  # positives first, in random order
-        neg_order = torch.argsort(torch.where(neg, key, big))
+        pos_order = torch.argsort(torch.where(pos, key, big), stable=True)  # positives first, in random order
+        neg_order = torch.argsort(torch.where(neg, key, big), stable=True)
         n_pos_all, n_neg_all = pos.sum(), neg.sum()
         n_pos = torch.clamp(n_pos_all, max=exp_pos)
         n_neg = torch.minimum(n_neg_all, num - n_pos)

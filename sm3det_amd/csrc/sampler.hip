@@ -1,0 +1,194 @@
+// sampler.hip -- RandomSampler / RRandomSampler (mmdet core/bbox/samplers/random_sampler.py as the reference configs use it,
+// mmrotate/core/bbox/samplers/rotate_random_sampler.py:10) as a fixed-size, sync-free selection on the device.
+//
+// The rule (sm3det_amd/assign.py `RandomSampler.sample_fixed`, which restates `_sample_pos` / `_sample_neg`): with one
+// uniform random key per candidate, take the min(int(num * pos_fraction), #positives) positives with the SMALLEST keys
+// (a uniformly random subset in a uniformly random order -- what `randperm(len(candidates))[:k]` draws), then the
+// negatives with the smallest keys until `num` slots are filled (optionally capped at neg_pos_ub * max(n_pos, 1)).
+//
+// The host form sorts all n keys twice (n = 261 888 anchors in the RPN stage: two radix sorts of ~10 launches each) and
+// then spends ~25 elementwise launches on the slot arithmetic.  Here: (1) one pass counts positives and negatives;
+// (2) one pass appends the candidates whose key lies below a threshold tau = (m + 6 sqrt(m) + 24) / count to a short list
+// (m = the number wanted: the list then holds m + O(sqrt m) entries, and fewer than m with probability < 1e-9);
+// (3) one workgroup sorts the two lists in LDS by (key, index) and writes the slots.  If a list comes up short or
+// overflows, the same workgroup rebuilds it with another threshold (doubling, then bisection; a scan of all n by one
+// workgroup: slow, exact, practically never taken), so the result is the exact m smallest keys -- identical to the host
+// form on the same keys.
+#include "common.h"
+
+namespace {
+
+constexpr int SP_CAP = 4096;      // list capacity per class (power of two: the LDS bitonic sort's size)
+constexpr int SP_THREADS = 1024;  // emit kernel
+struct SpEntry {
+  float key;
+  int idx;
+};
+struct SpWork {
+  int counts[2];   // positives, negatives among the n candidates
+  int listed[2];   // entries appended to the lists
+  SpEntry list[2][SP_CAP];
+};
+
+__device__ __forceinline__ int wanted_pos(int P, int exp_pos) { return min(P, exp_pos); }
+__device__ __forceinline__ int wanted_neg(int N, int m_pos, int num, float neg_pos_ub) {
+  int m = min(N, num - m_pos);
+  if (neg_pos_ub >= 0.f) m = min(m, (int)(long)(neg_pos_ub * (float)max(m_pos, 1)));
+  return max(m, 0);
+}
+__device__ __forceinline__ float threshold(int m, int count) {
+  if (m <= 0) return -1.f;            // nothing wanted: keys are >= 0
+  const float want = (float)m + 6.f * sqrtf((float)m) + 24.f;
+  return want >= (float)count ? 2.f : want / (float)count;  // keys are < 1: 2 takes every candidate
+}
+
+__global__ __launch_bounds__(256) void sampler_count_kernel(const int64_t* __restrict__ gt_inds, int n, SpWork* w) {
+  int p = 0, q = 0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int64_t g = gt_inds[i];
+    p += g > 0;
+    q += g == 0;
+  }
+  for (int o = 32; o; o >>= 1) {
+    p += __shfl_xor(p, o);
+    q += __shfl_xor(q, o);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (p) atomicAdd(&w->counts[0], p);
+    if (q) atomicAdd(&w->counts[1], q);
+  }
+}
+
+__global__ __launch_bounds__(256) void sampler_list_kernel(const int64_t* __restrict__ gt_inds, const float* __restrict__ key,
+                                                          int n, int num, int exp_pos, float neg_pos_ub, SpWork* w) {
+  const int P = w->counts[0], N = w->counts[1];
+  const int m_pos = wanted_pos(P, exp_pos), m_neg = wanted_neg(N, m_pos, num, neg_pos_ub);
+  const float tp = threshold(m_pos, P), tn = threshold(m_neg, N);
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int64_t g = gt_inds[i];
+    if (g < 0) continue;
+    const int c = g > 0 ? 0 : 1;
+    const float k = key[i];
+    if (k < (c ? tn : tp)) {
+      const int slot = atomicAdd(&w->listed[c], 1);
+      if (slot < SP_CAP) w->list[c][slot] = SpEntry{k, i};
+    }
+  }
+}
+
+// (key, index) ascending
+__device__ __forceinline__ bool before(const SpEntry& a, const SpEntry& b) { return a.key < b.key || (a.key == b.key && a.idx < b.idx); }
+
+__global__ __launch_bounds__(SP_THREADS) void sampler_emit_kernel(const int64_t* __restrict__ gt_inds,
+                                                                 const float* __restrict__ key, int n, int num, int exp_pos,
+                                                                 float neg_pos_ub, SpWork* w, int64_t* __restrict__ idx_out,
+                                                                 uint8_t* __restrict__ is_pos_out, uint8_t* __restrict__ valid_out,
+                                                                 int64_t* __restrict__ n_pos_out, int64_t* __restrict__ n_neg_out) {
+  __shared__ SpEntry s[SP_CAP];
+  __shared__ int relisted;
+  const int P = w->counts[0], N = w->counts[1];
+  const int m_pos = wanted_pos(P, exp_pos), m_neg = wanted_neg(N, m_pos, num, neg_pos_ub);
+  for (int c = 0; c < 2; c++) {
+    const int m = c ? m_neg : m_pos;
+    const int count = c ? N : P;
+    // Slow path, same workgroup: the list holds fewer than m entries (probability < 1e-9 per call for uniform keys) or
+    // overflowed (keys that are not uniform).  Re-list with another threshold -- doubled while no upper bound is known,
+    // then bisected between "too few" and "too many" -- until m <= entries <= SP_CAP.  A scan of all n by one workgroup:
+    // slow, exact, practically never taken.  (Only SP_CAP - m candidates sharing one key bit for bit can defeat the
+    // bisection; after 64 rounds the truncated list is used.)
+    int listed = w->listed[c];
+    float tau = threshold(m, count), lo = -1.f, hi = 3.f;
+    bool ok = listed >= m && listed <= SP_CAP;
+    if (!ok) (listed < m ? lo : hi) = tau;
+    for (int it = 0; !ok && it < 64; it++) {
+      if (hi > 2.5f) tau = tau >= 0.5f ? 2.f : fmaxf(tau * 2.f, 1e-6f);
+      else tau = 0.5f * (fmaxf(lo, 0.f) + hi);
+      if (threadIdx.x == 0) relisted = 0;
+      __syncthreads();
+      for (int i = threadIdx.x; i < n; i += SP_THREADS) {
+        const int64_t g = gt_inds[i];
+        if (g >= 0 && (g > 0 ? 0 : 1) == c && key[i] < tau) {
+          const int slot = atomicAdd(&relisted, 1);
+          if (slot < SP_CAP) w->list[c][slot] = SpEntry{key[i], i};
+        }
+      }
+      __threadfence_block();
+      __syncthreads();
+      listed = relisted;
+      __syncthreads();
+      if (listed < m) lo = tau;
+      else if (listed > SP_CAP) hi = tau;
+      else ok = true;
+    }
+    const int have = min(listed, SP_CAP);
+    // sort the smallest power of two >= have entries in LDS (padding sorts last)
+    int size = 64;
+    while (size < have) size <<= 1;
+    for (int i = threadIdx.x; i < size; i += SP_THREADS) s[i] = i < have ? w->list[c][i] : SpEntry{3.f, 0x7fffffff};
+    __syncthreads();
+    for (int k = 2; k <= size; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int i = threadIdx.x; i < size; i += SP_THREADS) {
+          const int l = i ^ j;
+          if (l > i) {
+            const SpEntry a = s[i], b = s[l];
+            const bool up = (i & k) == 0;
+            if (up ? before(b, a) : before(a, b)) {
+              s[i] = b;
+              s[l] = a;
+            }
+          }
+        }
+        __syncthreads();
+      }
+    // positives fill the slots [0, m_pos), negatives [m_pos, m_pos + m_neg)
+    const int base = c ? m_pos : 0;
+    for (int i = threadIdx.x; i < m; i += SP_THREADS) {
+      idx_out[base + i] = s[i].idx;
+      is_pos_out[base + i] = c == 0;
+      valid_out[base + i] = 1;
+    }
+    __syncthreads();
+  }
+  // unused slots: what the host form leaves there (the clamped lookup of the negative order): any in-range index, flags 0
+  for (int i = m_pos + m_neg + threadIdx.x; i < num; i += SP_THREADS) {
+    idx_out[i] = 0;
+    is_pos_out[i] = 0;
+    valid_out[i] = 0;
+  }
+  if (threadIdx.x == 0) {
+    *n_pos_out = m_pos;
+    *n_neg_out = m_neg;
+    w->counts[0] = w->counts[1] = w->listed[0] = w->listed[1] = 0;  // ready for the next call
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t sm3_random_sample_workspace_bytes(void) { return sizeof(SpWork); }
+
+// workspace: sm3_random_sample_workspace_bytes() bytes whose first 16 are ZERO on entry (the call leaves them zero: a
+// buffer zeroed once can be reused by every later call on the same stream).
+int sm3_random_sample_fixed(const int64_t* gt_inds, const float* key, int n, int num, int exp_pos, float neg_pos_ub,
+                            int64_t* idx_out, uint8_t* is_pos_out, uint8_t* valid_out, int64_t* n_pos_out,
+                            int64_t* n_neg_out, void* workspace, size_t workspace_bytes, sm3_stream_t stream) {
+  if (n < 0 || num <= 0 || exp_pos < 0 || exp_pos > num || !idx_out || !is_pos_out || !valid_out || !n_pos_out || !n_neg_out)
+    return SM3_ERR_INVALID_ARG;
+  if (num > SP_CAP / 2) return SM3_ERR_UNSUPPORTED;  // the lists hold the wanted count + its 6 sigma margin
+  if (!workspace || workspace_bytes < sizeof(SpWork)) return SM3_ERR_WORKSPACE;
+  if (n > 0 && (!gt_inds || !key)) return SM3_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  SpWork* w = (SpWork*)workspace;
+  if (n > 0) {
+    const int blocks = min((n + 255) / 256, 1024);
+    sampler_count_kernel<<<blocks, 256, 0, st>>>(gt_inds, n, w);
+    sampler_list_kernel<<<blocks, 256, 0, st>>>(gt_inds, key, n, num, exp_pos, neg_pos_ub, w);
+  }
+  sampler_emit_kernel<<<1, SP_THREADS, 0, st>>>(gt_inds, key, n, num, exp_pos, neg_pos_ub, w, idx_out, is_pos_out, valid_out,
+                                               n_pos_out, n_neg_out);
+  return launch_status();
+}
+
+}  // extern "C"

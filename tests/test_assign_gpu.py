@@ -74,6 +74,56 @@ def test_rpn_assigner_horizontal_anchor_grid_vs_oracle(levels, k, seed):
     assert (gi > 0).sum() >= k and (gi == 0).sum() > 0 and (gi == -1).sum() > 0  # every gt got its best anchor
 
 
+@pytest.mark.parametrize('n,n_pos,n_ign,num,frac,ub', [
+    (261888, 150, 9000, 256, 0.5, -1), (261888, 40, 0, 256, 0.5, -1), (2008, 700, 30, 512, 0.25, -1), (2008, 3, 0, 512, 0.25, -1),
+    (300, 20, 100, 512, 0.25, -1), (5000, 64, 10, 256, 0.5, 3), (7, 0, 0, 256, 0.5, -1), (64, 64, 0, 256, 0.5, -1),
+    (100000, 60000, 100, 2048, 0.5, -1)])
+def test_sampler_kernels_equal_the_host_rule_on_the_same_keys(n, n_pos, n_ign, num, frac, ub):
+    """sampler.hip (count / list under a key threshold / LDS sort + slots) against `sample_fixed_host` (two full stable sorts of
+    the masked keys) on identical keys: the same valid slots in the same order, the same counts -- the RPN stage's 261 888
+    anchors, the RCNN stage's 2000 + gts, fewer candidates than slots, no positives, only positives, neg_pos_ub."""
+    from sm3det_amd.assign import RandomSampler
+    g = torch.Generator(device='cuda').manual_seed(n + n_pos)
+    gt_inds = torch.zeros(n, dtype=torch.long, device='cuda')
+    perm = torch.randperm(n, device='cuda', generator=g)
+    gt_inds[perm[:n_pos]] = torch.randint(1, 9, (n_pos,), device='cuda', generator=g)
+    gt_inds[perm[n_pos:n_pos + n_ign]] = -1
+    s = RandomSampler(num=num, pos_fraction=frac, neg_pos_ub=ub, add_gt_as_proposals=False)
+    for rep in range(3):
+        key = torch.rand(n, device='cuda', generator=g)
+        if rep == 2 and n > 16:
+            key[: n // 2] = key[0]  # heavy ties: broken by index in both forms
+        a = s.sample_fixed(gt_inds, key=key)
+        b = s.sample_fixed_host(gt_inds, key=key)
+        assert int(a[3]) == int(b[3]) and int(a[4]) == int(b[4])
+        v = b[2]
+        assert torch.equal(a[2], v) and torch.equal(a[1], b[1])
+        assert torch.equal(a[0][v], b[0][v])
+        assert bool((a[0] >= 0).all()) and (n == 0 or bool((a[0] < n).all()))
+
+
+def test_sampler_short_list_is_rebuilt_exactly():
+    """the emit kernel's slow path: keys that are NOT uniform -- none below 0.5 -- leave the candidate list empty, and
+    doubling the threshold past 0.5 overflows it; the workgroup bisects the threshold and still returns the exact smallest
+    keys.  Second case: every key below the first threshold (the fast list overflows)."""
+    from sm3det_amd.assign import RandomSampler
+    n = 50000
+    gt_inds = torch.zeros(n, dtype=torch.long, device='cuda')
+    gt_inds[:20000] = 1
+    key = torch.rand(n, device='cuda', generator=torch.Generator(device='cuda').manual_seed(5)) * 0.5 + 0.5  # none below 0.5
+    s = RandomSampler(num=256, pos_fraction=0.5, neg_pos_ub=-1, add_gt_as_proposals=False)
+    a, b = s.sample_fixed(gt_inds, key=key), s.sample_fixed_host(gt_inds, key=key)
+    assert int(a[3]) == 128 and int(a[4]) == 128 and bool(a[2].all())
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    key = torch.rand(n, device='cuda') * 1e-4
+    a, b = s.sample_fixed(gt_inds, key=key), s.sample_fixed_host(gt_inds, key=key)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and bool(a[2].all())
+    # the scratch counters are left zero: the next call on the same stream is correct
+    key2 = torch.rand(n, device='cuda')
+    a, b = s.sample_fixed(gt_inds, key=key2), s.sample_fixed_host(gt_inds, key=key2)
+    assert torch.equal(a[0], b[0])
+
+
 def test_random_sampler_rule_and_uniformity():
     from sm3det_amd.assign import AssignResult, RRandomSampler, RandomSampler
     g = torch.Generator(device='cuda').manual_seed(0)
