@@ -1028,8 +1028,10 @@ def main():
                                         sorted(kernels.items(), key=lambda kv: -kv[1]['ms'])
                                         if v['bytes'] > 0 and v['ms'] > 0 and not n.startswith('gemm_f')},
         }
+        # SM3_BENCH_OPS=full: only the full-model workload runs after the headline (profiling aid, like =slice)
+        only_full = os.environ.get('SM3_BENCH_OPS') == 'full'
         if world == 1 and not args.no_ops:
-            result['ops_us'] = ops_microbench()
+            result['ops_us'] = {} if only_full else ops_microbench()
             result['ops_roofline'] = ops_roofline(result['ops_us'])
             t_slice = result['ops_us'].get('detector_slice_train_step_bs2_1024')
             if t_slice:  # second named value, never mixed into `value`: see ops_microbench()

@@ -1,4 +1,4 @@
 #!/bin/bash
 set -u
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O; cd $R
-timeout 600 python scripts/slice_glue_audit2.py > $O/r04c16_glue.txt 2> $O/r04c16_glue.err; echo "rc=$?"; head -90 $O/r04c16_glue.txt; tail -5 $O/r04c16_glue.err
+timeout 600 python scripts/slice_glue_audit.py > $O/r04c17_glue.txt 2> $O/r04c17_glue.err; echo "rc=$?"; head -75 $O/r04c17_glue.txt

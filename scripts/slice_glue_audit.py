@@ -49,7 +49,7 @@ def step():
 for _ in range(2):
     step()
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
     step()
     torch.cuda.synchronize()
 cnt = collections.Counter()
@@ -61,8 +61,9 @@ for ev in prof.events():
     ks = getattr(ev, 'kernels', None)
     if not ks:
         continue
-    frame = next((s for s in ev.stack if '/sm3det_amd/' in s or 'slice_glue_audit' in s), ev.stack[0] if ev.stack else '?')
-    key = (ev.name, frame.strip()[-100:])
+    frame = next((s for s in ev.stack if '/sm3det_amd/' in s or 'slice_glue_audit' in s), ev.stack[0] if ev.stack else '')
+    shapes = str([tuple(x) for x in (ev.input_shapes or []) if x])[:70]  # (stacks are not recorded on this build: shapes)
+    key = (ev.name, (frame.strip()[-60:] + ' ' + shapes).strip())
     cnt[key] += len(ks)
     tim[key] += sum(k.duration for k in ks)
     total += len(ks)
