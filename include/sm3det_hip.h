@@ -530,6 +530,14 @@ int sm3_deform_col2im_coord(const float* col, const float* im, const float* offs
  * with the smallest keys in key order, slots [n_pos, n_pos + n_neg) the negatives with the smallest keys, n_neg =
  * min(#negatives, num - n_pos[, neg_pos_ub * max(n_pos, 1) when neg_pos_ub >= 0]); the other slots get valid = 0.
  * num <= 2048.  workspace: sm3_random_sample_workspace_bytes() bytes, the first 16 ZERO on entry (left zero on exit). */
+/* The sampled rows of one image for the RCNN stage: RoI (batch index | box; gts count as proposals when `prepended`),
+ * class label (num_classes = background for negatives) and matched gt of every slot
+ * (oriented_standard_roi_head.py:66-92 `rbbox2roi` of the sampling results, rotated_bbox_head.py:131-204 labels / gts per
+ * sample), written at slot `out0` of batch-wide blocks; unused slots get a unit box, valid_out = 0. */
+int sm3_rcnn_gather_samples(const float* gts, const int64_t* gt_labels, int k, int prepended, const float* props,
+                            int ld_props, const int64_t* gt_inds_all, const int64_t* labels, const int64_t* idx,
+                            const uint8_t* is_pos, const uint8_t* valid, int S, int num_classes, float batch_index, long out0,
+                            float* rois_out, int64_t* labels_out, float* gts_out, uint8_t* valid_out, sm3_stream_t stream);
 size_t sm3_random_sample_workspace_bytes(void);
 int sm3_random_sample_fixed(const int64_t* gt_inds, const float* key, int n, int num, int exp_pos, float neg_pos_ub,
                             int64_t* idx_out, uint8_t* is_pos_out, uint8_t* valid_out, int64_t* n_pos_out,

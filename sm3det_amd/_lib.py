@@ -49,6 +49,7 @@ def _declare(lib):
         'sm3_roi_align_rotated_multilevel_forward': (I, [P, P, P, P, I, F, P, P, P, I, I, I, I, I, I, I, I, P]),
         'sm3_roi_align_rotated_multilevel_backward': (I, [P, P, P, P, P, P, I, F, I, I, I, I, I, I, I, I, P]),
         'sm3_random_sample_workspace_bytes': (S, []),
+        'sm3_rcnn_gather_samples': (I, [P, P, I, I, P, I, P, P, P, P, P, I, I, F, ctypes.c_long, P, P, P, P, P]),
         'sm3_random_sample_fixed': (I, [P, P, I, I, I, F, P, P, P, P, P, P, S, P]),
         'sm3_roi_align_rotated_backward_tiled_workspace_bytes': (S, [I, I, I, I, I, I, P, P, I]),
         'sm3_roi_align_rotated_backward_tiled': (I, [P, P, P, P, P, P, I, F, I, I, I, I, I, I, I, I, I, P, S, P]),

@@ -160,7 +160,7 @@ class RandomSampler:
                                                 int(num * self.pos_fraction), float(self.neg_pos_ub), ptr(idx), ptr(flags[0]),
                                                 ptr(flags[1]), ptr(cnt[0:1]), ptr(cnt[1:2]), ptr(ws), ws.numel(),
                                                 stream_ptr()), 'random_sample_fixed')
-        fb = flags.bool()
+        fb = flags.view(torch.bool)  # (the kernel writes 0 / 1 bytes: a reinterpretation, not a copy)
         return idx, fb[0], fb[1], cnt[0], cnt[1]
 
     def sample_fixed_host(self, gt_inds, generator=None, key=None):

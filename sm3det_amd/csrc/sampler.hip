@@ -163,9 +163,65 @@ __global__ __launch_bounds__(SP_THREADS) void sampler_emit_kernel(const int64_t*
   }
 }
 
+// one thread per sampled slot: the RoI row, its class label, its matched gt (OrientedStandardRoIHead.forward_train's
+// `bbox_results` inputs + RotatedBBoxHead.get_targets' per-sample label / gt, oriented_standard_roi_head.py:66-92,
+// rotated_bbox_head.py:131-204) for one image, written at slot offset `out0` of the batch-wide blocks
+__global__ __launch_bounds__(256) void rcnn_gather_samples_kernel(
+    const float* __restrict__ gts, const int64_t* __restrict__ gt_labels, int k, int prepended,
+    const float* __restrict__ props, int ld_props, const int64_t* __restrict__ gt_inds_all,
+    const int64_t* __restrict__ labels, const int64_t* __restrict__ idx, const uint8_t* __restrict__ is_pos,
+    const uint8_t* __restrict__ valid, int S, int num_classes, float batch_index, long out0, float* __restrict__ rois_out,
+    int64_t* __restrict__ labels_out, float* __restrict__ gts_out, uint8_t* __restrict__ valid_out) {
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= S) return;
+  const long j = idx[s];
+  const bool v = valid[s] != 0, pos = is_pos[s] != 0;
+  const int kp = prepended ? k : 0;
+  float box[5] = {0.f, 0.f, 1.f, 1.f, 0.f};  // unused slots: a harmless unit box (their rows carry no weight)
+  if (v) {
+    const float* src = j < kp ? gts + 5 * j : props + (long)ld_props * (j - kp);
+#pragma unroll
+    for (int c = 0; c < 5; c++) box[c] = src[c];
+  }
+  float* r = rois_out + 6 * (out0 + s);
+  r[0] = batch_index;
+#pragma unroll
+  for (int c = 0; c < 5; c++) r[1 + c] = box[c];
+  float* go = gts_out + 5 * (out0 + s);
+  if (k > 0) {
+    const long gi = max(gt_inds_all[j] - 1, (long)0);
+#pragma unroll
+    for (int c = 0; c < 5; c++) go[c] = gts[5 * gi + c];
+  } else {
+#pragma unroll
+    for (int c = 0; c < 5; c++) go[c] = 0.f;
+  }
+  int64_t lab = num_classes;
+  if (pos) lab = j < kp ? gt_labels[j] : labels[j - kp];
+  labels_out[out0 + s] = lab;
+  valid_out[out0 + s] = v;
+}
+
 }  // namespace
 
 extern "C" {
+
+// gts (k,5), gt_labels (k), props (n, ld_props >= 5), gt_inds_all (prepended ? k + n : n) as the sampler saw them, labels (n)
+// from the assigner, idx / is_pos / valid (S) from sm3_random_sample_fixed; outputs are batch-wide blocks, this image's
+// rows start at slot out0.
+int sm3_rcnn_gather_samples(const float* gts, const int64_t* gt_labels, int k, int prepended, const float* props,
+                            int ld_props, const int64_t* gt_inds_all, const int64_t* labels, const int64_t* idx,
+                            const uint8_t* is_pos, const uint8_t* valid, int S, int num_classes, float batch_index, long out0,
+                            float* rois_out, int64_t* labels_out, float* gts_out, uint8_t* valid_out, sm3_stream_t stream) {
+  if (S <= 0 || k < 0 || ld_props < 5 || !idx || !is_pos || !valid || !rois_out || !labels_out || !gts_out || !valid_out ||
+      !gt_inds_all)
+    return SM3_ERR_INVALID_ARG;
+  if (k > 0 && (!gts || !gt_labels)) return SM3_ERR_INVALID_ARG;
+  rcnn_gather_samples_kernel<<<(S + 255) / 256, 256, 0, (hipStream_t)stream>>>(
+      gts, gt_labels, k, prepended, props, ld_props, gt_inds_all, labels, idx, is_pos, valid, S, num_classes, batch_index, out0,
+      rois_out, labels_out, gts_out, valid_out);
+  return launch_status();
+}
 
 size_t sm3_random_sample_workspace_bytes(void) { return sizeof(SpWork); }
 

@@ -48,7 +48,7 @@ class _MultiLevelRoIAlign(Function):
         n, C, L = rois.shape[0], feats[0].shape[1], len(feats)
         if any(f.dtype != torch.float32 or f.shape[1] != C for f in feats):
             raise _lib.SM3Error('all levels must be float32 with the same channel count')
-        out = torch.zeros(n, C, out_h, out_w, device=rois.device)
+        out = torch.empty(n, C, out_h, out_w, device=rois.device)  # (every RoI has a level: the kernel writes all of it)
         levels = torch.empty(n, dtype=torch.int32, device=rois.device)
         ctx.geom = ((ctypes.c_int * L)(*[f.shape[2] for f in feats]), (ctypes.c_int * L)(*[f.shape[3] for f in feats]),
                     (ctypes.c_float * L)(*[1.0 / s for s in strides]))
@@ -293,32 +293,34 @@ class OrientedStandardRoIHead(nn.Module):
         dev = proposals.device
         S, C = self.bbox_sampler.num, self.bbox_head.num_classes
         slot = torch.arange(P, device=dev)
-        rois, labels, valids, gts_out, npos, nneg = [], [], [], [], [], []
+        rois = torch.empty(B * S, 6, device=dev)
+        labels = torch.empty(B * S, dtype=torch.long, device=dev)
+        gts_out = torch.empty(B * S, 5, device=dev)
+        valid_out = torch.empty(B * S, dtype=torch.uint8, device=dev)
+        npos, nneg = [], []
+        lib = _lib.lib()
         for i in range(B):
-            boxes = proposals[i, :, :5].contiguous()
-            g, gl = gt_bboxes[i].float()[:, :5].contiguous(), gt_labels[i].long()
+            boxes = proposals[i]  # (P, 5+): the kernels take the row stride
+            g, gl = gt_bboxes[i].float()[:, :5].contiguous(), gt_labels[i].long().contiguous()
             k = int(g.shape[0])
             flags = (slot < counts[i]).to(torch.uint8) if counts is not None else None
             ar = self.bbox_assigner.assign(boxes, g, None, gl, box_flags=flags)
-            gt_inds, lab = ar.gt_inds, ar.labels
-            if self.bbox_sampler.add_gt_as_proposals and k > 0:  # BaseSampler.sample: gts first, self-matched
-                boxes = torch.cat([g, boxes], 0)
+            gt_inds = ar.gt_inds
+            prepend = bool(self.bbox_sampler.add_gt_as_proposals and k > 0)
+            if prepend:  # BaseSampler.sample: gts first, self-matched
                 gt_inds = torch.cat([torch.arange(1, k + 1, device=dev), gt_inds])
-                lab = torch.cat([gl, lab])
             idx, is_pos, valid, n_pos, n_neg = self.bbox_sampler.sample_fixed(gt_inds, generator)
-            sel = boxes[idx]
-            unit = sel.new_zeros(5)  # (built with fill kernels: a host-to-device copy cannot sit inside a hipGraph capture)
-            unit[2:4] = 1.0
-            sel = torch.where(valid[:, None], sel, unit)  # unused slots: a harmless unit box (their rows carry no weight)
-            gsel = g[(gt_inds[idx] - 1).clamp(min=0)] if k > 0 else sel.new_zeros(S, 5)
-            rois.append(torch.cat([sel.new_full((S, 1), float(i)), sel], 1))
-            labels.append(torch.where(is_pos, lab[idx], torch.full_like(lab[idx], C)))
-            valids.append(valid)
-            gts_out.append(gsel)
+            # RoI rows (unused slots: a unit box), labels (background for negatives), matched gts: one launch
+            with torch.cuda.device(dev):
+                _lib.check(lib.sm3_rcnn_gather_samples(
+                    _lib.ptr(g), _lib.ptr(gl), k, int(prepend), _lib.ptr(boxes), boxes.stride(0), _lib.ptr(gt_inds),
+                    _lib.ptr(ar.labels), _lib.ptr(idx), _lib.ptr(is_pos), _lib.ptr(valid), S, C, float(i), i * S,
+                    _lib.ptr(rois), _lib.ptr(labels), _lib.ptr(gts_out), _lib.ptr(valid_out), _lib.stream_ptr()),
+                    'rcnn_gather_samples')
             npos.append(n_pos)
             nneg.append(n_neg)
-        return dict(rois=torch.cat(rois), labels=torch.cat(labels), valid=torch.cat(valids), gts=torch.cat(gts_out),
-                    n_pos=torch.stack(npos), n_neg=torch.stack(nneg))
+        return dict(rois=rois, labels=labels, valid=valid_out.view(torch.bool), gts=gts_out, n_pos=torch.stack(npos),
+                    n_neg=torch.stack(nneg))
 
     def forward_train(self, x, img_metas, proposal_list, gt_bboxes, gt_labels, gt_bboxes_ignore=None, gt_masks=None,
                       generator=None, return_samples=False):

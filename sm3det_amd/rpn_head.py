@@ -212,6 +212,7 @@ class OrientedRPNHead(nn.Module):
                 raise NotImplementedError('OrientedRPNHead: rpn sampler with add_gt_as_proposals=True')
             self.sampler = BBOX_SAMPLERS.build(train_cfg['sampler'])
         self._anchor_cache = {}
+        self._ids_cache = {}
         self._init_layers()
 
     def _init_layers(self):
@@ -327,9 +328,9 @@ class OrientedRPNHead(nn.Module):
                 props.append(p)
                 hboxes.append(hb)
                 scores.append(s)
-                ids.append(torch.full((s.numel(),), idx, dtype=torch.float32, device=s.device))
+                ids.append(int(s.numel()))
             proposals, hprop = torch.cat(props), torch.cat(hboxes)
-            scores, ids = torch.cat(scores), torch.cat(ids)
+            scores, ids = torch.cat(scores), self._level_ids(tuple(ids), scores[0].device)
             # batched_nms offset trick (mmcv/ops/nms.py:300-304), then ONE NMS whose keep count stays on the device
             off = ids * (hprop.max() + 1.0)
             keep, num = mmcv_ext.nms_fixed((hprop + off[:, None]).contiguous(), scores.contiguous(), thr, 0)
@@ -341,6 +342,16 @@ class OrientedRPNHead(nn.Module):
             out[i, :m] = dets
             counts[i] = cnt
         return out, counts
+
+    def _level_ids(self, counts, device):
+        """the level index of every concatenated candidate as a float vector (batched_nms's `idxs`): a function of the
+        per-level candidate counts only, so it is built once per configuration instead of with 6 launches per image"""
+        key = (counts, str(device))
+        hit = self._ids_cache.get(key)
+        if hit is None:
+            hit = self._ids_cache[key] = torch.cat([torch.full((n,), float(i), dtype=torch.float32, device=device)
+                                                    for i, n in enumerate(counts)])
+        return hit
 
     # ------------------------------------------------------------------------------------------ targets + loss
     def _train_anchors(self, sizes, pad_shape, img_shape, device):
