@@ -43,6 +43,7 @@ VARIANTS = {
     # per-workgroup phase timestamps of the GEMM kernel (scripts/gemm_trace.py) / static wave priority by residency slot
     'trace': ['-DSM3_TRACE=1'], 'prio1': ['-DSM3_PRIO=1'], 'prio2': ['-DSM3_PRIO=2'], 'stagger': ['-DSM3_STAGGER=1'],
     'trace_stagger': ['-DSM3_TRACE=1', '-DSM3_STAGGER=1'],
+    'lpt8': ['-DSM3_ROUTER_LPT=8'], 'lpt2': ['-DSM3_ROUTER_LPT=2'],  # lanes per token of the MoE router kernels
     'abl_noepi': ['-DSM3_ABL_NOEPI=1'], 'abl_loop_only_mfma': ['-DSM3_ABL_NOLOAD=1', '-DSM3_ABL_NOSTORE=1', '-DSM3_ABL_NOEPI=1'],
 }
 

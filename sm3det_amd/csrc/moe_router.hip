@@ -30,7 +30,11 @@ __device__ __forceinline__ float normal_pdf(float z) { return 0.3989422804014326
 __device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(__expf(x)); }  // torch threshold 20
 
 constexpr int RT_THREADS = 64;  // one wavefront per workgroup
-constexpr int LPT = 4;          // lanes per token
+#ifndef SM3_ROUTER_LPT
+#define SM3_ROUTER_LPT 4
+#endif
+constexpr int LPT = SM3_ROUTER_LPT;  // lanes per token (A/B builds: --variant lpt8 / lpt2; round 4, same box: 8 lanes change
+                                     // nothing -- fwd 0.205 -> 0.21, bwd 0.23 -> 0.20, the partials reduce +0.02 ms per step)
 constexpr int RT_TOKENS = RT_THREADS / LPT;  // tokens per workgroup
 
 // cooperative, coalesced copy of the [16 tokens][P] feature tile into LDS (row stride P+1).  Eight 16-byte loads per lane
