@@ -545,9 +545,21 @@ __global__ void moe_combine_fwd_kernel(const float* __restrict__ yslot, const in
     const long t = idx / nq;
     const int q = idx - t * nq;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int j = 0; j < k; j++) {
-      const float g = gates[t * k + j];
-      acc += ld4(yslot + (long)token_slot[t * k + j] * C + 4 * q) * g;
+    for (int j0 = 0; j0 < k; j0 += 4) {  // indices of up to four experts, then their vectors: two round trips, not 2 k
+      long sl[4];
+      float g[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const bool on = j0 + u < k;
+        sl[u] = on ? token_slot[t * k + j0 + u] : 0;
+        g[u] = on ? gates[t * k + j0 + u] : 0.f;
+      }
+      f32x4 yv[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) yv[u] = j0 + u < k ? ld4(yslot + sl[u] * C + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        if (j0 + u < k) acc += yv[u] * g[u];
     }
     float sc = rowscale ? rowscale[t / rows_per_scale] : 1.f;
     st4(out + t * C + 4 * q, ld4(shortcut + t * C + 4 * q) + ld4(gamma + 4 * q) * sc * acc);
@@ -586,23 +598,43 @@ __global__ __launch_bounds__(256) void moe_combine_bwd_kernel(
       d[i] = (tv && q < nq) ? ld4(dout + tok * C + 4 * q) * rs : f32x4{0.f, 0.f, 0.f, 0.f};
       ym[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    for (int j = 0; j < k; j++) {
-      const float g = tv ? gates[tok * k + j] : 0.f;
-      const long sl = tv ? token_slot[tok * k + j] : 0;
-      float dot = 0.f;
+    // all k slot indices and gates first, then all k x NV expert-output vectors (independent requests: one round trip for
+    // the indices, one for the vectors -- the j-loop used to chain index -> vector -> store per expert), then the math
+    constexpr int KB = 4;  // experts per batch (top-k of the SM3Det configs: 2)
+    for (int j0 = 0; j0 < k; j0 += KB) {
+      float g[KB];
+      long sl[KB];
 #pragma unroll
-      for (int i = 0; i < NV; i++) {
-        const int q = lg + i * G;
-        if (tv && q < nq) {
-          const f32x4 yv = ld4(yslot + sl * C + 4 * q);
-          const f32x4 dd = d[i] * gv[i];
-          dot += hsum4(dd * yv);
-          ym[i] += yv * g;
-          st4(dyslot + sl * C + 4 * q, dd * g);
-        }
+      for (int u = 0; u < KB; u++) {
+        const bool on = tv && j0 + u < k;
+        g[u] = on ? gates[tok * k + j0 + u] : 0.f;
+        sl[u] = on ? token_slot[tok * k + j0 + u] : 0;
       }
-      dot = group_sum<G>(dot);
-      if (tv && lg == 0) dgate[tok * k + j] = dot;
+      f32x4 yv[KB][NV];
+#pragma unroll
+      for (int u = 0; u < KB; u++)
+#pragma unroll
+        for (int i = 0; i < NV; i++) {
+          const int q = lg + i * G;
+          yv[u][i] = (tv && j0 + u < k && q < nq) ? ld4(yslot + sl[u] * C + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+      for (int u = 0; u < KB; u++) {
+        if (j0 + u >= k) break;
+        float dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; i++) {
+          const int q = lg + i * G;
+          if (tv && q < nq) {
+            const f32x4 dd = d[i] * gv[i];
+            dot += hsum4(dd * yv[u][i]);
+            ym[i] += yv[u][i] * g[u];
+            st4(dyslot + sl[u] * C + 4 * q, dd * g[u]);
+          }
+        }
+        dot = group_sum<G>(dot);
+        if (tv && lg == 0) dgate[tok * k + j0 + u] = dot;
+      }
     }
 #pragma unroll
     for (int i = 0; i < NV; i++) acc[0][i] += d[i] * ym[i];
@@ -619,7 +651,17 @@ __global__ void moe_gather_add_kernel(const float* __restrict__ dxslot, const in
     const long t = idx / nq;
     const int q = idx - t * nq;
     f32x4 acc = accumulate ? ld4(dx + t * C + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int j = 0; j < k; j++) acc += ld4(dxslot + (long)token_slot[t * k + j] * C + 4 * q);
+    for (int j0 = 0; j0 < k; j0 += 4) {
+      long sl[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) sl[u] = j0 + u < k ? token_slot[t * k + j0 + u] : 0;
+      f32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) v[u] = j0 + u < k ? ld4(dxslot + sl[u] * C + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        if (j0 + u < k) acc += v[u];
+    }
     st4(dx + t * C + 4 * q, acc);
   }
 }
