@@ -95,7 +95,7 @@ __global__ __launch_bounds__(SP_THREADS) void sampler_emit_kernel(const int64_t*
     // overflowed (keys that are not uniform).  Re-list with another threshold -- doubled while no upper bound is known,
     // then bisected between "too few" and "too many" -- until m <= entries <= SP_CAP.  A scan of all n by one workgroup:
     // slow, exact, practically never taken.  (Only SP_CAP - m candidates sharing one key bit for bit can defeat the
-    // bisection; after 64 rounds the truncated list is used.)
+    // bisection; the last round then lists the "too many" side and the truncated list is used: still m valid samples.)
     int listed = w->listed[c];
     float tau = threshold(m, count), lo = -1.f, hi = 3.f;
     bool ok = listed >= m && listed <= SP_CAP;
@@ -103,6 +103,7 @@ __global__ __launch_bounds__(SP_THREADS) void sampler_emit_kernel(const int64_t*
     for (int it = 0; !ok && it < 64; it++) {
       if (hi > 2.5f) tau = tau >= 0.5f ? 2.f : fmaxf(tau * 2.f, 1e-6f);
       else tau = 0.5f * (fmaxf(lo, 0.f) + hi);
+      if (it == 63) tau = hi > 2.5f ? 2.f : hi;  // give up separating: the "too many" side, truncated (>= m valid entries)
       if (threadIdx.x == 0) relisted = 0;
       __syncthreads();
       for (int i = threadIdx.x; i < n; i += SP_THREADS) {

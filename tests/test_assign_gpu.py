@@ -118,6 +118,12 @@ def test_sampler_short_list_is_rebuilt_exactly():
     key = torch.rand(n, device='cuda') * 1e-4
     a, b = s.sample_fixed(gt_inds, key=key), s.sample_fixed_host(gt_inds, key=key)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and bool(a[2].all())
+    # one key value everywhere: no threshold separates 128 of 20 000 equal keys; after 64 rounds the truncated list is used --
+    # still a valid sample (right classes, in range, no duplicates)
+    key = torch.full((n,), 0.25, device='cuda')
+    idx, is_pos, valid, n_pos, n_neg = s.sample_fixed(gt_inds, key=key)
+    assert int(n_pos) == 128 and int(n_neg) == 128 and bool(valid.all())
+    assert bool((gt_inds[idx[is_pos]] > 0).all()) and bool((gt_inds[idx[~is_pos]] == 0).all()) and idx.unique().numel() == 256
     # the scratch counters are left zero: the next call on the same stream is correct
     key2 = torch.rand(n, device='cuda')
     a, b = s.sample_fixed(gt_inds, key=key2), s.sample_fixed_host(gt_inds, key=key2)
