@@ -205,6 +205,14 @@ class GFLHead(nn.Module):
             out.append((vy[:, None] & vx[None, :]).reshape(-1))
         return out
 
+    def _valid_cat(self, featmap_sizes, pad_shape, device):
+        """the concatenated valid flags of one (pyramid geometry, padded image shape): built once, reused every step"""
+        key = (tuple(featmap_sizes), tuple(int(v) for v in pad_shape[:2]), str(device))
+        cache = self.__dict__.setdefault('_valid_cache', {})
+        if key not in cache:
+            cache[key] = torch.cat(self._valid_flags(featmap_sizes, pad_shape, device))
+        return cache[key]
+
     def get_targets(self, anchors, num_level_anchors, valid_flags_list, gt_bboxes_list, gt_labels_list):
         """per image ATSS assignment + PseudoSampler -> stacked (B, A) labels (num_classes = background), label weights,
         (B, A, 4) box targets, (B, A) positive mask.  anchors (A, 4) level-major, shared by the images."""
@@ -246,7 +254,7 @@ class GFLHead(nn.Module):
         lvl_anchors = self._anchors(sizes, dev)
         num_level = [int(a.shape[0]) for a in lvl_anchors]
         anchors = torch.cat(lvl_anchors)
-        valid = [torch.cat(self._valid_flags(sizes, m.get('pad_shape', m.get('img_shape')), dev)) for m in img_metas]
+        valid = [self._valid_cat(sizes, m.get('pad_shape', m.get('img_shape')), dev) for m in img_metas]
         labels, label_w, box_t, pos = self.get_targets(anchors, num_level, valid, gt_bboxes, gt_labels)
         B = labels.shape[0]
         qb = float((self.loss_cls_cfg or {}).get('beta', 2.0))
@@ -255,36 +263,49 @@ class GFLHead(nn.Module):
         w_box = float((self.loss_bbox_cfg or {}).get('loss_weight', 2.0))
         # get_targets: num_total_pos = sum over the images of max(#positives, 1); loss: reduce_mean over ranks, max(., 1)
         num_total = _reduce_mean(pos.sum(dim=1).clamp(min=1).sum().float()).clamp(min=1.0)
-        l_cls, l_box, l_dfl, avg = [], [], [], []
-        start = 0
         R = self.reg_max
-        for lv, (cs, bp, stride) in enumerate(zip(cls_scores, bbox_preds, self.strides)):
-            nl = num_level[lv]
-            a = anchors[start:start + nl]
-            cs = cs.permute(0, 2, 3, 1).reshape(B * nl, self.cls_out_channels).float()
-            bp = bp.permute(0, 2, 3, 1).reshape(B * nl, 4 * (R + 1)).float()
-            lab = labels[:, start:start + nl].reshape(-1)
-            lw = label_w[:, start:start + nl].reshape(-1)
-            bt = box_t[:, start:start + nl].reshape(-1, 4)
-            ps = pos[:, start:start + nl].reshape(-1)
-            start += nl
-            centers = torch.stack(((a[:, 0] + a[:, 2]) / 2.0, (a[:, 1] + a[:, 3]) / 2.0), dim=1) / stride
-            centers = centers[None].expand(B, nl, 2).reshape(-1, 2)
-            psf = ps.float()
-            wt = cs.detach().sigmoid().max(dim=1)[0] * psf          # weight_targets (0 off the positives)
-            corners = GL.integral(bp, R)
-            dec = GL.distance2bbox(centers, corners)
-            dec_t = bt / stride
-            score = GL.bbox_overlaps(dec.detach(), dec_t, is_aligned=True) * psf
-            tgt_c = GL.bbox2distance(centers, dec_t, R).reshape(-1)
-            l_box.append((GL.giou_loss(dec, dec_t) * wt).sum() * w_box)                      # avg_factor 1.0
-            dfl = GL.distribution_focal_loss(bp.reshape(-1, R + 1), tgt_c)
-            l_dfl.append((dfl * wt[:, None].expand(-1, 4).reshape(-1)).sum() / 4.0 * w_dfl)  # avg_factor 4.0
-            qfl = GL.quality_focal_loss(cs, lab, score, ps, qb)
-            l_cls.append((qfl * lw).sum() / num_total * w_cls)
-            avg.append(wt.sum())
-        avg_factor = _reduce_mean(sum(avg)).clamp(min=1.0)
-        return dict(loss_cls=l_cls, loss_bbox=[v / avg_factor for v in l_box], loss_dfl=[v / avg_factor for v in l_dfl])
+        # mmdet runs loss_single once per level (multi_apply).  Every term is per anchor and only the final sums are per
+        # level, so all levels go through ONE pass here -- per-anchor stride / centre / level tables are built once per
+        # pyramid geometry -- and the per-level sums are one product with the (A, levels) membership matrix: a fifth of the
+        # launches, the same numbers up to the order of the fp32 sums.
+        ctr, lvl1h = self._loss_tables(sizes, anchors, num_level, dev)     # (A, 2) centres / stride, (A, L) one-hot
+        A = anchors.shape[0]
+        cs = torch.cat([c.permute(0, 2, 3, 1).reshape(B, -1, self.cls_out_channels) for c in cls_scores], 1)
+        bp = torch.cat([r.permute(0, 2, 3, 1).reshape(B, -1, 4 * (R + 1)) for r in bbox_preds], 1)
+        cs, bp = cs.reshape(B * A, -1).float(), bp.reshape(B * A, -1).float()
+        centers = ctr[None].expand(B, A, 2).reshape(-1, 2)
+        stride = self._stride_vec[None].expand(B, A).reshape(-1, 1)
+        lab, lw, ps = labels.reshape(-1), label_w.reshape(-1), pos.reshape(-1)
+        psf = ps.float()
+        wt = cs.detach().sigmoid().max(dim=1)[0] * psf          # weight_targets (0 off the positives)
+        corners = GL.integral(bp, R)
+        dec = GL.distance2bbox(centers, corners)
+        dec_t = box_t.reshape(-1, 4) / stride
+        score = GL.bbox_overlaps(dec.detach(), dec_t, is_aligned=True) * psf
+        tgt_c = GL.bbox2distance(centers, dec_t, R).reshape(-1)
+        box_a = GL.giou_loss(dec, dec_t) * wt                                                   # avg_factor 1.0
+        dfl_a = (GL.distribution_focal_loss(bp.reshape(-1, R + 1), tgt_c).reshape(-1, 4) * wt[:, None]).sum(dim=1)
+        cls_a = GL.quality_focal_loss(cs, lab, score, ps, qb) * lw
+        per_level = torch.stack((box_a, dfl_a, cls_a, wt)).reshape(4, B, A).sum(dim=1) @ lvl1h  # (4, levels)
+        avg_factor = _reduce_mean(per_level[3].sum()).clamp(min=1.0)
+        l_box = per_level[0] * (w_box / avg_factor)
+        l_dfl = per_level[1] * (w_dfl / 4.0 / avg_factor)                                        # avg_factor 4.0
+        l_cls = per_level[2] * (w_cls / num_total)
+        return dict(loss_cls=list(l_cls.unbind(0)), loss_bbox=list(l_box.unbind(0)), loss_dfl=list(l_dfl.unbind(0)))
+
+    def _loss_tables(self, sizes, anchors, num_level, device):
+        """per-anchor constants of the loss, built once per pyramid geometry (capturable: no host -> device copy later):
+        anchor centres in units of the level's stride, the stride of every anchor, the (A, levels) level membership"""
+        key = (tuple(sizes), str(device))
+        cache = self.__dict__.setdefault('_loss_table_cache', {})
+        if key not in cache:
+            stride = torch.cat([anchors.new_full((n,), float(s)) for n, s in zip(num_level, self.strides)])
+            ctr = torch.stack(((anchors[:, 0] + anchors[:, 2]) / 2.0, (anchors[:, 1] + anchors[:, 3]) / 2.0), dim=1) \
+                / stride[:, None]
+            lvl = torch.cat([torch.full((n,), i, dtype=torch.long, device=device) for i, n in enumerate(num_level)])
+            cache[key] = (ctr, torch.nn.functional.one_hot(lvl, len(num_level)).float(), stride)
+        ctr, onehot, self._stride_vec = cache[key]
+        return ctr, onehot
 
     def forward_train(self, x, img_metas, gt_bboxes, gt_labels=None, gt_bboxes_ignore=None, proposal_cfg=None, **kwargs):
         """BaseDenseHead.forward_train (base_dense_head.py:306-345): heads -> loss"""
