@@ -151,13 +151,20 @@ class _RPNLoss(Function):
         grads, bufs = [], []
         for l in range(L):
             B, _, H, W = maps[2 * l].shape
-            buf = torch.zeros(B, H, W, 7 * A, device=dev)  # one NHWC map per level: [d cls (A) | d reg (6A)]
+            # one NHWC map per level: [d cls (A) | d reg (6A) | 0 ...] with the channel count of the map the predictions are
+            # views of (the RPN tower's fused, padded head output: rpn_head._SplitClsReg then hands this buffer on as the
+            # gradient of that output without a copy); 7A channels when the predictions are separate tensors
+            cs, rs_ = maps[2 * l], maps[2 * l + 1]
+            Cp = cs.stride(3) if (W > 1 and cs.stride(1) == 1 and rs_.stride() == cs.stride() and cs.stride(3) >= 7 * A
+                                  and rs_.storage_offset() == cs.storage_offset() + A) else 7 * A
+            buf = torch.zeros(B, H, W, Cp, device=dev)
+            buf._sm3_rest_is_zero = True
             bufs.append(buf)
             lv = d.level[l]
             lv.dcls, lv.dreg = buf.data_ptr(), buf.data_ptr() + 4 * A
-            lv.dcls_stride[:] = (H * W * 7 * A, 7 * A, 1)
-            lv.dreg_stride[:] = (H * W * 7 * A, 7 * A, 1)
-            grads += [buf[..., :A].permute(0, 3, 1, 2), buf[..., A:].permute(0, 3, 1, 2)]
+            lv.dcls_stride[:] = (H * W * Cp, Cp, 1)
+            lv.dreg_stride[:] = (H * W * Cp, Cp, 1)
+            grads += [buf[..., :A].permute(0, 3, 1, 2), buf[..., A:7 * A].permute(0, 3, 1, 2)]
         with torch.cuda.device(dev):
             check(lib().sm3_rpn_loss_backward(ctypes.byref(d), g_cls.data_ptr(), g_bbox.data_ptr(), stream_ptr()),
                   'rpn_loss_backward')

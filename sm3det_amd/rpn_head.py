@@ -173,6 +173,41 @@ def grid_anchors(featmap_sizes, strides, scales=(8,), ratios=(0.5, 1.0, 2.0), de
     return out
 
 
+class _SplitClsReg(torch.autograd.Function):
+    """(B, H, W, NP) fused head output -> the (B, A, H, W) objectness and (B, 6A, H, W) delta maps as views of it.  Plain
+    slicing does the same forward; its backward, however, builds a zero map per slice, copies the slice gradient in and adds
+    the two (5 launches over maps of up to 17 MB per level).  The fused RPN loss writes both gradients into ONE zero-filled
+    buffer of the fused layout (det_losses._RPNLoss.backward), so when the two incoming gradients are the matching views of
+    one such buffer it IS the gradient of the fused output and is returned as it stands."""
+
+    fast_path, fast_hits = True, 0  # (test hooks: tests/test_rpn_gpu.py checks the shortcut is taken and changes nothing)
+
+    @staticmethod
+    def forward(ctx, o, A):
+        ctx.A, ctx.shape = A, tuple(o.shape)
+        return o[..., :A].permute(0, 3, 1, 2), o[..., A:7 * A].permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, g_cls, g_reg):
+        A, shape = ctx.A, ctx.shape
+        base = None if g_cls is None or g_reg is None else g_cls._base
+        if (base is not None and base is g_reg._base and tuple(base.shape) == shape and base.is_contiguous()
+                and g_cls.storage_offset() == base.storage_offset()
+                and g_reg.storage_offset() == base.storage_offset() + A
+                and g_cls.stride() == (base.stride(0), 1, base.stride(1), base.stride(2))
+                and g_reg.stride() == g_cls.stride() and getattr(base, '_sm3_rest_is_zero', False)
+                and _SplitClsReg.fast_path):
+            _SplitClsReg.fast_hits += 1
+            return base, None
+        ref = g_cls if g_cls is not None else g_reg
+        g = ref.new_zeros(shape)
+        if g_cls is not None:
+            g[..., :A] = g_cls.permute(0, 2, 3, 1)
+        if g_reg is not None:
+            g[..., A:7 * A] = g_reg.permute(0, 2, 3, 1)
+        return g, None
+
+
 @_REG.register_module()
 class OrientedRPNHead(nn.Module):
     def __init__(self, in_channels, feat_channels=256, version='oc', anchor_generator=None, bbox_coder=None,
@@ -246,7 +281,7 @@ class OrientedRPNHead(nn.Module):
         t = conv3x3_nhwc(_to_nhwc(x), self.rpn_conv.weight, self.rpn_conv.bias, 1, True)  # conv + bias + ReLU
         B, H, W, C = t.shape
         o = ops.linear(t.reshape(-1, C), w, b).view(B, H, W, -1)
-        return o[..., :A].permute(0, 3, 1, 2), o[..., A:7 * A].permute(0, 3, 1, 2)
+        return _SplitClsReg.apply(o, A)
 
     def forward(self, feats):
         """multi_apply(forward_single, feats) -> (list of cls scores, list of bbox preds)"""
