@@ -143,11 +143,11 @@ class RandomSampler:
 
         On the GPU this is three launches of ``sampler.hip`` (count, list the candidates under a key threshold, sort the
         short lists in LDS and write the slots) instead of two full sorts of the n keys plus ~25 elementwise launches;
-        ``sample_fixed_host`` below is the definition in plain torch that the kernel reproduces on the same keys
-        (tests/test_assign_gpu.py) and that is itself compared with the reference's sampler class
-        (tests/test_oracle_heads_live.py)."""
-        if not gt_inds.is_cuda:
-            return self.sample_fixed_host(gt_inds, generator, key)
+        ``sample_fixed_host`` below is the rule written out in plain torch -- test infrastructure, not a fallback: the
+        kernels reproduce it on the same keys (tests/test_assign_gpu.py), a numpy model of the kernels' algorithm does
+        (tests/test_sampler_algorithm_cpu.py), and it is itself compared with the reference's sampler class
+        (tests/test_oracle_heads_live.py).  CPU tensors raise here like everywhere else on the product path."""
+        require_gpu(gt_inds, key)
         n, dev, num = gt_inds.numel(), gt_inds.device, self.num
         if key is None:
             key = torch.rand(n, device=dev, generator=generator)
@@ -164,7 +164,8 @@ class RandomSampler:
         return idx, fb[0], fb[1], cnt[0], cnt[1]
 
     def sample_fixed_host(self, gt_inds, generator=None, key=None):
-        """the rule of ``sample_fixed`` in plain torch (any device): two argsorts of the masked keys + slot arithmetic"""
+        """the rule of ``sample_fixed`` in plain torch (any device): two stable argsorts of the masked keys + slot
+        arithmetic.  Used by the tests as the definition; nothing on the product path calls it."""
         n = gt_inds.numel()
         dev = gt_inds.device
         num = self.num

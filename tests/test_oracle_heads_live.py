@@ -226,7 +226,8 @@ def test_max_iou_rule_vs_the_copy_in_the_reference_tree(rotated, cfg):
 @pytest.mark.parametrize('num,frac,ub,add_gt', [(64, 0.25, -1, True), (256, 0.5, -1, False), (64, 0.25, 3, True),
                                                 (512, 0.25, -1, True)])
 def test_sampler_counts_vs_live_reference_sampler(num, frac, ub, add_gt):
-    """The product sampler's sync-free core (sm3det_amd/assign.py `sample_fixed`, plain torch: runs on CPU) against the
+    """The rule of the product sampler's sync-free core (sm3det_amd/assign.py `sample_fixed_host`: plain torch, runs on CPU;
+    the device kernels behind `sample_fixed` reproduce it slot for slot on the same keys, tests/test_assign_gpu.py) against the
     reference's own `RRandomSampler.sample` (rotate_random_sampler.py) run live: both draw at random, so what is compared
     is what the reference's code DETERMINES -- how many positives and negatives, that positives come first and from the
     positive set, no duplicates, gts prepended when `add_gt_as_proposals` -- over assignments with too few, exactly enough
@@ -262,7 +263,7 @@ def test_sampler_counts_vs_live_reference_sampler(num, frac, ub, add_gt):
         ref = ref_s.sample(ra, boxes, gts, labels)
         full = ra.gt_inds  # after add_gt_ when applicable
         assert full.numel() == n + (k if add_gt else 0) and ref.bboxes.shape[0] == full.numel()
-        idx, is_pos, valid, n_pos, n_neg = mine_s.sample_fixed(full)
+        idx, is_pos, valid, n_pos, n_neg = mine_s.sample_fixed_host(full)
         assert int(n_pos) == ref.pos_inds.numel() and int(n_neg) == ref.neg_inds.numel(), (n, k)
         sel_pos, sel_neg = idx[is_pos & valid], idx[(~is_pos) & valid]
         assert sel_pos.numel() == int(n_pos) and sel_neg.numel() == int(n_neg)
