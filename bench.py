@@ -44,6 +44,9 @@ sys.path.insert(0, ROOT)
 
 MI355X_FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
 MI355X_HBM_PEAK_GBS = 8000.0  # same guide: HBM3E ~8 TB/s
+MI355X_BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: dense bf16 MFMA (v_mfma_f32_32x32x16_bf16), measured 2495
+# bf16x3 form of the fp32 GEMMs: six bf16 products per fp32 product -> fp32-equivalent ceiling of the matrix pipe
+MI355X_BF16X3_PEAK_TFLOPS = MI355X_BF16_MFMA_PEAK_TFLOPS / 6.0
 BATCH = 2
 RES = int(os.environ.get('SM3_BENCH_RES', '1024'))  # 1024 = BASELINE config; the override is a debugging aid only
 CONFIG_FILE = os.path.join(ROOT, 'sm3det_amd', 'configs', 'baseline_configs.json')
@@ -675,6 +678,24 @@ def ops_roofline(us):
     return out
 
 
+def native_f32_mfma_line(args):
+    """The headline step once more in a child process with SM3_GEMM_ARITH=f32 (every fp32 GEMM on v_mfma_f32_32x32x2_f32):
+    reported beside `value` so that the gain of the bf16x3 form is measured on the same box in the same run."""
+    import subprocess
+    env = dict(os.environ, SM3_GEMM_ARITH='f32', SM3_BENCH_NATIVE='0')
+    cmd = [sys.executable, os.path.abspath(__file__), '--gpus', '1', '--steps', str(args.steps), '--warmup', str(args.warmup),
+           '--config', args.config, '--no-ops', '--no-cpu-baseline'] + (['--fp32'] if args.fp32 else [])
+    try:
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600).stdout
+        line = json.loads([ln for ln in out.splitlines() if ln.startswith('{')][-1])
+        return dict(value_native_f32_mfma=line['value'], ms_per_step_native_f32_mfma=line['ms_per_step'],
+                    roofline_native_f32_mfma=dict(achieved=line['roofline']['achieved'], peak=line['roofline']['peak'],
+                                                  frac=line['roofline']['frac'], unit='TFLOP/s',
+                                                  gemm_ms_per_step=line['roofline']['gemm_ms_per_step']))
+    except Exception as e:  # noqa: BLE001
+        return dict(value_native_f32_mfma=None, native_f32_mfma_error=f'{type(e).__name__}: {e}'[:200])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -965,7 +986,7 @@ def main():
         # passes exist for the headline workload (fp32 and AMP), other configs report null
         traffic = traffic_file = None
         if args.config == DEFAULT_CONFIG or (args.amp and args.config == 'SM3Det_convnext_t'):  # the same backbone
-            for rnd in ('r04', 'r03', 'r02'):
+            for rnd in ('r05', 'r04', 'r03', 'r02'):
                 cand = os.path.join('profiles', rnd, 'pmc_traffic_amp.json' if args.amp else 'pmc_traffic.json')
                 try:
                     with open(os.path.join(ROOT, cand)) as f:
@@ -986,6 +1007,18 @@ def main():
                         gemm_ms_per_step=round(g_ms, 3),
                         other_kernels_ms_per_step=round(sum(v['ms'] for n, v in kernels.items()
                                                             if not n.startswith('gemm_f')), 3))
+        if not args.amp and LB.ARITH32 == 2:
+            # bf16x3: the fp32 contractions run as six v_mfma_f32_32x32x16_bf16 products per fp32 product (operands split exactly
+            # into three bf16 pieces in the loader, fp32 accumulation): the matrix-pipe ceiling is 2.5 PF / 6 fp32-equivalent
+            gbs = g_by / (g_ms * 1e-3) / 1e9 if g_ms > 0 else 0.0
+            roofline.update(kernel='gemm_f32_kernel<.., F16 = 2> (bf16x3: fp32 tensors, 3 exact bf16 pieces per operand element, '
+                            '6 x v_mfma_f32_32x32x16_bf16 per 16 k, fp32 accumulate)',
+                            peak=round(MI355X_BF16X3_PEAK_TFLOPS, 1), frac=round(achieved / MI355X_BF16X3_PEAK_TFLOPS, 4),
+                            peak_note='dense bf16 MFMA peak 2500 TF/s / 6 products per fp32 product; achieved = fp32 FLOP / time',
+                            x_native_fp32_mfma_peak=round(achieved / MI355X_FP32_MFMA_PEAK_TFLOPS, 3),
+                            hbm_gbs=round(gbs, 1), hbm_frac=round(gbs / MI355X_HBM_PEAK_GBS, 4))
+            if traffic_file is not None and 'r05' not in traffic_file:
+                roofline.update(traffic=None, traffic_source=None)  # the older passes measured the native-fp32 kernels
         if args.amp:  # fp16 operands: 16x the matrix rate -> the family streams its operands: HBM-bound
             gbs = g_by / (g_ms * 1e-3) / 1e9 if g_ms > 0 else 0.0
             roofline.update(bound='hbm', kernel='gemm_f32_kernel<.., F16, IO> (v_mfma_f32_32x32x16_f16; activations stored '
@@ -1013,6 +1046,12 @@ def main():
                                     'fwd+bwd + bucketed grad all-reduce + grad-clip(35)+AdamW (per-parameter lr); synthetic '
                                     f'randn({BATCH},3,{RES},{RES}) per GPU, random-init weights; neck/heads timed separately in ops_us'),
                        'name': args.config, 'baseline_config': cfg_entry['baseline_config'], 'backbone': desc,
+                       'gemm_arith': ('fp16 operands, fp32 accumulate (AMP)' if args.amp else
+                                      ('bf16x3: fp32 tensors; each operand element split exactly into three bf16 pieces, six bf16 MFMA '
+                                       'products (i+j<=2) accumulated in fp32 -- fp32-equivalent (error vs fp64 <= the native fp32 '
+                                       "kernel's x1.5 per shape: profiles/r05/gemm_b3_eval.txt); SM3_GEMM_ARITH=f32 runs the native "
+                                       'v_mfma_f32_32x32x2_f32 form (value_native_f32_mfma)' if LB.ARITH32 == 2 else
+                                       'native fp32 MFMA (v_mfma_f32_32x32x2_f32)')),
                        'global_batch': world * BATCH, 'resolution': RES, 'parallelism': f'dp{world}',
                        'grad_buckets': reducer.num_buckets, 'hip_graph': bool(use_graph),
                        'wgrad_side_stream': bool(overlap_was), 'split_backward': bool(split and use_graph),
@@ -1052,6 +1091,8 @@ def main():
                         'AdamW over 178 M parameters; device-resident synthetic inputs, no data pipeline')
                 except Exception as e:  # noqa: BLE001  (never lose the headline line to the extra workload)
                     result['full_model'] = dict(error=f'{type(e).__name__}: {e}'[:300])
+        if world == 1 and not args.amp and LB.ARITH32 == 2 and os.environ.get('SM3_BENCH_NATIVE', '1') == '1':
+            result.update(native_f32_mfma_line(args))  # the same step with the native fp32 matrix instruction, beside `value`
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(args.config)
         else:

@@ -192,7 +192,11 @@ typedef struct sm3_gemm_desc {
                         bit 16 TN: slices summed by the in-kernel fix-up instead of the second pass */
   int32_t compute;   /* 0: fp32 operands (v_mfma_f32_32x32x2_f32, exact).  1: operands rounded to fp16 on the fly, fp32
                         accumulation (v_mfma_f32_32x32x16_f16) -- the arithmetic autocast gives nn.Linear in the reference's
-                        AMP configs (fp16 = dict(loss_scale='dynamic')) */
+                        AMP configs (fp16 = dict(loss_scale='dynamic')).  2: fp32 tensors, fp32-equivalent arithmetic on the
+                        bf16 matrix pipe -- each operand element is split exactly into three bf16 pieces (x = x0+x1+x2,
+                        round-to-nearest each) in the loader and the six products a_i.b_j with i+j <= 2 are accumulated in
+                        fp32 by v_mfma_f32_32x32x16_bf16 (dropped terms <= 2^-25 |a||b|; non-finite inputs give NaN);
+                        K % 16 == 0, tiles 128x128 / 128x96 / 64x128 (TN: 96x128), k-step 16 */
   int32_t io;        /* compute == 1 only: which tensors are STORED as fp16 (the AMP data path; 0 = everything fp32 in
                         memory, rounded in the loader).  Bits: 1 A, 2 B, 4 C, 8 aux_in / aux_out.  Supported: NT {1 with
                         epilogue none / bias / bias+scale+residual, 1|4|8 with bias+GELU}; NN {1 with none, 4|8 with

@@ -126,6 +126,19 @@ def _p(t):
 
 _COUNTERS = {}
 COMPUTE = 0  # 0: fp32 operands; 1: fp16 operands / fp32 accumulation (set by sm3det_amd.amp.autocast)
+# How a COMPUTE == 0 (fp32) GEMM is evaluated -- sm3_gemm_desc.compute of the launch:
+#   2 'bf16x3' (default): every fp32 operand element split exactly into three bf16 pieces in the loader, six
+#     v_mfma_f32_32x32x16_bf16 products (i + j <= 2) with fp32 accumulation: fp32-equivalent results (24 operand bits kept,
+#     dropped terms <= 2^-25 |a||b|; error vs the fp64 product measured per shape in tests/test_gemm_gpu.py and
+#     profiles/r05/gemm_b3_error.txt) at 6/16 of the matrix-pipe time of the native fp32 instruction;
+#   0 'f32': v_mfma_f32_32x32x2_f32 (an exact fp32 FMA chain, 157.3 TF/s peak).  SM3_GEMM_ARITH=f32 selects it.
+ARITH32 = {'bf16x3': 2, 'f32': 0}[__import__('os').environ.get('SM3_GEMM_ARITH', 'bf16x3')]
+
+
+def gemm_arith():
+    """name of the arithmetic the fp32 GEMMs run in ('bf16x3' | 'f32'), for reports"""
+    return 'bf16x3' if ARITH32 == 2 else 'f32'
+
 TUNING = int(__import__('os').environ.get('SM3_GEMM_TUNING', '0'))  # benchmarking override forwarded to sm3_gemm_desc.tuning (scripts/gemm_sweep2.py); 0 in production
 
 
@@ -207,7 +220,7 @@ def gemm(mode, A, B, C, M, N, K, *, epilogue=EPI_NONE, bias=None, aux_in=None, a
     d.colsum_out = _p(colsum_out)
     d.counters = _p(gemm_counters(C.device))
     d.tuning = TUNING
-    d.compute = COMPUTE
+    d.compute = COMPUTE if COMPUTE else ARITH32
     h = torch.float16
     aux = aux_in if aux_in is not None else aux_out
     d.io = ((IO_A16 if A.dtype == h else 0) | (IO_B16 if B.dtype == h else 0) | (IO_C16 if C.dtype == h else 0) |
@@ -220,7 +233,7 @@ def gemm(mode, A, B, C, M, N, K, *, epilogue=EPI_NONE, bias=None, aux_in=None, a
     if nbytes:
         ws = _lib.workspace(nbytes, C.device)
     rows = K if mode == TN else M
-    tag = ('gemm_f16_' if COMPUTE else 'gemm_f32_') + ('nt', 'nn', 'tn')[mode]
+    tag = ('gemm_f16_' if COMPUTE else 'gemm_f32_') + ('nt', 'nn', 'tn')[mode]  # ('f32' = fp32 tensors, either arithmetic)
     if PROFILE is not None and PROFILE_SHAPES:
         tag += f' {M}x{N}x{K} g{num_groups} e{epilogue} s{splits}'
     # algorithmic bytes: each operand read once, the output (and the epilogue's auxiliary tensor) written once

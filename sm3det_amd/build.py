@@ -23,6 +23,9 @@ FILE_FLAGS = {
     'deform_conv.hip': ['-ffp-contract=off'],
     'rpn.hip': ['-ffp-contract=off'],
     'deform_fused.hip': ['-ffp-contract=off'],
+    # bf16x3 GEMMs: the operand split is scalar fp32 arithmetic beside MFMAs; SLP-packing it into v_pk_add_f32 costs more issue
+    # time than the scalar form (MI355X_MICROARCH.md, "price of one filler beside MFMAs")
+    'gemm_b3_nt.hip': ['-fno-slp-vectorize'], 'gemm_b3_nn.hip': ['-fno-slp-vectorize'], 'gemm_b3_tn.hip': ['-fno-slp-vectorize'],
 }
 
 
@@ -44,17 +47,25 @@ VARIANTS = {
     'trace': ['-DSM3_TRACE=1'], 'prio1': ['-DSM3_PRIO=1'], 'prio2': ['-DSM3_PRIO=2'], 'stagger': ['-DSM3_STAGGER=1'],
     'trace_stagger': ['-DSM3_TRACE=1', '-DSM3_STAGGER=1'],
     'lpt8': ['-DSM3_ROUTER_LPT=8'], 'lpt2': ['-DSM3_ROUTER_LPT=2'],  # lanes per token of the MoE router kernels
+    'abl_nocvt': ['-DSM3_ABL_NOCVT=1'],  # bf16x3 loop without the split arithmetic (stores kept)
+    'b3_nomix': ['-DSM3_B3_NOMIX=1'], 'b3_occ2': ['-DSM3_B3_OCC=2'],
+ # bf16x3 GEMMs at three workgroups per CU (register budget 168 instead of 256)
     'abl_noepi': ['-DSM3_ABL_NOEPI=1'], 'abl_loop_only_mfma': ['-DSM3_ABL_NOLOAD=1', '-DSM3_ABL_NOSTORE=1', '-DSM3_ABL_NOEPI=1'],
 }
 
 
-def build_variant(name, verbose=False):
+def build_variant(name, verbose=False, only=None):
+    """only: substring of the translation units the variant's define touches -- the others are linked from the main build's
+    objects (python -m sm3det_amd.build --variant b3_occ3 --only gemm_b3)"""
     flags = VARIANTS[name]
     vdir = os.path.join(CSRC, '_variant_' + name)
     os.makedirs(vdir, exist_ok=True)
     lib = os.path.join(CSRC, f'libsm3det_hip_{name}.so')
     objs, procs = [], []
     for s in sorted(glob.glob(os.path.join(CSRC, '*.hip'))):
+        if only and only not in os.path.basename(s):
+            objs.append(s[:-4] + '.o')
+            continue
         o = os.path.join(vdir, os.path.basename(s)[:-4] + '.o')
         objs.append(o)
         cmd = [_hipcc()] + BASE_FLAGS + FILE_FLAGS.get(os.path.basename(s), []) + flags + ['-c', s, '-o', o]
@@ -100,6 +111,7 @@ def build(force=False, verbose=False):
 
 if __name__ == '__main__':
     if '--variant' in sys.argv:
-        print(build_variant(sys.argv[sys.argv.index('--variant') + 1], verbose='-v' in sys.argv))
+        print(build_variant(sys.argv[sys.argv.index('--variant') + 1], verbose='-v' in sys.argv,
+                            only=sys.argv[sys.argv.index('--only') + 1] if '--only' in sys.argv else None))
     else:
         print(build(force='-f' in sys.argv, verbose='-v' in sys.argv))

@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
 }
 
 // ---- configuration: tile shape, k-step, split-K ---------------------------------------------------------------
-constexpr int COUNTER_SLOTS = kCounterSlots;  // the 16 top slots are the persistent launches' item queue
+constexpr int COUNTER_SLOTS = kCounterSlots;
 
 struct Cfg {
   int tile, bk, splits, fixup;
@@ -216,13 +216,6 @@ struct Cfg {
 };
 
 inline int pad_to(int n, int b) { return (n + b - 1) / b * b; }
-
-// workgroups per CU the kernel's launch bounds ask for (gemm_f32_kernel.h: occupancy<>)
-inline int resident_per_cu(int tile, int bk, bool f16) {
-  static const int titj[6] = {4, 3, 3, 6, 6, 2};
-  if (f16) return bk == 64 ? 2 : SM3_F16_OCC;
-  return (titj[tile] >= 6 || bk == 32) ? 2 : (titj[tile] >= 3 ? 3 : 4);
-}
 
 // blocks -> rounds of 256 CUs actually paid for / rounds of work (>= 1): the matrix pipes of a CU are shared by its
 // resident workgroups, so a launch costs as many tile-times as the fullest CU holds
@@ -243,7 +236,7 @@ inline double quant_cost(long blocks) {
 //    slice.  Since the k-loop lost its vector-ALU work the 96-wide tiles are as fast per FLOP as 128x128.
 // d->tuning (benchmarking aid, 0 in production): bits 0-3 tile+1, 4-7 k-step (1 = 16, 2 = 32, 3 = 64: fp16 only), 8-15 slices,
 // bit 16: TN slices summed by the in-kernel fix-up instead of the second pass (so a literal 256 in the slices field
-// reads as `automatic + fix-up`: scripts/gemm_sweep2.py); bit 17: persistent form of the NT / NN launches (sm3_gemm_f32)
+// reads as `automatic + fix-up`: scripts/gemm_sweep2.py)
 Cfg choose_cfg(const sm3_gemm_desc* d) {
   Cfg c;
   memset(&c, 0, sizeof(c));
@@ -270,6 +263,7 @@ Cfg choose_cfg(const sm3_gemm_desc* d) {
       bk = (d->K >= 3072 || (d->mode == MODE_NT && d->N <= 128 && d->K >= 384 && d->M >= 65536)) ? 64 : 32;
       if (t_bk) bk = t_bk == 1 ? 16 : (t_bk == 3 ? 64 : 32);
     }
+    if (d->compute == 2) bk = 16;  // bf16x3 form: k-step 16 only (three LDS planes per operand)
     if (d->K % bk) bk = (bk == 64 && d->K % 32 == 0) ? 32 : 16;
     const int kt = d->K / bk;
     double best = 0;
@@ -295,7 +289,8 @@ Cfg choose_cfg(const sm3_gemm_desc* d) {
     if (c.tile < 0) { c.tile = t_tile >= 0 ? t_tile : 0; best_s = 1; }
     c.bk = bk;
     if (c.tile == 3) c.bk = 16;
-    if (d->compute == 1 && c.tile != 0 && c.tile != 1 && c.tile != 5) c.tile = 0;  // fp16: 128x128 / 128x96 / 64x128
+    if (d->compute != 0 && c.tile != 0 && c.tile != 1 && c.tile != 5) c.tile = 0;  // fp16 / bf16x3: 128x128 / 128x96 / 64x128
+    if (d->compute == 2) c.bk = 16;
     tile_dims(c.tile, c.bm, c.bn);
     c.ntn = (d->N + c.bn - 1) / c.bn;
     // ragged groups: at most ceil(M/BM) + G row tiles exist; surplus blocks exit
@@ -349,6 +344,10 @@ Cfg choose_cfg(const sm3_gemm_desc* d) {
     c.bk = t_bk == 1 ? 16 : (t_bk == 3 ? 64 : 32);
     if (c.tile > 2) c.tile = 0;
   }
+  if (d->compute == 2) {
+    c.bk = 16;
+    if (c.tile > 2) c.tile = 0;
+  }
   tile_dims(c.tile, c.bm, c.bn);
   c.ntn = (d->N + c.bn - 1) / c.bn;
   c.ntm = (d->M + c.bm - 1) / c.bm;
@@ -398,7 +397,7 @@ int sm3_gemm_f32(const sm3_gemm_desc* d, void* workspace, size_t workspace_bytes
   if (d->mode == MODE_TN && (d->M & 3)) return SM3_ERR_UNSUPPORTED;
   if (d->mode == MODE_TN && d->epilogue != EPI_NONE) return SM3_ERR_INVALID_ARG;
   if (d->mode != MODE_NT && d->mode != MODE_NN && d->mode != MODE_TN) return SM3_ERR_INVALID_ARG;
-  if (d->compute != 0 && d->compute != 1) return SM3_ERR_INVALID_ARG;
+  if (d->compute != 0 && d->compute != 1 && d->compute != 2) return SM3_ERR_INVALID_ARG;
   if (d->io != 0 && (d->compute != 1 || d->io < 0 || d->io > 15)) return SM3_ERR_INVALID_ARG;
   // fp16-stored operands: 8-byte loads of k-quads (lda % 4, checked above) / 4-byte loads of column pairs (even dims)
   if (d->mode == MODE_TN && (((d->io & 1) && (d->M & 1)) || ((d->io & 2) && (d->N & 1)))) return SM3_ERR_UNSUPPORTED;
@@ -457,7 +456,8 @@ int sm3_gemm_f32(const sm3_gemm_desc* d, void* workspace, size_t workspace_bytes
     }
     dim3 grid(c.ntn * c.ntm, 1, c.groups * c.splits);
     const int rc = d->compute == 1 ? launch_tn16(p, c.tile, c.bk, d->io, grid, st)
-                                   : launch_tn(p, c.tile, c.bk, 0, grid, st);
+                   : d->compute == 2 ? launch_tn_b3(p, c.tile, grid, st)
+                                     : launch_tn(p, c.tile, c.bk, 0, grid, st);
     if (rc) return rc;
     if (c.splits > 1 && !c.fixup) {
       launch_splitk_reduce((const float*)workspace, out, mn, c.splits, c.groups, nullptr, 0, 0, st,
@@ -467,35 +467,13 @@ int sm3_gemm_f32(const sm3_gemm_desc* d, void* workspace, size_t workspace_bytes
   }
   if (d->M == 0) return SM3_OK;
   dim3 grid(c.ntn * c.ntm, 1, c.splits);
-  // Persistent form (gemm_f32_kernel.h, "work items"): with more tiles than the chip holds workgroups at once, launch
-  // exactly the resident set and let it walk the tiles.  OPT-IN through bit 17 of d->tuning: measured in round 4
-  // (profiles/r04/gemm_persistent_ab.txt) it is 2-35 % SLOWER than one workgroup per tile on every shape of the training
-  // step -- with 3-4 workgroups resident per CU the hardware already overlaps one workgroup's prologue and store drain
-  // with its neighbours' k-loops, the long "prologues" the per-workgroup trace shows are queueing for HBM, not idle
-  // pipes, and the persistent loop pays for its carried state with scratch traffic.  Kept as a tested measurement form.
-  bool persist = false;
-  {
-    const int enabled = (int)(((unsigned)d->tuning >> 17) & 1u);
-    const int resident = kNumCU * resident_per_cu(c.tile, c.bk, d->compute == 1);
-    const bool have = d->compute == 1 ? (d->io != 0 && has_persistent_h16(d->mode, d->epilogue, c.tile, c.bk, d->io))
-                                      : has_persistent_f32(c.tile, c.bk);
-    if (enabled && have && c.splits == 1 && d->counters != nullptr && (long)c.ntn * c.ntm > resident) {
-      persist = true;
-      p.total_tiles = c.ntn * c.ntm;
-      grid = dim3(resident, 1, 1);
-    }
-  }
   int rc;
-  if (persist) {
-    if (d->compute == 1)
-      rc = d->mode == MODE_NT ? launch_nt_h16_p(p, d->epilogue, c.tile, c.bk, d->io, grid, st)
-                              : launch_nn_h16_p(p, d->epilogue, c.tile, c.bk, d->io, grid, st);
-    else
-      rc = d->mode == MODE_NT ? launch_nt_p(p, d->epilogue, c.tile, c.bk, grid, st)
-                              : launch_nn_p(p, d->epilogue, c.tile, c.bk, grid, st);
-  } else if (d->compute == 1) {
+  if (d->compute == 1) {
     rc = d->mode == MODE_NT ? launch_nt16(p, d->epilogue, c.tile, c.bk, d->io, grid, st)
                             : launch_nn16(p, d->epilogue, c.tile, c.bk, d->io, grid, st);
+  } else if (d->compute == 2) {
+    rc = d->mode == MODE_NT ? launch_nt_b3(p, d->epilogue, c.tile, grid, st)
+                            : launch_nn_b3(p, d->epilogue, c.tile, grid, st);
   } else {
     rc = d->mode == MODE_NT ? launch_nt(p, d->epilogue, c.tile, c.bk, 0, grid, st)
                             : launch_nn(p, d->epilogue, c.tile, c.bk, 0, grid, st);

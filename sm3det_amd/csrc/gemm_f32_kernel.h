@@ -45,18 +45,14 @@ namespace sm3gemm {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int MODE_NT = 0, MODE_NN = 1, MODE_TN = 2;
 constexpr int NTHREADS = 256;
 // EPI codes (must match include/sm3det_hip.h)
 constexpr int EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_BIAS_SCALE_RES = 3, EPI_GELU_BWD = 4;
 constexpr int EPI_BIAS_RELU = 5;
-// persistent launches: 16 words at the top of the ticket-counter array (sm3_gemm_f32_counter_slots() ints) hold the item
-// queue -- one head per XCD (a workgroup draws items of its own residue mod 8: hardware block b runs on XCD b % 8, and the
-// tile remap keeps consecutive logical tiles on one XCD for L2 reuse of the shared operand) -- and the count of workgroups
-// that have left; the split-K tickets use the slots below
 constexpr int kCounterSlots = 1 << 16;
-constexpr int kPersistQueueSlot = kCounterSlots - 16;
 
 struct GemmParams {
   const float* A;
@@ -76,7 +72,6 @@ struct GemmParams {
   int kTilesPerSplit;  // NT/NN: k-tiles per slice
   float* slabs;        // fixup: [tile][split][BM*BN]
   int* counters;       // fixup: one ticket counter per tile, zero on entry, zero on exit
-  int total_tiles;     // PERSIST instantiations: grid.x workgroups walk this many items (first blockIdx.x, then a queue)
   // epilogue operands
   const float* bias;      // [N] (per group)
   const float* aux_in;    // EPI_GELU_BWD: gelu'(h)[M,N];  EPI_BIAS_SCALE_RES: residual[M,N]
@@ -127,11 +122,15 @@ using T64x128 = Tile<2, 2, 1, 2>;
 #ifndef SM3_F16_OCC
 #define SM3_F16_OCC 3  // A/B builds: python -m sm3det_amd.build --variant f16_occ2
 #endif
+#ifndef SM3_B3_OCC
+#define SM3_B3_OCC 3  // bf16x3 form: workgroups per CU the launch bounds ask for
+#endif
 template <class TL, int BK, int F16 = 0>
 constexpr int occupancy() {
   // F16: the fp16 LDS image of a k-step-32 tile is 34 KB (the fp32 image 66 KB), so three workgroups fit a CU and the
   // loop -- bound by load latency, not by the matrix pipe -- gets a third wave per SIMD to hide it; k-step 64 (68 KB,
   // twice the MFMAs per barrier) runs two
+  if (F16 == 2) return (TL::TI * TL::TJ >= 6) ? 2 : SM3_B3_OCC;
   if (F16) return BK == 64 ? 2 : SM3_F16_OCC;
   // 128x128 at k-step 16 needs ~150 VGPRs to keep its LDS read bases out of the loop: 3 waves per SIMD without spills
   // instead of 4 with scratch reloads and address arithmetic between the MFMAs
@@ -185,9 +184,8 @@ __device__ __forceinline__ void gelu_erf_both(float h, float& y, float& dy) {
 // output, GELU', their gradient) are fp16: half the bytes of the launches that move them.
 constexpr int IO_A16 = 1, IO_B16 = 2, IO_C16 = 4, IO_X16 = 8;  // A operand, B operand, C output, aux_in / aux_out
 
-template <int MODE, int EPI, int BK, class TL, int GATHER, int F16 = 0, int CSUM = 0, int IO = 0, int PERSIST = 0>
+template <int MODE, int EPI, int BK, class TL, int GATHER, int F16 = 0, int CSUM = 0, int IO = 0>
 __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32_kernel(GemmParams p) {
-  static_assert(!PERSIST || (MODE != MODE_TN && !GATHER), "persistent form: NT / NN without GATHER");
   constexpr int BM = TL::BM, BN = TL::BN, TI = TL::TI, TJ = TL::TJ, WN = TL::WN, WM = TL::WM;
   constexpr bool A16 = (IO & IO_A16) != 0, B16 = (IO & IO_B16) != 0, C16 = (IO & IO_C16) != 0, X16 = (IO & IO_X16) != 0;
   static_assert(IO == 0 || (F16 && !GATHER), "fp16 storage only with fp16 operands");
@@ -208,18 +206,29 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
   // fragment is ONE conflict-free ds_read_b128 with no conversion or permute between it and the MFMA (the fp32 image
   // needed 8 ds_read_b32 + 4 conversions per fragment).  LD16 = rows + 4 = 4 (mod 16) rows keeps the 8-byte transposed
   // stores of a k-step-32 tile on distinct banks.
+  // B3 (F16 == 2): fp32-equivalent arithmetic on the bf16 matrix pipe.  Every fp32 operand element is split EXACTLY into
+  // three bf16 pieces x = x0 + x1 + x2 (round-to-nearest each: 3 x 8 significant bits + signs >= the 24 of fp32) when its
+  // piece is stored to LDS; the image holds the three pieces as three fp16-style planes, and a k-step issues the six
+  // products a_i . b_j with i + j <= 2 on v_mfma_f32_32x32x16_bf16 (fp32 accumulation; each bf16 x bf16 product is exact in
+  // fp32, the dropped terms are <= 2^-25 |a||b|).  6 instructions of 32 cycles replace 8 of 64 per 16 k: the fp32 matrix
+  // instruction runs at the VECTOR rate (1/16 of the bf16 rate), this form at 6/16 of it.  k-step 16 only (the three
+  // planes of a k-step-32 tile would not leave room for two workgroups per CU).
+  constexpr bool B3 = (F16 == 2);
+  static_assert(!B3 || (BK == 16 && IO == 0 && !GATHER), "bf16x3 form: k-step 16, fp32 tensors");
+  constexpr int NIMG = B3 ? 3 : 1;
   constexpr int LDA16 = BM + 4, LDB16 = BN + 4;                          // rows per k-octet
-  constexpr int A_ST16 = (BK / 8) * LDA16 * 4, B_ST16 = (BK / 8) * LDB16 * 4;  // dwords per stage
+  constexpr int A_ST16 = (BK / 8) * LDA16 * 4, B_ST16 = (BK / 8) * LDB16 * 4;  // dwords per plane and stage
+  constexpr int A_STG = NIMG * A_ST16, B_STG = NIMG * B_ST16;                // dwords per stage
   // the allocation is the image of the instantiation's own precision (round 2 gave F16 the fp32 size, which capped it at
   // two workgroups per CU); never below the epilogue's per-wave staging patches (4 x 32 x 36 floats)
   static_assert(!(CSUM && A16), "the column-sum by-product adds the fp32 values of the A pieces");
-  constexpr int SMEM_IMAGE = F16 ? 2 * (A_ST16 + B_ST16) : 2 * (A_STAGE + B_STAGE);
+  constexpr int SMEM_IMAGE = F16 ? 2 * (A_STG + B_STG) : 2 * (A_STAGE + B_STAGE);
   constexpr int SMEM_WORDS = SMEM_IMAGE > 4 * 32 * 36 ? SMEM_IMAGE : 4 * 32 * 36;
   static_assert(!(F16 && CSUM) || (BK / 4) * BM <= SMEM_WORDS, "column-sum scratch of the fp16-operand TN form");
   __shared__ __attribute__((aligned(16))) float smem[SMEM_WORDS];
   float* As = smem;                // [2][BK][LDA_S]
   uint32_t* Aw = reinterpret_cast<uint32_t*>(smem);  // [2][BK/8][LDA16][4 dwords], then B
-  uint32_t* Bw = Aw + 2 * A_ST16;
+  uint32_t* Bw = Aw + 2 * A_STG;
   float* Bs = smem + 2 * A_STAGE;  // [2][BK][LDB_S]
 
   const int tid = threadIdx.x;
@@ -251,18 +260,8 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
   const int lh = lane >> 5;
 
   // ---- work items ------------------------------------------------------------------------------------------------
-  // One item = one output tile (x one k-slice: blockIdx.z).  Plain launches run one item per workgroup (grid.x = items).
-  // PERSISTENT launches (PERSIST instantiations: NT / NN without GATHER, no k-slices): grid.x resident workgroups walk the items --
-  // the first is blockIdx.x, the following ones come from a device-side queue (one relaxed atomic per item, fetched a
-  // whole k-loop ahead of its use) -- and the operands of the next item's first k-tile are requested INSIDE the epilogue
-  // of the current one (after its first 32x32 accumulator tile has been staged: those registers take the data), so that neither the workgroup launch, nor the group look-up, nor the first HBM round trip of a
-  // tile (3-14 us under load, measured per workgroup with the `trace` build: profiles/r04/gemm_trace_*.txt) is exposed
-  // after the first item, and the store drain of an epilogue overlaps the next k-loop.
-  // PERSIST is a template flag: the plain instantiations keep exactly the register budget they had (the item loop folds
-  // away); the persistent ones carry the next item's state across the epilogue.
-  constexpr bool CAN_PERSIST = PERSIST != 0;
-  constexpr bool persist = CAN_PERSIST;
-  const int nitems = persist ? p.total_tiles : (int)gridDim.x;
+  // One item = one output tile (x one k-slice: blockIdx.z), one item per workgroup (grid.x = items).
+  const int nitems = (int)gridDim.x;
   const int ntn = (p.N + BN - 1) / BN;
   // group offsets of a grouped NT / NN launch in ONE vector load: lane l holds offsets[l] and the tile -> group look-up is
   // scalar ALU over v_readlane (the look-up used to issue up to 2 * G dependent scalar loads per workgroup)
@@ -315,6 +314,14 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
   int gy[PA], gx[PA];    // GATHER (NT/NN): grid coordinates of this thread's A rows
   unsigned m9[PA];       // GATHER (NT/NN): bit t set <=> tap t of this row reads a pixel inside the image
   int tn_tap = 0;        // GATHER (TN): the tap this N-tile belongs to (cC % BN == 0)
+  // direct pieces of the fp16 / bf16x3 images: unit idx -> (k-quad g4, column c) of an operand with R columns, column
+  // fastest: a wave's 4-byte loads then cover 256 contiguous bytes of a k-row.  (Measured for the bf16x3 form: a k-quad-
+  // parity-fastest order, whose 8-byte LDS stores are bank-conflict free, is 0.45 ms per step SLOWER -- two 128-byte row
+  // segments per load instruction cost more than the 2-way store conflict; profiles/r05/gemm_b3_variants.txt)
+  auto unit_gc = [](int idx, int R, int& g4, int& c) {
+    g4 = min(idx / R, BK / 4 - 1);  // surplus units repeat the last k-quad
+    c = idx % R;
+  };
   // item-independent part: where a piece lands in the LDS image
 #pragma unroll
   for (int i = 0; i < PA; i++) {
@@ -337,7 +344,8 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
         // F16: a piece is FOUR CONSECUTIVE k OF ONE COLUMN (four coalesced 4-byte loads, lanes along the columns), so
         // that it lands in the fp16 image as 8 contiguous bytes like a transposed piece; a piece of four columns at
         // one k would scatter 2-byte stores 16 B apart (8-way bank conflicts: measured 13.5 vs 9.4 ms per step)
-        const int g4 = min(idx / BM, BK / 4 - 1), c = idx % BM;  // surplus units repeat the last k-quad
+        int g4, c;
+        unit_gc(idx, BM, g4, c);
         ha[i] = ((g4 >> 1) * LDA16 + c) * 4 + 2 * (g4 & 1);
         if (A16) {
           // unit = (k-octet, column pair, k-quad parity), parity fastest: the two 8-byte LDS stores of 16 consecutive
@@ -370,7 +378,8 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
           const int g8 = min(u / (BN / 2), BK / 8 - 1), cc = 2 * (u % (BN / 2));
           hb[i] = (g8 * LDB16 + cc) * 4 + 2 * par;
         } else {
-          const int g4 = min(idx / BN, BK / 4 - 1), c = idx % BN;
+          int g4, c;
+          unit_gc(idx, BN, g4, c);
           hb[i] = ((g4 >> 1) * LDB16 + c) * 4 + 2 * (g4 & 1);
         }
       }
@@ -391,7 +400,7 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
   // ---- everything that depends on the item: tile coordinates, group, row range, k-slice, source offsets, descriptors ----
   auto setup_item = [&](int item) {
     // XCD-aware remap of the linear item id (speed only): consecutive logical tiles share an XCD (hardware block b runs
-    // on XCD b % 8; a persistent workgroup's items keep its residue: grid.x is a multiple of 8 there)
+    // on XCD b % 8)
     bid = item;
     {
       const int nblk = nitems;
@@ -517,7 +526,8 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
         pa[i] = Ag + min(m0 + 4 * cq, p.M - 4);
         oa[i] = (unsigned)(((long)min(kk, BK - 1) * p.lda + min(m0 + 4 * cq, p.M - 4)) * 4);  // kk >= BK: lane without an element
         if (F16) {
-          const int g4 = min(idx / BM, BK / 4 - 1), c = idx % BM;  // surplus units repeat the last k-quad
+          int g4, c;
+          unit_gc(idx, BM, g4, c);
           oa[i] = (unsigned)(((long)(4 * g4) * p.lda + min(m0 + c, p.M - 1)) * 4);
           if (A16) {
             const int par = idx & 1, u = idx >> 1;
@@ -563,7 +573,8 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
             const int g8 = min(u / (BN / 2), BK / 8 - 1), cc = 2 * (u % (BN / 2));
             ob[i] = (unsigned)(((long)(8 * g8 + 4 * par) * p.ldb + min(n0 + cc, p.N - 2)) * 2);
           } else {
-            const int g4 = min(idx / BN, BK / 4 - 1), c = idx % BN;
+            int g4, c;
+            unit_gc(idx, BN, g4, c);
             ob[i] = (unsigned)(((long)(4 * g4) * p.ldb + min(n0 + c, p.N - 1)) * 4);
           }
         }
@@ -594,7 +605,7 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
   };
   int item = blockIdx.x;
   setup_item(item);
-  if (!valid && !persist) return;  // surplus block of a ragged plain launch (all slices of it leave: no ticket is ever drawn)
+  if (!valid) return;  // surplus block of a ragged plain launch (all slices of it leave: no ticket is ever drawn)
   // piece q in [0, NP): q < PA -> A piece q, else B piece q - PA.  tail == false (the bulk of the k-loop): tile kt is a
   // complete tile strictly before the last one, so no clamp and no select is issued; tail == true: the last steps, where
   // kt may be clamped and TN reduction rows past the segment end are zeroed.
@@ -730,19 +741,46 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
     // the two columns' k-quads (v_perm_b32: low halves / high halves of two words)
     auto lo2 = [&](float w0, float w1) { return __builtin_amdgcn_perm(bits(w1), bits(w0), 0x05040100u); };
     auto hi2 = [&](float w0, float w1) { return __builtin_amdgcn_perm(bits(w1), bits(w0), 0x07060302u); };
-    if (q < PA) {
+    // B3: exact three-way bf16 split of the four k-values of a piece -> 8 bytes into each of the three planes
+    auto cvt2 = [](float lo, float hi) {  // v_cvt_pk_bf16_f32: two round-to-nearest-even bf16 in one dword
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+      return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
+    };
+    auto split3 = [&](const f32x4& v, uint32_t* dst, int plane) {
+      typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+      auto lo_f = [](uint32_t w) { return __builtin_bit_cast(float, w << 16); };
+      auto hi_f = [](uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); };
+#ifdef SM3_ABL_NOCVT  // ablation: the three 8-byte stores without the conversion arithmetic (wrong results, timing only)
+      *reinterpret_cast<u32x2*>(dst) = u32x2{__builtin_bit_cast(uint32_t, v[0]), __builtin_bit_cast(uint32_t, v[1])};
+      *reinterpret_cast<u32x2*>(dst + plane) = u32x2{__builtin_bit_cast(uint32_t, v[2]), __builtin_bit_cast(uint32_t, v[3])};
+      *reinterpret_cast<u32x2*>(dst + 2 * plane) = u32x2{__builtin_bit_cast(uint32_t, v[1]), __builtin_bit_cast(uint32_t, v[2])};
+      return;
+#endif
+      const uint32_t h0 = cvt2(v[0], v[1]), h1 = cvt2(v[2], v[3]);
+      *reinterpret_cast<u32x2*>(dst) = u32x2{h0, h1};
+      const float r0 = v[0] - lo_f(h0), r1 = v[1] - hi_f(h0), r2 = v[2] - lo_f(h1), r3 = v[3] - hi_f(h1);  // exact
+      const uint32_t m0 = cvt2(r0, r1), m1 = cvt2(r2, r3);
+      *reinterpret_cast<u32x2*>(dst + plane) = u32x2{m0, m1};
+      const float s0 = r0 - lo_f(m0), s1 = r1 - hi_f(m0), s2 = r2 - lo_f(m1), s3 = r3 - hi_f(m1);          // exact
+      *reinterpret_cast<u32x2*>(dst + 2 * plane) = u32x2{cvt2(s0, s1), cvt2(s2, s3)};
+    };
+    if (B3) {
+      if (q < PA) split3(ra[q], Aw + buf * A_STG + ha[q], A_ST16);
+      else split3(rb[q - PA], Bw + buf * B_STG + hb[q - PA], B_ST16);
+    } else if (q < PA) {
       if (F16 && A16 && A_TRANS) {
         typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-        *reinterpret_cast<u32x2*>(Aw + buf * A_ST16 + ha[q]) = u32x2{bits(ra[q][0]), bits(ra[q][1])};  // already halves
+        *reinterpret_cast<u32x2*>(Aw + buf * A_STG + ha[q]) = u32x2{bits(ra[q][0]), bits(ra[q][1])};  // already halves
       } else if (F16 && A16) {
         typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-        uint32_t* d = Aw + buf * A_ST16 + ha[q];
+        uint32_t* d = Aw + buf * A_STG + ha[q];
         *reinterpret_cast<u32x2*>(d) = u32x2{lo2(ra[q][0], ra[q][1]), lo2(ra[q][2], ra[q][3])};
         *reinterpret_cast<u32x2*>(d + 4) = u32x2{hi2(ra[q][0], ra[q][1]), hi2(ra[q][2], ra[q][3])};
       } else if (F16) {
         typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
         // every F16 piece is four consecutive k of one row / column -> 8 contiguous bytes
-        *reinterpret_cast<u32x2*>(Aw + buf * A_ST16 + ha[q]) = u32x2{pack2(ra[q][0], ra[q][1]), pack2(ra[q][2], ra[q][3])};
+        *reinterpret_cast<u32x2*>(Aw + buf * A_STG + ha[q]) = u32x2{pack2(ra[q][0], ra[q][1]), pack2(ra[q][2], ra[q][3])};
       } else {
         float* a_s = As + buf * A_STAGE;
         if (A_TRANS) {
@@ -756,15 +794,15 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
       const int i = q - PA;
       if (F16 && B16 && B_TRANS) {
         typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-        *reinterpret_cast<u32x2*>(Bw + buf * B_ST16 + hb[i]) = u32x2{bits(rb[i][0]), bits(rb[i][1])};  // already halves
+        *reinterpret_cast<u32x2*>(Bw + buf * B_STG + hb[i]) = u32x2{bits(rb[i][0]), bits(rb[i][1])};  // already halves
       } else if (F16 && B16) {
         typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-        uint32_t* d = Bw + buf * B_ST16 + hb[i];
+        uint32_t* d = Bw + buf * B_STG + hb[i];
         *reinterpret_cast<u32x2*>(d) = u32x2{lo2(rb[i][0], rb[i][1]), lo2(rb[i][2], rb[i][3])};
         *reinterpret_cast<u32x2*>(d + 4) = u32x2{hi2(rb[i][0], rb[i][1]), hi2(rb[i][2], rb[i][3])};
       } else if (F16) {
         typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-        *reinterpret_cast<u32x2*>(Bw + buf * B_ST16 + hb[i]) = u32x2{pack2(rb[i][0], rb[i][1]), pack2(rb[i][2], rb[i][3])};
+        *reinterpret_cast<u32x2*>(Bw + buf * B_STG + hb[i]) = u32x2{pack2(rb[i][0], rb[i][1]), pack2(rb[i][2], rb[i][3])};
       } else {
         float* b_s = Bs + buf * B_STAGE;
         if (B_TRANS) {
@@ -843,8 +881,8 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
     const int kt_load = tail ? min(kt + 2, nk - 1) : kt + 2;
     const bool live = tail ? kt + 1 < nk : true;
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    const uint32_t* a_w = Aw + buf * A_ST16 + (wm0 + l31) * 4;
-    const uint32_t* b_w = Bw + buf * B_ST16 + (wn0 + l31) * 4;
+    const uint32_t* a_w = Aw + buf * A_STG + (wm0 + l31) * 4;
+    const uint32_t* b_w = Bw + buf * B_STG + (wn0 + l31) * 4;
 #ifndef SM3_ABL_NOLOAD  // ablation builds (sm3det_amd/build.py VARIANTS): measurement aids, never the default library
 #pragma unroll
     for (int q = 0; q < NP; q++) load_piece(na, nb, q, kt_load, tail);
@@ -886,25 +924,121 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
     }
     __syncthreads();
   };
-  // ---- the item loop (one pass for a plain launch) -----------------------------------------------------------------
-  // persistent queue: q_head[0..7] = items handed out per XCD residue beyond the first grid.x, q_head[8] = workgroups that
-  // have left; all zero on entry, the last workgroup to leave zeroes them again (the kernel boundary publishes that).
-  __shared__ int s_next_item;
-  int* q_head = persist ? p.counters + kPersistQueueSlot : nullptr;
-  if (nk > 0) {  // first k-tile of the first item (later items: requested before the previous item's epilogue)
+  // B3 (bf16x3, see the LDS image above).  One body = the 16 k of one tile: the fragments of its three planes are read at
+  // the top (12 ds_read_b128 at 128x128), then six products a_s . b_t (s + t <= 2) of TI x TJ MFMAs each, a_1 . b_1 first
+  // (the smallest terms lead).  Tile t + 1 is written to the other stage -- split into its three bf16 planes: 22 VALU
+  // instructions and three 8-byte stores per piece, one piece per product slot, interleaved with that slot's MFMAs -- and the
+  // registers a piece came from are refilled at once with tile t + 3 (two bodies of prefetch on two register sets: a body
+  // is 768 matrix-pipe cycles, a third of the fp32 form's).  166 VGPRs at 128x128: three workgroups per CU.
+  // Measured alternatives, all within +-3 % of this form or worse (profiles/r05/gemm_b3_variants.txt): fragment reads one
+  // tile ahead with plane 0 double-buffered (207 VGPRs, two workgroups per CU), compiler-ordered body, no interleave hint.
+  // Phase ablations (profiles/r05/gemm_b3_ablations.txt): the conversion arithmetic is free beside the bf16 MFMAs; the
+  // family is latency-bound -- global loads 2.0 ms, LDS stores 1.8 ms, epilogues 1.2 ms, MFMAs 2.5 ms of 12.3 ms add up.
+  bf16x8 fa[3][TI], fb[3][TJ];
+  typedef uint32_t u32x4b __attribute__((ext_vector_type(4)));
+  auto rd_a = [&](int buf, int s, int dst) {
+    const uint32_t* a_w = Aw + buf * A_STG + s * A_ST16 + (lh * LDA16 + wm0 + l31) * 4;
+#pragma unroll
+    for (int i = 0; i < TI; i++) fa[dst][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4b*>(a_w + 32 * i * 4));
+  };
+  auto rd_b = [&](int buf, int s, int dst) {
+    const uint32_t* b_w = Bw + buf * B_STG + s * B_ST16 + (lh * LDB16 + wn0 + l31) * 4;
+#pragma unroll
+    for (int j = 0; j < TJ; j++) fb[dst][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4b*>(b_w + 32 * j * 4));
+  };
+  // operands swapped as in the fp32 form: D = (B fragment) x (A fragment) = the transposed 32x32 tile
+  auto prod = [&](int sa_, int sb_) {
+#ifdef SM3_ABL_NOMFMA
+#pragma unroll
+    for (int i = 0; i < TI; i++) asm volatile("" ::"v"(fa[sa_][i]));
+#pragma unroll
+    for (int j = 0; j < TJ; j++) asm volatile("" ::"v"(fb[sb_][j]));
+#else
+#pragma unroll
+    for (int i = 0; i < TI; i++)
+#pragma unroll
+      for (int j = 0; j < TJ; j++)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[sb_][j], fa[sa_][i], acc[i][j], 0, 0, 0);
+#endif
+  };
+  static_assert(!B3 || NP <= 4, "bf16x3 body: one piece per product slot, four slots");
+  auto b3_piece = [&](f32x4 (&ra)[PA], f32x4 (&rb)[PB], int q, int stage, bool live, int kt_load, bool tail) {
+    if (q >= NP) return;
+#ifndef SM3_ABL_NOSTORE
+    store_piece(ra, rb, q, stage, live);
+#endif
+#ifndef SM3_ABL_NOLOAD
+    load_piece(ra, rb, q, kt_load, tail);
+#endif
+  };
+  // interleave hint for one product slot: after each MFMA a share of the slot's vector-ALU work and one LDS operation
+  auto slot_mix = [&]() {
+#ifndef SM3_B3_NOMIX
+#pragma unroll
+    for (int m = 0; m < TI * TJ; m++) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                          // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, (22 + TI * TJ - 1) / (TI * TJ), 0);  // VALU
+      __builtin_amdgcn_sched_group_barrier(0x200, (3 + TI * TJ - 1) / (TI * TJ), 0);   // DS write
+    }
+    __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);  // the refill loads last
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto body_b3 = [&](f32x4 (&ra)[PA], f32x4 (&rb)[PB], int t, int par, bool tail) {
+    const int st = par, nx = par ^ 1;
+    const bool live = tail ? t + 1 < nk : true;
+    const int kt_load = tail ? min(t + 3, nk - 1) : t + 3;
+#pragma unroll
+    for (int s_ = 0; s_ < 3; s_++) {
+      rd_a(st, s_, s_);
+      rd_b(st, s_, s_);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    prod(1, 1);
+    b3_piece(ra, rb, 0, nx, live, kt_load, tail);
+    slot_mix();
+    prod(2, 0);
+    b3_piece(ra, rb, 1, nx, live, kt_load, tail);
+    slot_mix();
+    prod(0, 2);
+    b3_piece(ra, rb, 2, nx, live, kt_load, tail);
+    slot_mix();
+    prod(1, 0);
+    b3_piece(ra, rb, 3, nx, live, kt_load, tail);
+    slot_mix();
+    prod(0, 1);
+    prod(0, 0);
+    __syncthreads();
+  };
+  if (B3) {
+    // bf16x3 prologue: tiles 0 and 1 into the two register sets (tile 0 goes to stage 0 below, its set then takes tile 2)
+    if (nk > 0) {
+#pragma unroll
+      for (int q = 0; q < NP; q++) load_piece(sa0, sb0, q, 0, true);
+#pragma unroll
+      for (int q = 0; q < NP; q++) load_piece(sa1, sb1, q, min(1, nk - 1), true);
+    }
+  } else if (nk > 0) {  // first k-tile
 #pragma unroll
     for (int q = 0; q < NP; q++) load_piece(sa0, sb0, q, 0, true);
   }
-  for (;;) {
-    unsigned ticket = 0;
-    if (CAN_PERSIST && tid == 0)  // the NEXT item: in flight during this item's whole k-loop
-      ticket = __hip_atomic_fetch_add(q_head + (blockIdx.x & 7), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  {
 #pragma unroll
     for (int i = 0; i < TI; i++)
 #pragma unroll
       for (int j = 0; j < TJ; j++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    if (B3) {
+      // tile 0 -> stage 0; the register sets then hold tiles 1 (sa1: stored by body 0) and 2 (sa0: stored by body 1)
+      if (nk > 0) {
+#pragma unroll
+        for (int q = 0; q < NP; q++) store_piece(sa0, sb0, q, 0, true);
+#pragma unroll
+        for (int q = 0; q < NP; q++) load_piece(sa0, sb0, q, min(2, nk - 1), true);
+      }
+      __syncthreads();
+    } else {
     if (nk > 0) {
 #pragma unroll
       for (int q = 0; q < NP; q++) store_piece(sa0, sb0, q, 0, true);
@@ -912,10 +1046,11 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
       for (int q = 0; q < NP; q++) load_piece(sa0, sb0, q, min(1, nk - 1), true);
     }
     __syncthreads();
+    }
 #ifdef SM3_STAGGER  // measurement build only: the workgroups of the first dispatch round start their k-loops a third of a
     {                // tile-time apart per residency slot (tests whether co-resident workgroups run in lockstep)
       const unsigned lb = blockIdx.x + gridDim.x * blockIdx.z;
-      if (lb < 768u && item == (int)blockIdx.x && !persist) {
+      if (lb < 768u) {
         const long long wait = (long long)((lb >> 8) % 3u) * nk * (BK * TI * TJ * 32);  // cls x MFMA cycles of the tile alone
         const long long t_in = __builtin_amdgcn_s_memtime();
         while ((long long)__builtin_amdgcn_s_memtime() - t_in < wait) __builtin_amdgcn_s_sleep(32);
@@ -931,10 +1066,14 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
   // Two steps per iteration WITHOUT a branch between them (a conditional second step made hipcc drain vmcnt(0) at the
   // loop header).  The bulk loop carries no clamp / select / zeroing at all; the last three or four steps run the
   // `tail` variant, which also absorbs an odd nk by one extra step on an all-zero stage (see store_piece).
+  // (bf16x3: a bulk body loads tile t + 3 unclamped and stores tile t + 1 as live)
   const int nk_bulk = max(0, nk - 3) & ~1;
   int kt = 0;
   for (; kt < nk_bulk; kt += 2) {
-    if (F16) {
+    if (B3) {
+      body_b3(sa1, sb1, kt, 0, false);
+      body_b3(sa0, sb0, kt + 1, 1, false);
+    } else if (F16) {
       k_step16(sa0, sb0, sa1, sb1, kt, false);
       k_step16(sa1, sb1, sa0, sb0, kt + 1, false);
     } else {
@@ -943,7 +1082,10 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
     }
   }
   for (; kt < nk; kt += 2) {
-    if (F16) {
+    if (B3) {
+      body_b3(sa1, sb1, kt, 0, true);
+      body_b3(sa0, sb0, kt + 1, 1, true);
+    } else if (F16) {
       k_step16(sa0, sb0, sa1, sb1, kt, true);
       k_step16(sa1, sb1, sa0, sb0, kt + 1, true);
     } else {
@@ -958,7 +1100,9 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
 #pragma unroll
     for (int i = 0; i < PA; i++) {
       const int idx = tid + NTHREADS * i;
-      if (idx < (BK / 4) * BM) red[idx] = (csa[i][0] + csa[i][1]) + (csa[i][2] + csa[i][3]);
+      int g4, c;
+      unit_gc(idx, BM, g4, c);
+      if (idx < (BK / 4) * BM) red[g4 * BM + c] = (csa[i][0] + csa[i][1]) + (csa[i][2] + csa[i][3]);
     }
     __syncthreads();
     if (tid < BM && m0 + tid < p.M) {
@@ -999,26 +1143,7 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
     return;
   }
 #endif
-  // ---- next item: its tile set-up and the request for its first k-tile go out INSIDE this item's epilogue, right after
-  // the first 32x32 accumulator tile has been staged (its 16 registers are dead then and receive the loads, so the
-  // epilogue's peak register use does not grow); the loads land in sa0 / sb0 while the rest of the epilogue runs.  The LDS
-  // image itself is free only after the epilogue's staging.
   const int e_m0 = m0, e_n0 = n0, e_row_end = row_end, e_g = g, e_tile_m = tile_m, e_bid = bid, e_split = split;
-  bool has_next = false;
-  auto next_item = [&]() {
-    if (tid == 0) s_next_item = (int)gridDim.x + (int)(blockIdx.x & 7) + 8 * (int)ticket;  // same residue mod 8 (grid.x % 8 == 0)
-    __syncthreads();
-    const int nxt = s_next_item;
-    has_next = nxt < nitems;
-    if (has_next) {
-      item = nxt;
-      setup_item(item);
-      if (nk > 0) {
-#pragma unroll
-        for (int q = 0; q < NP; q++) load_piece(sa0, sb0, q, 0, true);
-      }
-    }
-  };
   // ---- split-K fix-up: publish this slice, the last arriver of the tile sums all slices in order ------------
   if (p.splits > 1 && p.fixup) {
     constexpr int NF = TI * TJ * 4;  // float4 fragments per thread
@@ -1093,12 +1218,7 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
   // back row-contiguous: one wave instruction then touches 8 rows x 128 contiguous bytes (full cache lines) of C and of
   // the auxiliary tensors.  LDS operations of one wave execute in order, so the write -> read hand-over needs no
   // barrier, only a compiler fence.
-  // (persistent form: the thread index goes through an opaque move first, otherwise hipcc hoists every constant of the
-  // epilogue -- staging addresses, row / column offsets -- out of the item loop and keeps them in registers through the
-  // k-loop, which is the kernel's register peak)
-  int tid_e = tid;
-  if (CAN_PERSIST) asm volatile("" : "+v"(tid_e));
-  const int lane_e = tid_e & 63, wave_e = tid_e >> 6;
+  const int lane_e = tid & 63, wave_e = tid >> 6;
   float* stg = smem + wave_e * (32 * 36);
   const int sr = lane_e >> 3, sc = (lane_e & 7) * 4;
   f32x4 cs[TJ];
@@ -1169,7 +1289,6 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
         *reinterpret_cast<f32x4*>(stg + l31 * 36 + 8 * q + 4 * lh) =
             f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
       asm volatile("" ::: "memory");
-      if (CAN_PERSIST && t == 0) next_item();
       if (AUX_IN && t + AUX_DEPTH < NT_) aux_fetch(t + AUX_DEPTH, pre[(t + AUX_DEPTH) % (AUX_DEPTH + 1)]);
       f32x4 v[4];
 #pragma unroll
@@ -1242,23 +1361,6 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
   sm3_first_pass = false;
   sm3_items++;
 #endif
-  if (!has_next) break;
-  __syncthreads();  // every wave is done with its staging patch: the next item's LDS image overlays it
-  }  // item loop
-#ifdef SM3_TRACE
-  if (CAN_PERSIST && p.trace && tid == 0) {  // persistent form: [4] = the workgroup's exit, [6] |= items walked << 32
-    unsigned long long* tr = p.trace + ((size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.z) * 8;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    tr[4] = __builtin_amdgcn_s_memtime();
-    tr[6] |= (unsigned long long)sm3_items << 32;
-  }
-#endif
-  if (CAN_PERSIST && tid == 0) {  // leave the queue zeroed for the next launch (last workgroup out)
-    const int d = __hip_atomic_fetch_add(q_head + 8, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (d == (int)gridDim.x - 1) {
-#pragma unroll
-      for (int w = 0; w < 9; w++) __hip_atomic_store(q_head + w, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
   }
 }
 
@@ -1278,13 +1380,11 @@ int launch_nt_h16(const GemmParams& p, int epi, int tile, int bk, int io, dim3 g
 int launch_nn_h16(const GemmParams& p, int epi, int tile, int bk, int io, dim3 grid, hipStream_t st);
 int launch_tn_h16(const GemmParams& p, int tile, int bk, int io, dim3 grid, hipStream_t st);
 
-// persistent instantiations (gemm_f32_p.hip, gemm_h16_p.hip): grid.x = resident workgroups, p.total_tiles = items
-bool has_persistent_f32(int tile, int bk);
-bool has_persistent_h16(int mode, int epi, int tile, int bk, int io);
-int launch_nt_p(const GemmParams& p, int epi, int tile, int bk, dim3 grid, hipStream_t st);
-int launch_nn_p(const GemmParams& p, int epi, int tile, int bk, dim3 grid, hipStream_t st);
-int launch_nt_h16_p(const GemmParams& p, int epi, int tile, int bk, int io, dim3 grid, hipStream_t st);
-int launch_nn_h16_p(const GemmParams& p, int epi, int tile, int bk, int io, dim3 grid, hipStream_t st);
+// bf16x3 form (gemm_b3_{nt,nn,tn}.hip): fp32 tensors, k-step 16, tiles 0 / 1 / 5 (NT, NN), 0 / 1 / 2 (TN)
+int launch_nt_b3(const GemmParams& p, int epi, int tile, dim3 grid, hipStream_t st);
+int launch_nn_b3(const GemmParams& p, int epi, int tile, dim3 grid, hipStream_t st);
+int launch_tn_b3(const GemmParams& p, int tile, dim3 grid, hipStream_t st);
+
 
 inline void tile_dims(int tile, int& bm, int& bn) {
   static const int d[6][2] = {{128, 128}, {128, 96}, {96, 128}, {128, 192}, {192, 128}, {64, 128}};

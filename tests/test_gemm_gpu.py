@@ -12,6 +12,16 @@ def _mods():
     return LB
 
 
+@pytest.fixture(autouse=True, params=['bf16x3', 'f32'])
+def _arith(request):
+    """every test of this module runs in both arithmetics of the fp32 GEMM family: the bf16x3 form (three exact bf16 pieces
+    per operand element, six v_mfma_f32_32x32x16_bf16 products, the default) and the native v_mfma_f32_32x32x2_f32 form"""
+    LB = _mods()
+    old, LB.ARITH32 = LB.ARITH32, {'bf16x3': 2, 'f32': 0}[request.param]
+    yield request.param
+    LB.ARITH32 = old
+
+
 def _rand(*shape, seed=0):
     g = torch.Generator(device='cpu').manual_seed(seed)
     return torch.randn(*shape, generator=g).cuda()
@@ -372,3 +382,68 @@ def test_tn_column_sums_of_a_as_a_by_product(E, counts, M, N, splits):
     refb = torch.stack([A[bounds[e]:bounds[e + 1]].double().sum(0) for e in range(E)])
     _close(dW, refw)
     assert (db.double() - refb).abs().max().item() <= 1e-4 * (refb.abs().max().item() + 1e-12) + 1e-6
+
+
+# ------------------------------------------------------------------------------------------ bf16x3 vs native fp32 MFMA
+_STEP_SHAPES = [  # (mode, M, N, K): the contraction shapes of the training step (rows capped: the error does not depend on M)
+    ('nt', 8192, 384, 96), ('nt', 8192, 96, 384), ('nn', 8192, 384, 96), ('nn', 8192, 96, 384),
+    ('tn', 384, 96, 131072), ('tn', 96, 384, 131072),
+    ('nt', 8192, 768, 192), ('nt', 8192, 192, 768), ('nn', 8192, 768, 192), ('nn', 8192, 192, 768),
+    ('tn', 768, 192, 32768), ('tn', 192, 768, 32768),
+    ('nt', 8192, 1536, 384), ('nt', 8192, 384, 1536), ('nn', 8192, 1536, 384), ('nn', 8192, 384, 1536),
+    ('tn', 1536, 384, 8192), ('tn', 384, 1536, 8192),
+    ('nt', 2048, 3072, 768), ('nt', 2048, 768, 3072), ('nn', 2048, 3072, 768), ('nn', 2048, 768, 3072),
+    ('tn', 3072, 768, 2048), ('tn', 768, 3072, 2048),
+    ('nt', 8192, 224, 384), ('nn', 8192, 384, 224), ('tn', 224, 384, 8192), ('nt', 8192, 128, 192), ('nt', 2048, 288, 768)]
+
+
+@pytest.mark.parametrize('mode,M,N,K', _STEP_SHAPES)
+def test_bf16x3_error_is_that_of_the_native_fp32_form(mode, M, N, K, _arith):
+    """Guardrail of the bf16x3 form: on every contraction shape of the training step its error against the fp64 product of
+    the SAME fp32 operands (max-norm and rms) is at most 1.5 x the native fp32 MFMA kernel's -- i.e. it is an fp32
+    evaluation, not a reduced-precision one (24 operand bits are kept: three bf16 pieces sum to the fp32 value exactly)."""
+    if _arith != 'bf16x3':
+        pytest.skip('comparison test: runs once')
+    LB = _mods()
+    md = dict(nt=LB.NT, nn=LB.NN, tn=LB.TN)[mode]
+    if mode == 'nt':
+        A, B = _rand(M, K, seed=11), _rand(N, K, seed=12) * 0.05
+        ref = A.double() @ B.double().t()
+    elif mode == 'nn':
+        A, B = _rand(M, K, seed=13), _rand(K, N, seed=14) * 0.05
+        ref = A.double() @ B.double()
+    else:
+        A, B = _rand(K, M, seed=15), _rand(K, N, seed=16)
+        ref = A.double().t() @ B.double()
+    err = {}
+    for name, ar in (('f32', 0), ('bf16x3', 2)):
+        LB.ARITH32 = ar
+        C = torch.full((M, N), float('nan'), device='cuda')
+        LB.gemm(md, A, B, C, M, N, K)
+        d = C.double() - ref
+        err[name] = (d.abs().max().item(), d.pow(2).mean().sqrt().item())
+    LB.ARITH32 = 2
+    assert err['bf16x3'][0] <= 1.5 * err['f32'][0], err
+    assert err['bf16x3'][1] <= 1.5 * err['f32'][1], err
+
+
+def test_single_term_products_carry_all_24_operand_bits():
+    """One non-zero k per row: C[i][j] = a_i * b_j.  Both arithmetics must return the fp32 product to within two ulp
+    (|err| <= 2^-22 |ab|: the six-product form measured 1.03 ulp, the native form half an ulp); one bf16 piece would give 2^-8, two pieces 2^-16.  Operands with fully populated mantissas."""
+    LB = _mods()
+    old = LB.ARITH32
+    try:
+        K = 32
+        A = torch.zeros(256, K, device='cuda')
+        B = torch.zeros(128, K, device='cuda')
+        A[:, 5] = _rand(256, seed=41) * 3.0
+        B[:, 5] = _rand(128, seed=42) * 0.01
+        ref = A[:, 5].double()[:, None] * B[:, 5].double()[None, :]
+        for ar in (0, 2):
+            LB.ARITH32 = ar
+            C = torch.full((256, 128), float('nan'), device='cuda')
+            LB.gemm(LB.NT, A, B, C, 256, 128, K)
+            rel = ((C.double() - ref).abs() / ref.abs().clamp_min(1e-30)).max().item()
+            assert rel <= 2.0 ** -22, (ar, rel)
+    finally:
+        LB.ARITH32 = old
