@@ -454,3 +454,39 @@ def load_sampler():
             else:
                 sys.modules[k] = v
     return mod.RRandomSampler
+
+
+_NMS_FILE = ('mmrotate', 'core', 'post_processing', 'bbox_nms_rotated.py')
+
+
+def load_test_path(assigner_factory=None, sampler_factory=None):
+    """-> dict(roi_head=<the reference's OrientedStandardRoIHead class, TEST-TIME path live>, multiclass_nms_rotated=<the
+    reference's own function>, rbbox2result=<the reference's own>).  ``bbox_nms_rotated.py`` is imported unmodified with
+    ``mmcv.ops.nms_rotated`` = the reference's python wrapper over the reference's CPU C++ (oracle/_ref); the module globals
+    the import shims had stubbed -- ``rotated_bbox_head.multiclass_nms_rotated``, ``rotate_standard_roi_head.rbbox2result``
+    -- are pointed at the live functions, so ``RotatedBBoxHead.get_bboxes`` (rotated_bbox_head.py:358-430),
+    ``simple_test_bboxes`` (oriented_standard_roi_head.py:126-188) and ``simple_test`` (rotate_standard_roi_head.py:235-262)
+    run as the reference wrote them."""
+    live = load_inference()
+    Head = load_roi_head(assigner_factory or (lambda cfg: None), sampler_factory or (lambda cfg, context=None: None))
+    T, _, _ = ref_rpn.load()
+    name = f'{_PKG}_post.bbox_nms_rotated'
+    if name not in sys.modules:
+        shims = {'mmcv': _mod('mmcv'), 'mmcv.ops': _mod('mmcv.ops', nms_rotated=live['ops']['nms'].nms_rotated)}
+        saved = {k: sys.modules.get(k) for k in shims}
+        sys.modules.update(shims)
+        try:
+            spec = importlib.util.spec_from_file_location(name, os.path.join(REF_ROOT, *_NMS_FILE))
+            mod = importlib.util.module_from_spec(spec)
+            sys.modules[name] = mod
+            spec.loader.exec_module(mod)
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    sys.modules.pop(k, None)
+                else:
+                    sys.modules[k] = v
+    nms_mod = sys.modules[name]
+    sys.modules[f'{_PKG}.roi_heads.bbox_heads.rotated_bbox_head'].multiclass_nms_rotated = nms_mod.multiclass_nms_rotated
+    sys.modules[f'{_PKG}.roi_heads.rotate_standard_roi_head'].rbbox2result = T.rbbox2result
+    return dict(roi_head=Head, multiclass_nms_rotated=nms_mod.multiclass_nms_rotated, rbbox2result=T.rbbox2result)

@@ -39,6 +39,7 @@ PY
     fullsize)     timeout 1500 python -m pytest tests/test_fullsize_gpu.py -x -q 2>&1 | tail -15 | tee $O/fullsize_tests.txt ;;
     backbone)     timeout 900 python -m pytest tests/test_backbone_gpu.py tests/test_amp_gpu.py tests/test_graph_replay_gpu.py -x -q 2>&1 | tail -8 | tee $O/backbone_tests.txt ;;
     alltests)     timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee $O/alltests.txt ;;
+    heads)        timeout 900 python -m pytest tests/test_roi_head_gpu.py tests/test_detector_gpu.py tests/test_rpn_gpu.py -x -q 2>&1 | tail -12 | tee $O/heads_tests.txt ;;
     smoke)        timeout 600 python __graft_entry__.py --smoke 2>&1 | tail -3 ;;
     *) echo "unknown step $step" ;;
   esac

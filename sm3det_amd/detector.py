@@ -234,21 +234,20 @@ class TriSourceDetector(nn.Module):
 
     @torch.no_grad()
     def simple_test(self, img, img_metas, subdataset, proposals=None, rescale=False):
-        """:371-400.  The SAR branch returns [(dets (n, 5), labels (n,))] per image; the two-stage branches return the
-        proposal list of the RPN (the RoI head's `simple_test` -- multiclass rotated NMS on the refined boxes -- is mmdet /
-        mmrotate test-time code outside SURVEY section 8)."""
+        """:371-400.  Every branch returns the reference's result type: per image a list over the classes of float32
+        arrays -- (k, 5) horizontal detections for the SAR branch (``bbox2result`` of ``GFLHead.simple_test``), (k, 6)
+        rotated detections (cx, cy, w, h, a, score) for the RGB / IR branches (``OrientedStandardRoIHead.simple_test``:
+        RPN proposals -> RoI extractor + Shared2FC -> decode + rescale -> multiclass rotated NMS)."""
+        from .post_processing import bbox2result
         assert isinstance(subdataset[0], list) and len(subdataset) == 1
         assert all(s == subdataset[0][0] for s in subdataset[0]), f'Not all elements in subdataset are the same: {subdataset}'
         sub = subdataset[0][0]
         x, _ = self.extract_feat(img, [sub])
         if sub == 'sar':
-            return self.sar_bbox_head.simple_test(x, img_metas, rescale=rescale)
+            results = self.sar_bbox_head.simple_test(x, img_metas, rescale=rescale)
+            return [bbox2result(d, l, self.sar_bbox_head.num_classes) for d, l in results]
         if sub in ('rgb', 'ifr'):
-            rpn = getattr(self, f'{sub}_rpn_head')
             if proposals is None:
-                proposals = rpn.get_bboxes(*rpn(x), img_metas=img_metas, cfg=(getattr(self, f'{sub}_test_cfg') or {}).get('rpn'))
-            roi = getattr(self, f'{sub}_roi_head')
-            if hasattr(roi, 'simple_test'):
-                return roi.simple_test(x, proposals, img_metas, rescale=rescale)
-            return proposals
+                proposals = getattr(self, f'{sub}_rpn_head').simple_test_rpn(x, img_metas)
+            return getattr(self, f'{sub}_roi_head').simple_test(x, proposals, img_metas, rescale=rescale)
         raise AssertionError('Invalid dataset')

@@ -202,6 +202,29 @@ class RotatedShared2FCBBoxHead(nn.Module):
             raise NotImplementedError('reg_class_agnostic=False is not used by any SM3Det config')
         return float(lc.get('loss_weight', 1.0)), float(lb.get('loss_weight', 1.0)), float(lb.get('beta', 1.0))
 
+    @torch.no_grad()
+    def get_bboxes(self, rois, cls_score, bbox_pred, img_shape, scale_factor, rescale=False, cfg=None):
+        """rotated_bbox_head.py:358-430: softmax scores, ``DeltaXYWHAOBBoxCoder.decode`` of the deltas on the RoIs (clipped
+        to ``img_shape``), optional division of (cx, cy, w, h) by ``scale_factor``, then -- with a test cfg -- multiclass
+        rotated NMS -> (dets (k, 6), labels (k,)); without one the raw (boxes, scores)."""
+        from .post_processing import multiclass_nms_rotated
+        scores = torch.softmax(cls_score, dim=-1) if cls_score is not None else None
+        if bbox_pred is not None:
+            bboxes = self._coder().decode(rois[..., 1:], bbox_pred, max_shape=img_shape)
+        else:
+            bboxes = rois[:, 1:].clone()
+            if img_shape is not None:  # (the reference clamps a temporary here, i.e. does nothing; kept as is)
+                pass
+        if rescale and bboxes.size(0) > 0:
+            sf = bboxes.new_tensor(scale_factor)
+            bboxes = bboxes.view(bboxes.size(0), -1, 5)
+            bboxes[..., :4] = bboxes[..., :4] / sf
+            bboxes = bboxes.view(bboxes.size(0), -1)
+        if cfg is None:
+            return bboxes, scores
+        return multiclass_nms_rotated(bboxes, scores, _cfg_get(cfg, 'score_thr'), _cfg_get(cfg, 'nms'),
+                                      _cfg_get(cfg, 'max_per_img'))
+
     def get_targets(self, sampling_results, gt_bboxes, gt_labels, rcnn_train_cfg, concat=True):
         """rotated_bbox_head.py:209-273 (+ _get_target_single :141-207): per image labels / label_weights / bbox_targets /
         bbox_weights of [positives | negatives]; targets through the DeltaXYWHAOBBoxCoder encode kernel."""
@@ -248,6 +271,12 @@ class RotatedShared2FCBBoxHead(nn.Module):
         return dict(loss_cls=l_cls, acc=acc, loss_bbox=l_box)
 
 
+def _cfg_get(cfg, key, default=None):
+    if cfg is None:
+        return default
+    return cfg.get(key, default) if isinstance(cfg, dict) else getattr(cfg, key, default)
+
+
 @_REG.register_module()
 class OrientedStandardRoIHead(nn.Module):
     """``mmrotate/models/roi_heads/oriented_standard_roi_head.py`` (on ``rotate_standard_roi_head.py:13-78``): RoI
@@ -285,6 +314,31 @@ class OrientedStandardRoIHead(nn.Module):
         feats = self.bbox_roi_extractor(x[:self.bbox_roi_extractor.num_inputs], rois)
         cls_score, bbox_pred = self.bbox_head(feats)
         return dict(cls_score=cls_score, bbox_pred=bbox_pred, bbox_feats=feats)
+
+    @torch.no_grad()
+    def simple_test_bboxes(self, x, img_metas, proposals, rcnn_test_cfg, rescale=False):
+        """oriented_standard_roi_head.py:126-188: ONE extractor + head pass over the proposals of all images, then the box
+        head's ``get_bboxes`` image by image -> (list of (k_i, 6) detections, list of (k_i,) labels)"""
+        from .rpn_head import rbbox2roi
+        rois = rbbox2roi(proposals)
+        res = self._bbox_forward(x, rois)
+        counts = [int(p.shape[0]) for p in proposals]
+        rois_l, cls_l, reg_l = rois.split(counts, 0), res['cls_score'].split(counts, 0), res['bbox_pred'].split(counts, 0)
+        det_bboxes, det_labels = [], []
+        for i in range(len(proposals)):
+            d, l = self.bbox_head.get_bboxes(rois_l[i], cls_l[i], reg_l[i], img_metas[i].get('img_shape'),
+                                             img_metas[i].get('scale_factor'), rescale=rescale, cfg=rcnn_test_cfg)
+            det_bboxes.append(d)
+            det_labels.append(l)
+        return det_bboxes, det_labels
+
+    @torch.no_grad()
+    def simple_test(self, x, proposal_list, img_metas, rescale=False):
+        """rotate_standard_roi_head.py:235-262: per image a list over the classes of (k, 6) float32 arrays"""
+        from .post_processing import rbbox2result
+        assert self.with_bbox, 'Bbox head must be implemented.'
+        det_bboxes, det_labels = self.simple_test_bboxes(x, img_metas, proposal_list, self.test_cfg, rescale=rescale)
+        return [rbbox2result(det_bboxes[i], det_labels[i], self.bbox_head.num_classes) for i in range(len(det_bboxes))]
 
     def sample_fixed(self, proposals, counts, gt_bboxes, gt_labels, generator=None):
         """Assign + sample every image on the device.  proposals (B, P, 5+), counts (B,) or None -> dict of fixed-size

@@ -489,6 +489,11 @@ class OrientedRPNHead(nn.Module):
                 props = self.get_bboxes(cls_scores, bbox_preds, img_metas, proposal_cfg)
         return losses, props
 
+    @torch.no_grad()
+    def simple_test_rpn(self, x, img_metas):
+        """mmdet RPNTestMixin.simple_test_rpn: the head's outputs -> proposals under ``self.test_cfg``"""
+        return self.get_bboxes(*self(x), img_metas=img_metas)
+
     def get_bboxes(self, cls_scores, bbox_preds, img_metas=None, cfg=None, rescale=False, mlvl_anchors=None):
         """per-image proposals (list of (n,6) tensors) from the multi-level head outputs"""
         num_imgs = cls_scores[0].shape[0]

@@ -101,5 +101,18 @@ def test_detector_skips_the_branch_of_an_absent_source_and_sar_inference_runs():
     assert not any(k.startswith('ifr_') for k in losses) and 'rgb_loss_cls' in losses and 'sar_loss_dfl' in losses
     det.eval()
     x = torch.randn(1, 3, 256, 256, device='cuda')
-    res = det.simple_test(x, [dict(img_shape=(256, 256, 3), scale_factor=1.0)], [['sar']])
-    assert len(res) == 1 and res[0][0].shape[1] == 5 and res[0][0].shape[0] == res[0][1].shape[0] <= 100
+    import numpy as np
+    meta = [dict(img_shape=(256, 256, 3), scale_factor=np.ones(4, np.float32))]
+    # the reference's result type (trisource_H1stage_R2stage_detector.py:371-400): per image a list over the classes
+    res = det.simple_test(x, meta, [['sar']])
+    assert len(res) == 1 and len(res[0]) == det.sar_bbox_head.num_classes
+    assert all(isinstance(a, np.ndarray) and a.ndim == 2 and a.shape[1] == 5 for a in res[0])
+    assert sum(a.shape[0] for a in res[0]) <= 100
+    for sub in ('rgb', 'ifr'):  # two-stage branches: RPN proposals -> RoI head -> multiclass rotated NMS
+        res = det.simple_test(x, meta, [[sub]], rescale=True)
+        roi = getattr(det, f'{sub}_roi_head')
+        assert len(res) == 1 and len(res[0]) == roi.bbox_head.num_classes
+        assert all(isinstance(a, np.ndarray) and a.dtype == np.float32 and a.ndim == 2 and a.shape[1] == 6 for a in res[0])
+        assert sum(a.shape[0] for a in res[0]) <= 2000
+        dets = np.concatenate(res[0])
+        assert np.isfinite(dets).all() and (dets[:, 5] > 0.05).all()

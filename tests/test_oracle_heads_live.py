@@ -271,3 +271,88 @@ def test_sampler_counts_vs_live_reference_sampler(num, frac, ub, add_gt):
         assert sel_pos.unique().numel() == sel_pos.numel() and sel_neg.unique().numel() == sel_neg.numel()
         assert bool(valid[:int(n_pos) + int(n_neg)].all()) and not bool(valid[int(n_pos) + int(n_neg):].any())
         assert bool(is_pos[:int(n_pos)].all())  # positives first
+
+
+# ------------------------------------------------------------------------------------------------ test-time path (g2)
+def _test_path():
+    try:
+        return RH.load_test_path()
+    except (FileNotFoundError, ImportError, OSError) as e:
+        pytest.skip(f'live reference heads unavailable: {e}')
+
+
+@pytest.mark.parametrize('n,nc,seed', [(400, 5, 0), (1500, 26, 1), (60, 3, 2)])
+def test_multiclass_nms_rotated_vs_live_reference(n, nc, seed):
+    """`multiclass_nms_rotated` of the reference (bbox_nms_rotated.py:6-96) over the reference's compiled `nms_rotated`,
+    against oracle/roi_oracle.py: detections, labels and the kept candidate indices identical (incl. score filter,
+    class offsets, top max_num, and the nothing-passes case)."""
+    live = _test_path()
+    g = torch.Generator().manual_seed(seed)
+    boxes = torch.from_numpy(synth.rotated_boxes(n, seed, cluster=True))
+    scores = torch.softmax(torch.randn(n, nc + 1, generator=g) * 2.0, -1)
+    for thr, max_num in ((0.05, 2000), (0.2, 37), (0.999, 100)):
+        d_ref, l_ref, k_ref = live['multiclass_nms_rotated'](boxes, scores, thr, _Cfg(iou_thr=0.1), max_num, return_inds=True)
+        d, l, k = roi_oracle.multiclass_nms_rotated(boxes.numpy(), scores.numpy(), thr, 0.1, max_num)
+        assert np.array_equal(d_ref.numpy(), d) and np.array_equal(l_ref.numpy(), l)
+        if d.shape[0]:
+            assert np.array_equal(k_ref.numpy(), k)
+    assert d.shape[0] == 0  # the last threshold filters everything: the empty branch (:61-66)
+
+
+@pytest.mark.parametrize('rescale', [False, True])
+def test_roi_head_simple_test_vs_live_reference(rescale):
+    """`OrientedStandardRoIHead.simple_test` of the reference run live -- `simple_test_bboxes`
+    (oriented_standard_roi_head.py:126-188), `RotatedBBoxHead.get_bboxes` (rotated_bbox_head.py:358-430: softmax, the
+    reference's `DeltaXYWHAOBBoxCoder.decode`, rescale, `multiclass_nms_rotated`), `rbbox2result` -- against the
+    composition oracle/roi_oracle.py::simple_test the GPU test of the product head uses: per image and class the same
+    number of detections, boxes and scores equal."""
+    live = _test_path()
+    C, strides = 6, [4, 8, 16, 32]
+    means, stds = (0.,) * 5, (0.1, 0.1, 0.2, 0.2, 0.1)
+    cfg = _Cfg(nms_pre=2000, min_bbox_size=0, score_thr=0.05, nms=_Cfg(iou_thr=0.1), max_per_img=2000)
+    torch.manual_seed(7)
+    head = live['roi_head'](
+        bbox_roi_extractor=dict(type='RotatedSingleRoIExtractor',
+                                roi_layer=dict(type='RoIAlignRotated', out_size=7, sample_num=2, clockwise=True),
+                                out_channels=8, featmap_strides=strides),
+        bbox_head=dict(type='RotatedShared2FCBBoxHead', in_channels=8, fc_out_channels=32, roi_feat_size=7,
+                       num_classes=C, reg_class_agnostic=True,
+                       bbox_coder=dict(type='DeltaXYWHAOBBoxCoder', angle_range='le90', norm_factor=None, edge_swap=True,
+                                       proj_xy=True, target_means=means, target_stds=stds),
+                       loss_cls=dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0),
+                       loss_bbox=dict(type='SmoothL1Loss', beta=1.0, loss_weight=1.0)),
+        test_cfg=cfg, version='le90')
+    with torch.no_grad():  # spread the class scores so that several classes pass the score threshold
+        head.bbox_head.fc_cls.weight.mul_(8.0)
+        head.bbox_head.fc_reg.weight.mul_(10.0)
+    g = torch.Generator().manual_seed(3)
+    feats = [torch.randn(2, 8, 64 >> i, 64 >> i, generator=g) for i in range(4)]
+    props = []
+    for i in range(2):  # proposals inside the image, overlapping in clusters, sizes over all four pyramid levels
+        ctr = torch.rand(30, 2, generator=g) * 200 + 28
+        c = ctr[torch.randint(0, 30, (150,), generator=g)] + torch.randn(150, 2, generator=g) * 6
+        w = torch.exp(torch.rand(150, generator=g) * 3.0 + 2.2)
+        props.append(torch.stack([c[:, 0], c[:, 1], w, w * (0.3 + 0.6 * torch.rand(150, generator=g)),
+                                  (torch.rand(150, generator=g) - 0.5) * 3.0, torch.rand(150, generator=g)], 1))
+    metas = [dict(img_shape=(256, 256, 3), scale_factor=np.array([1.25, 1.25, 1.25, 1.25], np.float32)) for _ in range(2)]
+    with torch.no_grad():
+        ref = head.simple_test(feats, props, metas, rescale=rescale)
+        raw = head.simple_test_bboxes(feats, metas, props, None)[1]
+    # distinct scores: with ties the kept set would depend on the (unspecified) tie order of the sort inside NMS
+    for sc in raw:
+        v = sc[:, :-1].reshape(-1)
+        v = v[v > 0.05]
+        assert torch.unique(v).numel() == v.numel()
+    params = {k: v.detach() for k, v in head.bbox_head.state_dict().items()}
+    got = roi_oracle.simple_test(feats, props, metas, params, strides, C, cfg, means, stds,
+                                 dict(edge_swap=True, proj_xy=True), rescale=rescale)
+    assert len(ref) == len(got) == 2
+    total = 0
+    for r_img, g_img in zip(ref, got):
+        assert len(r_img) == len(g_img) == C
+        for r, q in zip(r_img, g_img):
+            assert r.shape == q.shape and r.dtype == np.float32
+            np.testing.assert_allclose(r, q, rtol=1e-6, atol=1e-6)
+            total += r.shape[0]
+    assert total > 20  # a real test: detections exist, in more than one class
+    assert sum(1 for r in ref[0] if r.shape[0]) >= 2
