@@ -189,7 +189,7 @@ typedef struct sm3_gemm_desc {
                         fix-up (TN slices are then reduced by a second pass, NT/NN never slice K) */
   int32_t tuning;    /* 0 in production.  Benchmarking override: bits 0-3 tile+1 (0 128x128, 1 128x96, 2 96x128,
                         3 128x192, 4 192x128, 5 64x128), bits 4-7 k-step (1 = 16, 2 = 32), bits 8-15 slices,
-                        bit 16 TN: slices summed by the in-kernel fix-up instead of the second pass */
+                        bit 16 TN: slices summed by the in-kernel fix-up instead of the second pass, bits 20-23: slices / 256 */
   int32_t compute;   /* 0: fp32 operands (v_mfma_f32_32x32x2_f32, exact).  1: operands rounded to fp16 on the fly, fp32
                         accumulation (v_mfma_f32_32x32x16_f16) -- the arithmetic autocast gives nn.Linear in the reference's
                         AMP configs (fp16 = dict(loss_scale='dynamic')).  2: fp32 tensors, fp32-equivalent arithmetic on the

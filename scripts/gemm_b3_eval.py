@@ -113,10 +113,18 @@ def main():
         alts = []
         if sweep:
             for t in ((0, 1, 2) if mode == 'tn' else (0, 1, 5)):
-                try:
-                    alts.append((timed(2, t + 1), t))
-                except Exception as ex:  # noqa: BLE001
-                    alts.append((float('inf'), t))
+                sl = [0]
+                if '--splits' in sys.argv:
+                    sl = [1, 2, 3, 4, 6, 8] if mode != 'tn' else [8, 16, 24, 32, 48, 64, 96, 128, 192, 256, 384, 512, 768]
+                for sp in sl:
+                    if mode == 'tn' and sp and (K // G) // sp < 64:
+                        continue
+                    try:
+                        alts.append((timed(2, (t + 1) | ((sp & 255) << 8) | ((sp >> 8) << 20)), f'{t}s{sp}' if sp else str(t)))
+                    except Exception as ex:  # noqa: BLE001
+                        alts.append((float('inf'), f'{t}s{sp}'))
+            if '--splits' in sys.argv:
+                alts = sorted(alts)[:6]
         tbest = min([tb3] + [a[0] for a in alts])
         tot['f32'] += cnt * t32
         tot['b3'] += cnt * tb3

@@ -19,6 +19,9 @@ for step in "$@"; do
         SM3DET_HIP_LIB=sm3det_amd/csrc/libsm3det_hip_$v.so timeout 300 python scripts/gemm_b3_eval.py --no-sweep > $O/gemm_b3_$v.txt 2>&1
         echo "$v: $(tail -2 $O/gemm_b3_$v.txt | head -1)"; done ;;
     b3_eval_quick) timeout 600 python scripts/gemm_b3_eval.py --no-sweep > $O/gemm_b3_eval_quick.txt 2>&1; tail -2 $O/gemm_b3_eval_quick.txt ;;
+    b3_trace)     SM3DET_HIP_LIB=sm3det_amd/csrc/libsm3det_hip_trace.so timeout 600 python scripts/gemm_trace.py $O/gemm_trace_b3.npz > $O/gemm_trace_b3.log 2>&1
+                  timeout 300 python scripts/gemm_trace_analyse.py $O/gemm_trace_b3.npz > $O/gemm_trace_b3.txt 2>&1; tail -60 $O/gemm_trace_b3.txt ;;
+    b3_sweep)     timeout 1500 python scripts/gemm_b3_eval.py --splits > $O/gemm_b3_sweep.txt 2>$O/gemm_b3_sweep.err; tail -3 $O/gemm_b3_sweep.txt; tail -3 $O/gemm_b3_sweep.err ;;
     bench_quick)  timeout 900 python bench.py --no-ops --no-cpu-baseline > $O/bench_quick.json 2>$O/bench_quick.err; python - <<'PY'
 import json
 r = json.loads([l for l in open('gpurun_out/r05/bench_quick.json') if l.startswith('{')][-1])

@@ -242,7 +242,8 @@ Cfg choose_cfg(const sm3_gemm_desc* d) {
   memset(&c, 0, sizeof(c));
   c.groups = d->num_groups > 0 ? d->num_groups : 1;
   const unsigned tune = (unsigned)d->tuning;
-  const int t_tile = (int)(tune & 15) - 1, t_bk = (int)((tune >> 4) & 15), t_splits = (int)((tune >> 8) & 255);
+  const int t_tile = (int)(tune & 15) - 1, t_bk = (int)((tune >> 4) & 15),
+            t_splits = (int)((tune >> 8) & 255) | (int)(((tune >> 20) & 15) << 8);  // bits 20-23: slices / 256
   const bool have_counters = d->counters != nullptr;
   const int G = c.groups;
   if (d->mode != MODE_TN) {
@@ -316,7 +317,9 @@ Cfg choose_cfg(const sm3_gemm_desc* d) {
   static const double handicap32[3] = {1.0, 0.97, 0.97}, handicap16[3] = {1.0, 1.1, 1.1};  // fp16: see above
   const double* handicap = d->compute == 1 ? handicap16 : handicap32;
   const int rows = d->K / G > 0 ? d->K / G : 1;
-  const double pen = d->K > 0 ? 60.0 * G / d->K : 0.0;
+  // bf16x3: a k-loop is a third as long, the launch is latency-bound and more, shorter slices win on the long reductions
+  // (stage-0 / stage-1 weight gradients: 256 slices 78 us vs 89 us at the fp32 form's 85; profiles/r05/gemm_b3_sweep.txt)
+  const double pen = d->K > 0 ? (d->compute == 2 ? 40.0 : 60.0) * G / d->K : 0.0;
   double best = 0;
   int best_s = 1;
   c.tile = -1;
@@ -329,7 +332,7 @@ Cfg choose_cfg(const sm3_gemm_desc* d) {
     for (int s = 1; s <= 512; s++) {
       if (s > 1 && rows / s < 64) break;
       if (d->splits > 0 && s != d->splits) continue;
-      if (d->splits <= 0 && s > 192) break;  // beyond ~200 slices the second pass and the short k-loops cost more than
+      if (d->splits <= 0 && s > (d->compute == 2 ? 256 : 192)) break;  // beyond ~200 slices the second pass and the short k-loops cost more than
                                              // the extra workgroups bring (stage-0 weight gradients: 128-192 best)
       const long blocks = tiles * s;
       const double cost = quant_cost(blocks) * handicap[i] * waste + pen * (s > 1 ? s : 0);
