@@ -569,6 +569,20 @@ int sm3_adamw_multi(const uint64_t* p_ptrs, const uint64_t* g_ptrs, const uint64
                     float* grad_norm, float* partials, float* scaler, float growth_factor, float backoff_factor,
                     int growth_interval, sm3_stream_t stream);
 
+/* DynamicLrUpdaterHook (mmrotate/core/hook/dynamic_lr.py:107-217; local_configs/main_SM3Det.py:291-300 `policy='dynamic'`)
+ * on the device: losses[n] = this iteration's loss scalars (the keys of `reweight_losses` present in the step, in log_vars
+ * order), loss_subnet[n] = index of the sub-network each belongs to, param_subnet[n_params] = sub-network of every optimizer
+ * tensor or -1 for shared (backbone / neck) tensors, base_lr[n_params] = the groups' initial lr, sched[1] = the step-decay
+ * factor gamma^exp of get_lr.  state = n + 2 doubles, zero before the first call: loss EMAs, number of EMA updates,
+ * iteration index (all advanced here).  Writes lr[n_params] -- the vector sm3_adamw_multi reads -- without any host read:
+ * warm-up iterations (< warmup_iters) get the linear warm-up factor, later ones base_lr * sched * (sub-network weight |
+ * backbone-policy weight).  head_policy 0 normal / 1 reverse / 2 'None'; backbone_policy 0 min / 1 avg / 2 max / 3 kl /
+ * 4 sigmoid_kl / 5 none.  n <= 32, n_subnets <= 63. */
+int sm3_dla_lr(const float* losses, int n, const int32_t* loss_subnet, int n_subnets, const int32_t* param_subnet,
+               const float* base_lr, int n_params, const float* sched, double* state, int head_policy,
+               int backbone_policy, int warmup_iters, float warmup_ratio, float T, float b, float ema_beta, float* lr,
+               sm3_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,9 +12,22 @@ REF_FILE = os.path.join(REF_ROOT, 'mmrotate', 'core', 'hook', 'dynamic_lr.py')
 
 
 class _LrUpdaterHook:
+    """what the dynamic hook uses of mmcv's LrUpdaterHook: the constructor fields, ``get_warmup_lr`` for warmup='linear'
+    (mmcv/mmcv/runner/hooks/lr_updater.py:75-92, restated: k = (1 - cur / warmup_iters) * (1 - warmup_ratio);
+    lr = regular * (1 - k)) and a ``_set_lr`` that records what would be written into the optimizer's groups"""
+
     def __init__(self, by_epoch=True, warmup=None, warmup_iters=0, warmup_ratio=0.1, warmup_by_epoch=False):
-        self.by_epoch, self.warmup, self.warmup_iters = by_epoch, warmup, warmup_iters
+        self.by_epoch, self.warmup, self.warmup_iters, self.warmup_ratio = by_epoch, warmup, warmup_iters, warmup_ratio
         self.base_lr, self.regular_lr = [], []
+        self.last_set = None
+
+    def get_warmup_lr(self, cur_iters):
+        assert self.warmup == 'linear'
+        k = (1 - cur_iters / self.warmup_iters) * (1 - self.warmup_ratio)
+        return [_lr * (1 - k) for _lr in self.regular_lr]
+
+    def _set_lr(self, runner, lr_groups):
+        self.last_set = list(lr_groups)
 
 
 def available():

@@ -43,6 +43,9 @@ PY
     backbone)     timeout 900 python -m pytest tests/test_backbone_gpu.py tests/test_amp_gpu.py tests/test_graph_replay_gpu.py -x -q 2>&1 | tail -8 | tee $O/backbone_tests.txt ;;
     alltests)     timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee $O/alltests.txt ;;
     heads)        timeout 900 python -m pytest tests/test_roi_head_gpu.py tests/test_detector_gpu.py tests/test_rpn_gpu.py -x -q 2>&1 | tail -12 | tee $O/heads_tests.txt ;;
+    optim)        timeout 600 python -m pytest tests/test_optim_gpu.py -x -q 2>&1 | tail -8 | tee $O/optim_tests.txt ;;
+    bench_full)   SM3_BENCH_OPS=full SM3_BENCH_NATIVE=0 timeout 1200 python bench.py --no-cpu-baseline > $O/bench_full.json 2>$O/bench_full.err
+                  python -c "import json; r=json.loads([l for l in open('$O/bench_full.json') if l.startswith('{')][-1]); print(r['ms_per_step']); print(json.dumps(r.get('full_model'))[:1500])"; tail -3 $O/bench_full.err ;;
     smoke)        timeout 600 python __graft_entry__.py --smoke 2>&1 | tail -3 ;;
     *) echo "unknown step $step" ;;
   esac

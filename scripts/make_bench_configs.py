@@ -7,7 +7,7 @@ Run in the build container only (the GPU box has no /root/reference):
 For each BASELINE.json config the file under /root/reference/local_configs is read UNCHANGED by
 sm3det_amd.config.Config.fromfile (python exec + `_base_` merge) and the parts `bench.py --config NAME` needs are
 stored: the whole `model` dict (backbone / neck / heads / train_cfg exactly as written), `fp16` (the AMP switch),
-`optimizer`, `optimizer_config`, `data.samples_per_gpu`.  tests/test_config_cpu.py re-derives the file from the live
+`optimizer`, `optimizer_config`, `lr_config` (the dynamic-lr policy), `data.samples_per_gpu`.  tests/test_config_cpu.py re-derives the file from the live
 reference and compares, so the committed copy cannot drift.
 """
 import glob
@@ -49,6 +49,7 @@ def derive():
             baseline_config=num, file='local_configs/' + os.path.basename(files[0]),
             model=_plain(cfg['model']), fp16=_plain(cfg.get('fp16')), optimizer=_plain(cfg.get('optimizer')),
             optimizer_config=_plain(cfg.get('optimizer_config')),
+            lr_config=_plain(cfg.get('lr_config')),
             samples_per_gpu=(cfg.get('data') or {}).get('samples_per_gpu'))
     return out
 

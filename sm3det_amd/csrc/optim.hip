@@ -190,11 +190,111 @@ __global__ __launch_bounds__(OPT_THREADS) void adamw_multi_kernel(TensorTable tt
   }
 }
 
+// DynamicLrUpdaterHook.after_train_iter (mmrotate/core/hook/dynamic_lr.py:192-217) + get_dynamic_lr (:107-175) as ONE launch
+// on device-resident loss scalars: the reference reads every loss with .item() (11 host syncs per iteration), here the loss
+// EMAs, the update counter and the iteration counter live in `state` (doubles: [0, n) EMA, [n] number of EMA updates,
+// [n + 1] iteration index) and the per-tensor lr vector the AdamW launch reads is written directly.  Double precision as in
+// the reference (python floats / float64 tensors).  One workgroup; thread 0 does the O(n) scalar work.
+struct DlaCfg {
+  int n, n_subnets, n_params;
+  int head_policy;      // 0 normal (history / current), 1 reverse, 2 'None'
+  int backbone_policy;  // 0 min, 1 avg, 2 max, 3 kl, 4 sigmoid_kl, 5 other (1.0)
+  int warmup_iters;     // LrUpdaterHook.warmup_iters (0: no warm-up)
+  float warmup_ratio, T, b, beta;
+};
+__global__ __launch_bounds__(256) void dla_lr_kernel(DlaCfg c, const float* __restrict__ losses,
+                                                    const int32_t* __restrict__ loss_subnet,
+                                                    const int32_t* __restrict__ param_subnet,
+                                                    const float* __restrict__ base_lr, const float* __restrict__ sched,
+                                                    double* __restrict__ state, float* __restrict__ lr) {
+  __shared__ double s_w[64];  // per-subnet multiplier, [63] = shared (backbone / neck) multiplier
+  __shared__ double s_all;    // warm-up: one factor for every tensor (< 0: not in warm-up)
+  constexpr int MAXN = 32;
+  if (threadIdx.x == 0) {
+    const int n = c.n;
+    double cur[MAXN], hist[MAXN], bw[MAXN];
+    const double steps = state[n], it = state[n + 1];
+    for (int i = 0; i < n; i++) {
+      cur[i] = (double)losses[i];
+      hist[i] = steps > 0 ? state[i] : 1e-3;  // EMA_meter.get()
+    }
+    s_all = -1.0;
+    if (c.warmup_iters > 0 && it < (double)c.warmup_iters) {
+      // :203-216 -- linear warm-up of the regular lr (mmcv LrUpdaterHook.get_warmup_lr), the EMAs keep updating
+      const double k = (1.0 - it / c.warmup_iters) * (1.0 - (double)c.warmup_ratio);
+      s_all = 1.0 - k;
+    } else {
+      if (steps < (double)c.warmup_iters || c.head_policy == 2) {
+        for (int i = 0; i < n; i++) bw[i] = 1.0;
+      } else {
+        double mx = -1e300, sum = 0;
+        for (int i = 0; i < n; i++) {
+          bw[i] = (c.head_policy == 1 ? cur[i] / hist[i] : hist[i] / cur[i]) / (double)c.T;
+          mx = fmax(mx, bw[i]);
+        }
+        for (int i = 0; i < n; i++) { bw[i] = exp(bw[i] - mx); sum += bw[i]; }
+        for (int i = 0; i < n; i++) bw[i] = n * bw[i] / sum;
+      }
+      double vmin = 1e300, vmax = -1e300, vsum = 0;
+      for (int sn = 0; sn < c.n_subnets; sn++) {
+        double a = 0; int m = 0;
+        for (int i = 0; i < n; i++) if (loss_subnet[i] == sn) { a += bw[i]; m++; }
+        // a sub-network none of whose losses is present this step: the reference divides 0 by 0 (a python error); 1 here
+        const double w = m ? a / m : 1.0;
+        s_w[sn] = w;
+        vmin = fmin(vmin, w); vmax = fmax(vmax, w); vsum += w;
+      }
+      double shared = 1.0;
+      if (c.backbone_policy == 0) shared = vmin;
+      else if (c.backbone_policy == 1) shared = vsum / c.n_subnets;
+      else if (c.backbone_policy == 2) shared = vmax;
+      else if (c.backbone_policy == 3 || c.backbone_policy == 4) {
+        // F.kl_div(softmax(cur).log(), softmax(history), reduction='batchmean') of 1-D tensors: sum / n
+        double mh = -1e300, mc = -1e300, sh = 0, sc = 0;
+        for (int i = 0; i < n; i++) { mh = fmax(mh, hist[i]); mc = fmax(mc, cur[i]); }
+        for (int i = 0; i < n; i++) { sh += exp(hist[i] - mh); sc += exp(cur[i] - mc); }
+        double kl = 0;
+        for (int i = 0; i < n; i++) {
+          const double lh = hist[i] - mh - log(sh), lc = cur[i] - mc - log(sc);
+          kl += exp(lh) * (lh - lc);
+        }
+        kl /= n;
+        shared = c.backbone_policy == 3 ? 1.0 + (1.0 - kl) / sqrt((double)c.T)
+                                        : 2.0 / (1.0 + exp(-((1.0 - kl - (double)c.b) * (double)c.T)));
+      }
+      s_w[63] = shared;
+    }
+    for (int i = 0; i < n; i++)  // EMA_meter.update, after the weights were taken from the OLD history
+      state[i] = steps > 0 ? (1.0 - (double)c.beta) * state[i] + (double)c.beta * cur[i] : cur[i];
+    state[n] = steps + 1.0;
+    state[n + 1] = it + 1.0;
+  }
+  __syncthreads();
+  const double sch = (double)sched[0];  // step-decay factor gamma^exp of get_lr (:92-105), maintained by the host
+  for (int p = threadIdx.x; p < c.n_params; p += blockDim.x) {
+    const int sn = param_subnet[p];
+    const double mult = s_all >= 0.0 ? s_all : (sn >= 0 ? s_w[sn] : s_w[63]);
+    lr[p] = (float)((double)base_lr[p] * sch * mult);
+  }
+}
+
 }  // namespace
 
 extern "C" {
 
 int sm3_optim_chunk_elems(void) { return OPT_CHUNK; }
+
+int sm3_dla_lr(const float* losses, int n, const int32_t* loss_subnet, int n_subnets, const int32_t* param_subnet,
+               const float* base_lr, int n_params, const float* sched, double* state, int head_policy,
+               int backbone_policy, int warmup_iters, float warmup_ratio, float T, float b, float ema_beta, float* lr,
+               sm3_stream_t stream) {
+  if (!losses || !loss_subnet || !param_subnet || !base_lr || !sched || !state || !lr) return SM3_ERR_INVALID_ARG;
+  if (n <= 0 || n > 32 || n_subnets <= 0 || n_subnets > 63 || n_params <= 0) return SM3_ERR_INVALID_ARG;
+  if (head_policy < 0 || head_policy > 2 || backbone_policy < 0 || backbone_policy > 5) return SM3_ERR_INVALID_ARG;
+  DlaCfg c{n, n_subnets, n_params, head_policy, backbone_policy, warmup_iters, warmup_ratio, T, b, ema_beta};
+  dla_lr_kernel<<<1, 256, 0, (hipStream_t)stream>>>(c, losses, loss_subnet, param_subnet, base_lr, sched, state, lr);
+  return launch_status();
+}
 
 int sm3_adamw_multi(const uint64_t* p_ptrs, const uint64_t* g_ptrs, const uint64_t* m_ptrs, const uint64_t* v_ptrs,
                     const uint64_t* h_ptrs, const int64_t* numel, const int32_t* chunk_tab, int n_chunks, const float* lr, const float* wd,

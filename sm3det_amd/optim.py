@@ -244,6 +244,8 @@ class MultiTensorAdamW(torch.optim.Optimizer):
             return
         lr = [self.param_groups[gi]['lr'] for gi, _ in self._params]
         wd = [self.param_groups[gi]['weight_decay'] for gi, _ in self._params]
+        if getattr(self, '_dla_owns_lr', False) and not force:
+            return  # DeviceDynamicLr writes the lr vector on the device every iteration
         if force or (lr, wd) != self._last_hyper:
             slot = self._hyper_slot
             self._hyper_slot ^= 1
@@ -333,7 +335,15 @@ class DynamicLrPolicy:
             ws = [bw[i] for i, k in enumerate(names) if self.reweight_losses[k] == s]
             subnet[s] = sum(ws) / len(ws) if ws else 1.0
         vals = list(subnet.values())
-        shared = {'min': min(vals), 'avg': sum(vals) / len(vals), 'max': max(vals)}.get(self.backbone_policy, 1.0)
+        if self.backbone_policy in ('kl', 'sigmoid_kl'):
+            # F.kl_div(softmax(cur).log(), softmax(history), reduction='batchmean') of 1-D tensors = sum / n (:156-165)
+            hist = [m.get() for m in self.history[:n]]
+            lh, lc = _log_softmax(hist), _log_softmax(cur)
+            kl = sum(math.exp(a) * (a - c) for a, c in zip(lh, lc)) / n
+            shared = (1 + (1 - kl) / math.sqrt(self.T)) if self.backbone_policy == 'kl' else \
+                2.0 / (1.0 + math.exp(-((1 - kl - self.b) * self.T)))
+        else:
+            shared = {'min': min(vals), 'avg': sum(vals) / len(vals), 'max': max(vals)}.get(self.backbone_policy, 1.0)
         for i, c in enumerate(cur):
             self.history[i].update(c)
         out = {}
@@ -345,6 +355,129 @@ class DynamicLrPolicy:
                     break
             out[pn] = mult
         return out
+
+
+def dynamic_lr_after_train_iter(policy, log_vars, param_names, base_lrs, it, step, gamma=0.1, warmup_iters=0,
+                                warmup_ratio=0.1):
+    """Host form of ``DynamicLrUpdaterHook.after_train_iter`` (dynamic_lr.py:192-217) for iteration index `it`: during the
+    linear warm-up the loss EMAs keep updating and every group gets ``regular_lr * (1 - k)`` (mmcv
+    ``LrUpdaterHook.get_warmup_lr``, mmcv/mmcv/runner/hooks/lr_updater.py:75-92), afterwards ``get_dynamic_lr``.  `policy` is a
+    ``DynamicLrPolicy`` (it carries the EMAs).  -> list of lrs, one per name.  Pinned on the reference hook by
+    tests/test_dla_cpu.py; the device kernel (``DeviceDynamicLr``) is compared with it on the GPU."""
+    e = (it // step) if isinstance(step, int) else next((i for i, s_ in enumerate(step) if it < s_), len(step))
+    regular = [b * gamma ** e for b in base_lrs]
+    if warmup_iters and it < warmup_iters:
+        names = [k for k in log_vars if k in policy.reweight_losses]
+        for i, k in enumerate(names):
+            v = log_vars[k]
+            policy.history[i].update(float(sum(v) if isinstance(v, list) else v))
+        k_ = (1 - it / warmup_iters) * (1 - warmup_ratio)
+        return [r * (1 - k_) for r in regular]
+    mult = policy.multipliers(log_vars, param_names)
+    return [r * mult[n] for r, n in zip(regular, param_names)]
+
+
+def _log_softmax(v):
+    mx = max(v)
+    ls = math.log(sum(math.exp(x - mx) for x in v))
+    return [x - mx - ls for x in v]
+
+
+_HEAD_POLICY = {'normal': 0, 'reverse': 1, 'None': 2}
+_BACKBONE_POLICY = {'min': 0, 'avg': 1, 'max': 2, 'kl': 3, 'sigmoid_kl': 4}
+
+
+class DeviceDynamicLr:
+    """``DynamicLrUpdaterHook`` (mmrotate/core/hook/dynamic_lr.py:45-217; ``lr_config = dict(policy='dynamic', ...)`` of
+    local_configs/main_SM3Det.py:291-300) as one kernel launch per iteration on device-resident loss scalars
+    (``sm3_dla_lr``): the reference reads its 11 losses with ``.item()`` every iteration; here the loss EMAs, the update and
+    iteration counters and the per-tensor lr vector never leave the device, so the step stays capturable in a hipGraph.
+
+    ``update(losses)`` is the hook's ``after_train_iter`` -- it runs BEFORE the optimizer step of the same iteration (the
+    lr hook has priority VERY_HIGH, the optimizer hook ABOVE_NORMAL), so the lr it writes is the one that iteration's
+    AdamW update uses.  ``losses``: {name: 0-d device tensor (or list of them: summed)} -- the step's log_vars; only the
+    keys of ``reweight_losses`` count, in the dict's order (as the reference walks ``log_vars``)."""
+
+    def __init__(self, optimizer, param_names, step, gamma=0.1, min_lr=None, extra_args=None, reweight_losses=None,
+                 warmup=None, warmup_iters=0, warmup_ratio=0.1, by_epoch=False, **_unused):
+        if by_epoch:
+            raise NotImplementedError('the dynamic policy asserts by_epoch=False (dynamic_lr.py:217)')
+        if warmup not in (None, 'linear'):
+            raise NotImplementedError(f"warmup={warmup!r}: the SM3Det configs use 'linear'")
+        ea = dict(T=5, b=0.5, ema=0.005, backbone_policy='min', head_policy='normal')
+        ea.update(extra_args or {})
+        self.extra, self.reweight = ea, dict(reweight_losses or DEFAULT_REWEIGHT)
+        self.step_at = [step] if isinstance(step, int) else list(step)
+        self.step_is_int = isinstance(step, int)
+        self.gamma, self.min_lr = gamma, min_lr
+        if min_lr is not None:
+            raise NotImplementedError('min_lr clipping is per-tensor host arithmetic in the reference; no SM3Det config sets it')
+        self.warmup_iters = int(warmup_iters) if warmup else 0
+        self.warmup_ratio = float(warmup_ratio)
+        self.opt = optimizer
+        if not optimizer._built:
+            optimizer._build()
+        names = list(param_names)
+        assert len(names) == len(optimizer._params), 'one name per optimizer tensor, in the optimizer\'s order'
+        self.subnets = sorted(set(self.reweight.values()))
+        dev = optimizer._lr.device
+        ps = []
+        for n in names:  # dynamic_lr.py:166-174: the first sub-network whose name occurs in the parameter's name, else shared
+            ps.append(next((i for i, sname in enumerate(self.subnets) if sname in n), -1))
+        self._param_subnet = torch.tensor(ps, dtype=torch.int32, device=dev)
+        self._base_lr = torch.tensor([optimizer.param_groups[gi].get('initial_lr', optimizer.param_groups[gi]['lr'])
+                                      for gi, _ in optimizer._params], dtype=torch.float32, device=dev)
+        self._sched = torch.ones(1, dtype=torch.float32, device=dev)
+        self._sched_host = 1.0
+        self._state = None
+        self._keys = None
+        self.iter = 0
+
+    def _decay(self, it):
+        if self.step_is_int:
+            e = it // self.step_at[0]
+        else:
+            e = next((i for i, s_ in enumerate(self.step_at) if it < s_), len(self.step_at))
+        return self.gamma ** e
+
+    def set_iter(self, it):
+        """host bookkeeping of get_lr's step decay (:92-105): call with the runner's iteration index when not replaying a
+        fixed graph; the factor changes at the few `step` milestones only (a tiny H2D copy then)"""
+        f = self._decay(it)
+        if f != self._sched_host:
+            self._sched.fill_(f)
+            self._sched_host = f
+
+    def update(self, losses):
+        keys = [k for k in losses if k in self.reweight]
+        if self._keys is None:
+            self._keys = keys
+            dev = self._base_lr.device
+            self._loss_subnet = torch.tensor([self.subnets.index(self.reweight[k]) for k in keys], dtype=torch.int32, device=dev)
+            self._state = torch.zeros(len(keys) + 2, dtype=torch.float64, device=dev)
+        elif keys != self._keys:
+            raise _lib.SM3Error('DeviceDynamicLr: the set / order of reweighted losses changed between iterations '
+                                f'({self._keys} -> {keys}); the device tables are built for one set')
+        vals = [sum(losses[k]) if isinstance(losses[k], (list, tuple)) else losses[k] for k in keys]
+        cur = torch.stack([v.detach().float().reshape(()) for v in vals])
+        ea = self.extra
+        LB.call('dla_lr', cur, len(keys), self._loss_subnet, len(self.subnets), self._param_subnet, self._base_lr,
+                self._base_lr.numel(), self._sched, self._state, _HEAD_POLICY[str(ea['head_policy'])],
+                _BACKBONE_POLICY.get(ea['backbone_policy'], 5), self.warmup_iters, self.warmup_ratio, float(ea['T']),
+                float(ea['b']), float(ea['ema']), self.opt._lr)
+        self.opt._dla_owns_lr = True  # the optimizer must not overwrite the device lr vector from its host-side groups
+
+    def fast_forward(self, iters):
+        """set the update / iteration counters (e.g. past the warm-up, to time or test the steady-state branch); the EMAs keep
+        the values they have"""
+        if self._state is None:
+            raise _lib.SM3Error('DeviceDynamicLr.fast_forward: call update() once first (the state is sized by the loss set)')
+        self._state[-2:] = float(iters)
+
+    def state_host(self):
+        """(EMAs, updates, iteration) read back -- tests / checkpointing only"""
+        s_ = self._state.cpu().tolist()
+        return s_[:-2], int(s_[-2]), int(s_[-1])
 
 
 # ------------------------------------------------------------------------------------------------------------------------

@@ -35,6 +35,7 @@ CASES = {
     'full_e16t2_b1': dict(cfg=TINY_E16, batch=1, res=1024, seed=13),
     'full_e16t2_b2': dict(cfg=TINY_E16, batch=2, res=1024, seed=14),  # config #4 at its per-GPU batch
     'full_base_b1': dict(cfg=BASE_E8, batch=1, res=1024, seed=15),    # config #5 (ConvNeXt-B, C = 128..1024)
+    'full_base_b2': dict(cfg=BASE_E8, batch=2, res=1024, seed=17),    # config #5 at the per-GPU batch BASELINE.json names
     # the gate-noise seed of the cases above is the best of 24 candidates by widest top-k margin (routing flips are rare by
     # construction); this one takes its FIRST candidate unselected, so near-ties occur at their natural rate
     'full_e8t2_b1_plainseed': dict(cfg=TINY_E8, batch=1, res=1024, seed=16, select_noise=False),

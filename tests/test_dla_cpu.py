@@ -20,7 +20,7 @@ def _losses(step):
     return d
 
 
-@pytest.mark.parametrize('backbone_policy', ['min', 'avg', 'max'])
+@pytest.mark.parametrize('backbone_policy', ['min', 'avg', 'max', 'kl', 'sigmoid_kl'])
 @pytest.mark.parametrize('head_policy', ['normal', 'reverse', 'None'])
 @pytest.mark.parametrize('warmup_iters', [0, 3])
 def test_policy_matches_reference_hook(backbone_policy, head_policy, warmup_iters):
@@ -62,3 +62,39 @@ def test_policy_shapes_without_reference():
     pol2.multipliers(eq, PARAMS)
     m2 = pol2.multipliers(eq, PARAMS)
     assert all(abs(v - 1.0) < 1e-9 for v in m2.values())
+
+
+@pytest.mark.parametrize('backbone_policy,head_policy', [('sigmoid_kl', 'normal'), ('min', 'reverse')])
+def test_after_train_iter_flow_with_linear_warmup_matches_reference_hook(backbone_policy, head_policy):
+    """The whole per-iteration flow of the hook -- `after_train_iter` (dynamic_lr.py:192-217): linear warm-up with the EMAs
+    updating underneath, then `get_dynamic_lr` with the step decay of `get_lr` -- run live against
+    `sm3det_amd.optim.dynamic_lr_after_train_iter` (the host form the device kernel is compared with on the GPU), with the
+    extra_args of local_configs/main_SM3Det.py:291-300 (T 3, b 0.4, ema 0.001)."""
+    from oracle import ref_dla
+    if not ref_dla.available():
+        pytest.skip('/root/reference not present (GPU box)')
+    from sm3det_amd.optim import DynamicLrPolicy, dynamic_lr_after_train_iter
+    mod = ref_dla.load()
+    extra = {'T': 3, 'b': 0.4, 'ema': 0.001, 'backbone_policy': backbone_policy, 'head_policy': head_policy}
+    W, steps_at = 5, [9, 12]
+    hook = mod.DynamicLrUpdaterHook(step=steps_at, gamma=0.1, extra_args=extra, by_epoch=False, warmup='linear',
+                                    warmup_iters=W, warmup_ratio=1.0 / 3)
+    base = [1e-4 * (1 + 0.1 * i) for i in range(len(PARAMS))]
+    hook.base_lr = list(base)
+    hook.param_groups_param_names_mapping = dict(enumerate(PARAMS))
+    pol = DynamicLrPolicy(T=3, b=0.4, ema=0.001, backbone_policy=backbone_policy, head_policy=head_policy, warmup_iters=W)
+
+    class Runner:
+        iter, epoch = 0, 0
+    r = Runner()
+    for it in range(15):
+        lv = _losses(100 + it)
+        r.outputs = {'log_vars': lv}
+        r.iter = it
+        # mmcv sets regular_lr in before_train_epoch from get_lr; for an iteration-based run it is the decayed base lr
+        hook.regular_lr = [hook.get_lr(r, b) for b in hook.base_lr]
+        hook.after_train_iter(r)
+        ref = hook.last_set
+        got = dynamic_lr_after_train_iter(pol, lv, PARAMS, base, it, steps_at, 0.1, W, 1.0 / 3)
+        for i, n in enumerate(PARAMS):
+            assert abs(got[i] - ref[i]) <= 1e-6 * abs(ref[i]), (it, n, got[i], ref[i])

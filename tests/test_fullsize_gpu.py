@@ -64,7 +64,7 @@ def test_full_size_values_vs_reference_fixture(case):
     _run_case(case, amp=False)
 
 
-@pytest.mark.parametrize('case', ['full_e8t2_b2', 'full_base_b1'])
+@pytest.mark.parametrize('case', ['full_e8t2_b2', 'full_base_b1', 'full_base_b2'])
 def test_full_size_amp_data_path_vs_fp32_reference_fixture(case):
     """configs #3 (ConvNeXt-T e8t2, the headline batch) and #5 (ConvNeXt-B) under `wrap_fp16_model` at 1024^2 against the
     reference module's fp32 results.  Two runs:

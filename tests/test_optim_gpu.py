@@ -70,3 +70,64 @@ def test_graph_capture_and_dynamic_lr_policy():
     m2 = pol.multipliers({k: v * (2.0 if k.startswith('sar') else 1.0) for k, v in lv.items()}, names)
     assert set(m1) == set(names) and all(v > 0 for v in m2.values())
     assert m2['backbone.stages.0.0.gamma'] == min(m2.values())  # backbone_policy='min'
+
+
+@pytest.mark.parametrize('backbone_policy,head_policy', [('sigmoid_kl', 'normal'), ('min', 'reverse'), ('kl', 'None'),
+                                                         ('avg', 'normal'), ('max', 'normal')])
+def test_device_dynamic_lr_matches_the_host_flow_pinned_on_the_reference_hook(backbone_policy, head_policy):
+    """``DeviceDynamicLr`` (sm3_dla_lr: one launch, no host read) against ``dynamic_lr_after_train_iter`` -- the host form
+    that tests/test_dla_cpu.py pins on the reference's own ``DynamicLrUpdaterHook.after_train_iter`` -- over a recorded loss
+    sequence that crosses the linear warm-up, both step-decay milestones and has list-valued losses (the GFL head's
+    per-level lists are summed): the lr vector the AdamW launch reads equals the hook's within 1e-6, the EMAs within 1e-12."""
+    from sm3det_amd.optim import (DeviceDynamicLr, DynamicLrPolicy, MultiTensorAdamW, dynamic_lr_after_train_iter)
+    names = ['backbone.stages.0.0.gamma', 'backbone.stages.2.1.ffn.w1', 'neck.lateral_convs.0.conv.weight',
+             'sar_bbox_head.gfl_cls.weight', 'rgb_rpn_head.rpn_conv.weight', 'rgb_roi_head.bbox_head.fc_cls.weight',
+             'ifr_rpn_head.rpn_reg.bias', 'ifr_roi_head.bbox_head.shared_fcs.0.weight']
+    ps = [torch.nn.Parameter(torch.randn(8, 4, device='cuda')) for _ in names]
+    for p in ps:
+        p.grad = torch.randn_like(p)
+    base = [1e-4 * (1 + 0.1 * i) for i in range(len(ps))]
+    opt = MultiTensorAdamW([dict(params=[p], lr=b) for p, b in zip(ps, base)], lr=1e-4, weight_decay=0.05)
+    extra = {'T': 3, 'b': 0.4, 'ema': 0.001, 'backbone_policy': backbone_policy, 'head_policy': head_policy}
+    W, steps_at = 5, [9, 12]
+    dla = DeviceDynamicLr(opt, names, step=steps_at, gamma=0.1, extra_args=extra, warmup='linear', warmup_iters=W,
+                          warmup_ratio=1.0 / 3)
+    pol = DynamicLrPolicy(T=3, b=0.4, ema=0.001, backbone_policy=backbone_policy, head_policy=head_policy, warmup_iters=W)
+    keys = ['sar_loss_cls', 'sar_loss_bbox', 'sar_loss_dfl', 'rgb_loss_rpn_cls', 'rgb_loss_rpn_bbox', 'rgb_loss_cls',
+            'rgb_loss_bbox', 'ifr_loss_rpn_cls', 'ifr_loss_rpn_bbox', 'ifr_loss_cls', 'ifr_loss_bbox']
+    for it in range(15):
+        g = torch.Generator().manual_seed(100 + it)
+        v = (torch.rand(len(keys) + 4, generator=g) * 2 + 0.05)
+        dev = {'gate_loss': v[-1].cuda(), 'loss': v.sum().cuda()}  # not reweight keys: ignored
+        host = {}
+        for i, k in enumerate(keys):
+            if k == 'sar_loss_bbox':  # a per-level list, as GFLHead returns it
+                parts = [v[i] * 0.5, v[-2] * 0.25, v[-3] * 0.25]
+                dev[k] = [q.cuda() for q in parts]
+                host[k] = [float(q) for q in parts]
+            else:
+                dev[k] = v[i].cuda()
+                host[k] = float(v[i])
+        dla.set_iter(it)
+        dla.update(dev)
+        want = dynamic_lr_after_train_iter(pol, host, names, base, it, steps_at, 0.1, W, 1.0 / 3)
+        got = opt._lr.cpu().tolist()
+        for a, b, n in zip(got, want, names):
+            assert abs(a - b) <= 1e-6 * abs(b) + 1e-12, (it, n, a, b)
+        opt.step()  # the optimizer must keep the device lr vector (not rewrite it from its host groups)
+        assert opt._lr.cpu().tolist() == got
+    emas, updates, iters = dla.state_host()
+    assert updates == iters == 15
+    for e, m in zip(emas, pol.history):
+        assert abs(e - m.get()) <= 1e-6 * abs(m.get())  # (the list-valued loss is summed in fp32 on the device, as mmdet does)
+    # the launch is capturable: no host read of a loss
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            dla.update(dev)
+    torch.cuda.current_stream().wait_stream(s)
+    gr.replay()
+    torch.cuda.synchronize()
+    assert dla.state_host()[1] == 16
