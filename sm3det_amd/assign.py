@@ -29,8 +29,8 @@ _SAMPLER_WS = {}
 
 
 def _sampler_workspace(device):
-    """the sampler kernels' scratch (counters + candidate lists), zeroed once per (device, stream): every call leaves the
-    counters zero again, and calls on one stream are ordered"""
+    """the sampler kernels' scratch (counters + candidate lists) per (device, stream); sm3_random_sample_fixed zeroes the
+    counters itself at the start of every call"""
     k = (device.index, torch.cuda.current_stream(device).cuda_stream)
     ws = _SAMPLER_WS.get(k)
     if ws is None:

@@ -246,7 +246,7 @@ def _half():
 AMP_HALF_STORAGE = os.environ.get('SM3_AMP_STORAGE', 'fp16') != 'fp32'
 # fp16 SHADOWS of the FFN / expert weights as the B operand of the four GEMMs of a block (what the half model of
 # `wrap_fp16_model` holds next to the fp32 master weights): a third fewer operand bytes through the L1, which bounds the
-# fp16-operand launches.  SM3_AMP_W16=1 turns it on (bit-identical results: the loader rounds the fp32 weights to the
+# fp16-operand launches.  ON by default (bit-identical results: the loader rounds the fp32 weights to the
 # same halves -- tests/test_amp_gpu.py), 11.85 -> 11.71 ms per AMP step with a cast per forward, less with the shadows kept by
 # the optimizer (profiles/r04); SM3_AMP_W16=0 reads the fp32 weights.
 AMP_W16 = os.environ.get('SM3_AMP_W16', '1') == '1'

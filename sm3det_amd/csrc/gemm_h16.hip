@@ -9,7 +9,7 @@
 //   TN  A16|B16        dh(f16)^T . x(f16)      -> fp32                                      (FC1 weight gradient)
 // Weights, biases, the residual stream and all C-wide gradients stay fp32.  With `| B16` on an NT / NN form the B operand is
 // read from an fp16 SHADOW of the (fp32 master) weights: what the half model of wrap_fp16_model holds -- a third fewer
-// operand bytes through the L1 (opt-in: SM3_AMP_W16=1, backbone_ops._shadow).
+// operand bytes through the L1 (default; SM3_AMP_W16=0 reads the fp32 masters; backbone_ops._shadow).
 #include "gemm_f32_kernel.h"
 
 namespace sm3gemm {

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(SP_THREADS) void sampler_emit_kernel(const int64_t*
                                                                  uint8_t* __restrict__ is_pos_out, uint8_t* __restrict__ valid_out,
                                                                  int64_t* __restrict__ n_pos_out, int64_t* __restrict__ n_neg_out) {
   __shared__ SpEntry s[SP_CAP];
-  __shared__ int relisted;
+  __shared__ int relisted, got_pos, got_neg;
   const int P = w->counts[0], N = w->counts[1];
   const int m_pos = wanted_pos(P, exp_pos), m_neg = wanted_neg(N, m_pos, num, neg_pos_ub);
   for (int c = 0; c < 2; c++) {
@@ -142,13 +142,18 @@ __global__ __launch_bounds__(SP_THREADS) void sampler_emit_kernel(const int64_t*
         }
         __syncthreads();
       }
-    // positives fill the slots [0, m_pos), negatives [m_pos, m_pos + m_neg)
+    // positives fill the slots [0, m_pos), negatives [m_pos, m_pos + m_neg).  Only entries that exist are handed out: with
+    // consistent counters have >= m always; should the scratch ever hold stale counters (a capture that recorded its
+    // zero-fill but never replayed it), the surplus slots are marked invalid instead of carrying a padding index
     const int base = c ? m_pos : 0;
+    const int got_c = min(m, have);
     for (int i = threadIdx.x; i < m; i += SP_THREADS) {
-      idx_out[base + i] = s[i].idx;
-      is_pos_out[base + i] = c == 0;
-      valid_out[base + i] = 1;
+      const bool real = i < got_c;
+      idx_out[base + i] = real ? s[i].idx : 0;
+      is_pos_out[base + i] = real && c == 0;
+      valid_out[base + i] = real;
     }
+    if (threadIdx.x == 0) (c ? got_neg : got_pos) = got_c;
     __syncthreads();
   }
   // unused slots: what the host form leaves there (the clamped lookup of the negative order): any in-range index, flags 0
@@ -158,8 +163,8 @@ __global__ __launch_bounds__(SP_THREADS) void sampler_emit_kernel(const int64_t*
     valid_out[i] = 0;
   }
   if (threadIdx.x == 0) {
-    *n_pos_out = m_pos;
-    *n_neg_out = m_neg;
+    *n_pos_out = got_pos;  // what was actually written (= m_pos / m_neg)
+    *n_neg_out = got_neg;
     w->counts[0] = w->counts[1] = w->listed[0] = w->listed[1] = 0;  // ready for the next call
   }
 }
@@ -238,6 +243,9 @@ int sm3_random_sample_fixed(const int64_t* gt_inds, const float* key, int n, int
   if (n > 0 && (!gt_inds || !key)) return SM3_ERR_INVALID_ARG;
   hipStream_t st = (hipStream_t)stream;
   SpWork* w = (SpWork*)workspace;
+  // the four counters are zeroed by every call (a kernel node: ordered under capture and replay), not only left zero by the
+  // previous one: the scratch may have been allocated inside a capture whose zero-fill never ran
+  sm3_zero_async(w, 16, st);
   if (n > 0) {
     const int blocks = min((n + 255) / 256, 1024);
     sampler_count_kernel<<<blocks, 256, 0, st>>>(gt_inds, n, w);

@@ -60,8 +60,8 @@ def atss_assign(bboxes, num_level_bboxes, gt_bboxes, gt_labels=None, topk=9, val
     4. an anchor positive for several gts goes to the one with the highest IoU.
 
     bboxes (n, 4) level-major; num_level_bboxes: python ints; gt_bboxes (k, 4); valid (n,) bool or None: anchors outside
-    the padded image (mmdet removes them before assigning; here they get an infinite distance and can never be candidates
-    while a level holds >= topk valid anchors).  Returns (gt_inds (n,) long: 0 negative / i + 1, max_overlaps (n,),
+    the padded image (mmdet removes them before assigning; here they get an infinite distance, never become positives, and
+    are left out of the mean + std threshold -- the same assignment as the compacted form).  Returns (gt_inds (n,) long: 0 negative / i + 1, max_overlaps (n,),
     labels (n,) long or None: -1 where unassigned)."""
     n, k = bboxes.size(0), gt_bboxes.size(0)
     bboxes = bboxes[:, :4]
@@ -83,7 +83,16 @@ def atss_assign(bboxes, num_level_bboxes, gt_bboxes, gt_labels=None, topk=9, val
         start += nl
     cand = torch.cat(cand, dim=0)  # (c, k)
     cand_ov = overlaps.gather(0, cand)
-    thr = cand_ov.mean(0) + cand_ov.std(0)
+    if valid is None:
+        thr = cand_ov.mean(0) + cand_ov.std(0)
+    else:
+        # mmdet removes the anchors outside the padded image BEFORE assigning (and shrinks topk to the valid anchors a
+        # level holds), so only valid candidates enter a gt's mean + std threshold: masked moments (unbiased std, as
+        # torch.std) over the candidates that are valid -- equal to the compacted form whatever a level's valid count is
+        vc = valid[cand].to(cand_ov.dtype)
+        cnt = vc.sum(0)
+        mean = (cand_ov * vc).sum(0) / cnt
+        thr = mean + (((cand_ov - mean[None, :]) ** 2 * vc).sum(0) / (cnt - 1)).sqrt()
     is_pos = cand_ov >= thr[None, :]
     ccx, ccy = cx[cand], cy[cand]  # (c, k)
     side = torch.stack((ccx - gt_bboxes[None, :, 0], ccy - gt_bboxes[None, :, 1],

@@ -472,15 +472,14 @@ class OrientedRPNHead(nn.Module):
         if proposal_cfg is None:
             return losses
         with torch.no_grad():
-            if fixed_size:
-                # the fixed-size path decodes the whole batch against ONE image extent (one anchor set, one clamp); with
-                # keep-ratio resize + padding the images of a batch may differ: refuse instead of clamping image i > 0 to
-                # image 0's extent (the reference decodes each image with its own img_meta['img_shape'])
-                if any(tuple(m['img_shape'][:2]) != tuple(img_metas[0]['img_shape'][:2]) or
-                       tuple(m.get('pad_shape', m['img_shape'])[:2]) != tuple(img_metas[0].get('pad_shape', img_metas[0]['img_shape'])[:2])
-                       for m in img_metas):
-                    raise NotImplementedError('OrientedRPNHead.forward_train(fixed_size=True): the images of a batch must '
-                                              'share img_shape / pad_shape; pass fixed_size=False for mixed extents')
+            # the fixed-size path decodes the whole batch against ONE image extent (one anchor set, one clamp); with
+            # keep-ratio resize + padding the images of a batch may differ: such a batch takes the per-image path (each
+            # image decoded with its own img_meta['img_shape'], as the reference does) instead of clamping image i > 0 to
+            # image 0's extent.  The RoI head accepts either form.
+            mixed = any(tuple(m['img_shape'][:2]) != tuple(img_metas[0]['img_shape'][:2]) or
+                        tuple(m.get('pad_shape', m['img_shape'])[:2]) != tuple(img_metas[0].get('pad_shape', img_metas[0]['img_shape'])[:2])
+                        for m in img_metas)
+            if fixed_size and not mixed:
                 shape = img_metas[0]['img_shape']
                 lvl, _, _ = self._train_anchors([tuple(c.shape[-2:]) for c in cls_scores],
                                                 img_metas[0].get('pad_shape', shape), shape, cls_scores[0].device)

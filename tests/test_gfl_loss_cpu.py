@@ -94,3 +94,33 @@ def test_valid_flags_mask_out_anchors_beyond_the_padded_image():
     lab, w, tgt, pos = head.get_targets(torch.cat(lvl), [a.shape[0] for a in lvl], [valid], [gtb], [gtl])
     assert not bool((pos[0] & ~valid).any()) and float(w[0][~valid].abs().sum()) == 0.0
     assert int(pos.sum()) > 0
+
+
+def test_atss_with_partially_valid_levels_equals_assignment_on_the_compacted_anchors():
+    """mmdet drops the anchors outside the padded image before ATSS runs (`num_level_anchors_inside`); the masked product
+    form must give the same assignment even when a level keeps FEWER than topk valid anchors (its invalid anchors then sit
+    among the level's top-k candidates and must not enter the mean + std threshold).  Checked against the indexing-form
+    restatement (oracle/gfl_oracle.py) run on the compacted anchor list."""
+    from oracle import gfl_oracle as GO
+    from sm3det_amd.gfl_losses import atss_assign
+    g = torch.Generator().manual_seed(11)
+    levels = [64, 16, 4]
+    anchors = []
+    for li, nl in enumerate(levels):
+        c = torch.rand(nl, 2, generator=g) * 120 + 4
+        s = 8.0 * 2 ** li
+        anchors.append(torch.cat([c - s / 2, c + s / 2], 1))
+    bboxes = torch.cat(anchors)
+    valid = torch.ones(sum(levels), dtype=torch.bool)
+    valid[40:64] = False           # level 0: 40 valid
+    valid[64 + 5:64 + 16] = False  # level 1: 5 valid (< topk = 9)
+    valid[80 + 1:] = False         # level 2: 1 valid
+    gts = torch.tensor([[10., 10., 60., 70.], [50., 40., 120., 110.], [5., 80., 40., 125.]])
+    gtl = torch.tensor([3, 7, 1])
+    gi, mo, lab = atss_assign(bboxes, levels, gts, gtl, topk=9, valid=valid)
+    keep = valid.nonzero().squeeze(1)
+    inside = [int(valid[:64].sum()), int(valid[64:80].sum()), int(valid[80:].sum())]
+    gi_c, mo_c, lab_c = GO.atss_assign(bboxes[keep], inside, gts, gtl, topk=9)
+    assert torch.equal(gi[keep], gi_c) and torch.equal(lab[keep], lab_c)
+    assert int((gi[~valid] != 0).sum()) == 0 and int((gi > 0).sum()) > 0
+    torch.testing.assert_close(mo[keep], mo_c)
