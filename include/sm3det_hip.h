@@ -569,6 +569,11 @@ int sm3_adamw_multi(const uint64_t* p_ptrs, const uint64_t* g_ptrs, const uint64
                     float* grad_norm, float* partials, float* scaler, float growth_factor, float backoff_factor,
                     int growth_interval, sm3_stream_t stream);
 
+/* Arithmetic of the implicit-GEMM 3x3 convolutions below (sm3_conv3x3_nhwc_*): 0 = native fp32 MFMA (default of the
+ * library), 2 = the bf16x3 form of sm3_gemm_desc.compute == 2 (fp32-equivalent, k-step 16; the weight gradient uses it when
+ * the output width is a multiple of 16, otherwise the native form).  Process-wide; set it before querying workspace sizes. */
+int sm3_conv3x3_set_arith(int compute);
+
 /* DynamicLrUpdaterHook (mmrotate/core/hook/dynamic_lr.py:107-217; local_configs/main_SM3Det.py:291-300 `policy='dynamic'`)
  * on the device: losses[n] = this iteration's loss scalars (the keys of `reweight_losses` present in the step, in log_vars
  * order), loss_subnet[n] = index of the sub-network each belongs to, param_subnet[n_params] = sub-network of every optimizer

@@ -77,6 +77,10 @@ def lib():
         handle = ctypes.CDLL(LIB_PATH)
         EXPORTED = _declare(handle)
         _lib = handle
+        # the 3x3 convolutions of the neck / heads follow the arithmetic of the fp32 GEMM family (SM3_GEMM_ARITH: 'bf16x3'
+        # by default, 'f32' = the native fp32 matrix instruction) -- _lib_backbone.ARITH32
+        from . import _lib_backbone
+        handle.sm3_conv3x3_set_arith(_lib_backbone.ARITH32)
     return _lib
 
 

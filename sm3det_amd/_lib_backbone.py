@@ -77,6 +77,7 @@ def signatures():
         'sm3_optim_chunk_elems': (I, []),
         'sm3_adamw_multi': (I, [P, P, P, P, P, P, P, I, P, P, F, F, F, F, P, P, P, P, P, F, F, I, P]),
         'sm3_dla_lr': (I, [P, I, P, I, P, P, I, P, P, I, I, I, F, F, F, F, P, P]),
+        'sm3_conv3x3_set_arith': (I, [I]),
         'sm3_deform_conv_fwd_fused_supported': (I, [I] * 6),
         'sm3_deform_conv_fwd_fused': (I, [P, P, P, P] + [I] * 13 + [P]),
         'sm3_deform_im2col': (I, [P, P, P] + [I] * 13 + [LL, P]),

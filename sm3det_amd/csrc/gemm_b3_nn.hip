@@ -19,4 +19,11 @@ int launch_nn_b3(const GemmParams& p, int epi, int tile, dim3 grid, hipStream_t 
   return SM3_ERR_INVALID_ARG;
 }
 
+
+// 3x3 convolution input gradient (GATHER = 1: transposed gather of dY, weights read as [tap][Cout] x Cin)
+int launch_nn_b3_conv(const GemmParams& p, dim3 grid, hipStream_t st) {
+  gemm_f32_kernel<MODE_NN, EPI_NONE, 16, T128x128, 1, 2><<<grid, NTHREADS, 0, st>>>(p);
+  return SM3_OK;
+}
+
 }  // namespace sm3gemm

@@ -28,4 +28,14 @@ int launch_nt_b3(const GemmParams& p, int epi, int tile, dim3 grid, hipStream_t 
   return SM3_ERR_INVALID_ARG;
 }
 
+
+// 3x3 convolution forward (GATHER = 1): the A operand is gathered tap by tap from the NHWC input
+int launch_nt_b3_conv(const GemmParams& p, int epi, dim3 grid, hipStream_t st) {
+  if (epi == EPI_NONE) gemm_f32_kernel<MODE_NT, EPI_NONE, 16, T128x128, 1, 2><<<grid, NTHREADS, 0, st>>>(p);
+  else if (epi == EPI_BIAS) gemm_f32_kernel<MODE_NT, EPI_BIAS, 16, T128x128, 1, 2><<<grid, NTHREADS, 0, st>>>(p);
+  else if (epi == EPI_BIAS_RELU) gemm_f32_kernel<MODE_NT, EPI_BIAS_RELU, 16, T128x128, 1, 2><<<grid, NTHREADS, 0, st>>>(p);
+  else return SM3_ERR_INVALID_ARG;
+  return SM3_OK;
+}
+
 }  // namespace sm3gemm

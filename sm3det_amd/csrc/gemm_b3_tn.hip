@@ -19,4 +19,11 @@ int launch_tn_b3(const GemmParams& p, int tile, dim3 grid, hipStream_t st) {
   return SM3_ERR_INVALID_ARG;
 }
 
+
+// 3x3 convolution weight gradient (GATHER = 2: a k-tile of 16 output positions lies inside one image row)
+int launch_tn_b3_conv(const GemmParams& p, dim3 grid, hipStream_t st) {
+  gemm_f32_kernel<MODE_TN, EPI_NONE, 16, T128x128, 2, 2><<<grid, NTHREADS, 0, st>>>(p);
+  return SM3_OK;
+}
+
 }  // namespace sm3gemm

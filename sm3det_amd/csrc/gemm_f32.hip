@@ -377,12 +377,23 @@ size_t colpart_bytes(const sm3_gemm_desc* d, const Cfg& c) {
 
 }  // namespace
 
+// arithmetic of the convolutions (sm3_conv3x3_set_arith): 0 = v_mfma_f32_32x32x2_f32, 2 = the bf16x3 form (three exact bf16
+// pieces per fp32 operand element, six bf16 MFMA products, fp32 accumulation: sm3_gemm_desc.compute == 2), k-step 16
+static int g_conv_arith = 0;
+static inline int conv_bk() { return g_conv_arith == 2 ? 16 : 32; }
+
 #ifdef SM3_TRACE
 static unsigned long long* g_trace = nullptr;
 extern "C" void sm3_gemm_set_trace(void* buf) { g_trace = (unsigned long long*)buf; }  // measurement build only
 #endif
 
 extern "C" {
+
+int sm3_conv3x3_set_arith(int compute) {
+  if (compute != 0 && compute != 2) return SM3_ERR_INVALID_ARG;
+  g_conv_arith = compute;
+  return SM3_OK;
+}
 
 int sm3_gemm_f32_counter_slots(void) { return COUNTER_SLOTS; }
 
@@ -520,6 +531,7 @@ static void conv_geometry(GemmParams& p, int cC, int sH, int sW, int rH, int rW,
 
 constexpr int BM = 128, BN = 128;  // the implicit-GEMM convolutions run on the 128x128 tile
 
+
 static GemmParams conv_params_zero() {
   GemmParams p;
   memset(&p, 0, sizeof(p));
@@ -551,13 +563,13 @@ size_t sm3_conv3x3_nhwc_workspace_bytes(int B, int H, int W, int Cin, int Cout, 
   const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
   const long m = backward_input ? (long)B * H * W : (long)B * Ho * Wo;
   const int n = backward_input ? Cin : Cout, kc = backward_input ? Cout : Cin;
-  const int ks = conv_ksplits(m, n, 9 * kc / 32);
+  const int ks = conv_ksplits(m, n, 9 * kc / conv_bk());
   return ks > 1 ? (size_t)ks * m * n * sizeof(float) : 0;
 }
 
 static int conv_launch_nt_nn(GemmParams& p, int mode, const float* bias, int relu, float* out, void* workspace,
                              size_t workspace_bytes, hipStream_t st) {
-  const int k_tiles = p.K / 32;
+  const int k_tiles = p.K / conv_bk();
   const int ks = conv_ksplits(p.M, p.N, k_tiles);
   const long mn = (long)p.M * p.N;
   if (ks > 1) {  // raw k-slices to the workspace, one reduce pass adds them (+ bias, ReLU)
@@ -574,7 +586,9 @@ static int conv_launch_nt_nn(GemmParams& p, int mode, const float* bias, int rel
   p.fixup = 0;
   dim3 grid(((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM), 1, zs);
   const int epi = mode == MODE_NN ? EPI_NONE : (p.bias && relu ? EPI_BIAS_RELU : (p.bias ? EPI_BIAS : EPI_NONE));
-  const int rc = mode == MODE_NN ? launch_nn(p, epi, 0, 32, 1, grid, st) : launch_nt(p, epi, 0, 32, 1, grid, st);
+  int rc;
+  if (g_conv_arith == 2) rc = mode == MODE_NN ? launch_nn_b3_conv(p, grid, st) : launch_nt_b3_conv(p, epi, grid, st);
+  else rc = mode == MODE_NN ? launch_nn(p, epi, 0, 32, 1, grid, st) : launch_nt(p, epi, 0, 32, 1, grid, st);
   if (rc) return rc;
   if (ks > 1) launch_splitk_reduce((const float*)workspace, out, mn, zs, 1, bias, p.N, relu, st);
   return launch_status();
@@ -592,7 +606,7 @@ int sm3_conv3x3_nhwc_fwd(const float* x, const float* w, const float* bias, floa
   p.M = B * Ho * Wo; p.N = Cout; p.K = 9 * Cin;
   p.lda = Cin; p.ldb = 9 * Cin; p.ldc = Cout; p.ld_aux = Cout;
   p.bias = bias;
-  conv_geometry(p, Cin, H, W, Ho, Wo, stride, 0, 32);
+  conv_geometry(p, Cin, H, W, Ho, Wo, stride, 0, conv_bk());
   return conv_launch_nt_nn(p, MODE_NT, bias, relu, y, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
@@ -605,7 +619,7 @@ int sm3_conv3x3_nhwc_bwd_input(const float* dy, const float* w, float* dx, int B
   p.A = dy; p.B = w;
   p.M = B * H * W; p.N = Cin; p.K = 9 * Cout;
   p.lda = Cout; p.ldb = 9 * Cin; p.ldc = Cin; p.ld_aux = Cin;
-  conv_geometry(p, Cout, Ho, Wo, H, W, stride, 1, 32);
+  conv_geometry(p, Cout, Ho, Wo, H, W, stride, 1, conv_bk());
   return conv_launch_nt_nn(p, MODE_NN, nullptr, 0, dx, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
@@ -642,7 +656,9 @@ int sm3_conv3x3_nhwc_bwd_weight(const float* x, const float* dy, float* dw, int 
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM), 1, p.splits);
   p.fixup = 0;
-  const int rc = launch_tn(p, 0, 16, (Wo % 16) == 0 ? 2 : 1, grid, st);
+  // bf16x3: the row-aligned gather only (a k-tile inside one image row); other widths keep the native fp32 form
+  const int rc = (g_conv_arith == 2 && (Wo % 16) == 0) ? launch_tn_b3_conv(p, grid, st)
+                                                      : launch_tn(p, 0, 16, (Wo % 16) == 0 ? 2 : 1, grid, st);
   if (rc) return rc;
   launch_splitk_reduce((const float*)workspace, dw, (long)p.M * p.N, p.splits, 1, nullptr, 0, 0, st);
   return launch_status();

@@ -214,7 +214,7 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
   // instruction runs at the VECTOR rate (1/16 of the bf16 rate), this form at 6/16 of it.  k-step 16 only (the three
   // planes of a k-step-32 tile would not leave room for two workgroups per CU).
   constexpr bool B3 = (F16 == 2);
-  static_assert(!B3 || (BK == 16 && IO == 0 && !GATHER), "bf16x3 form: k-step 16, fp32 tensors");
+  static_assert(!B3 || (BK == 16 && IO == 0 && !(MODE == MODE_TN && GATHER == 1)), "bf16x3 form: k-step 16, fp32 tensors; TN gather only in the row-aligned form (GATHER == 2)");
   constexpr int NIMG = B3 ? 3 : 1;
   constexpr int LDA16 = BM + 4, LDB16 = BN + 4;                          // rows per k-octet
   constexpr int A_ST16 = (BK / 8) * LDA16 * 4, B_ST16 = (BK / 8) * LDB16 * 4;  // dwords per plane and stage
@@ -576,6 +576,12 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
             int g4, c;
             unit_gc(idx, BN, g4, c);
             ob[i] = (unsigned)(((long)(4 * g4) * p.ldb + min(n0 + c, p.N - 1)) * 4);
+            if (MODE == MODE_TN && GATHER == 2) {
+              // unit = four consecutive output positions (k) of one channel of this N-tile's tap: positions are cS * cC
+              // floats apart in the gathered tensor; kb = the unit's first position inside the k-tile (x-range test)
+              kb[i] = 4 * g4;
+              ob[i] = (unsigned)(((long)(4 * g4) * p.cS * p.cC + (min(n0 + c, p.N - 1) - tn_tap * p.cC)) * 4);
+            }
           }
         }
       }
@@ -671,8 +677,16 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
           const int syp = oy * p.cS + dy;  // source row + 1 (the base is shifted by one row and one pixel)
           const bool yok = syp >= 1 && syp <= p.sH;
           const long soff = ((((long)b * p.sH + syp) * p.sW + oxb * p.cS + dx) * p.cC) * 4;
+          if (F16) {  // four positions of one channel: one 4-byte load each, masked on its own x
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) {
+              const int sxk = (oxb + kb[i] + kk) * p.cS + dx - 1;
+              rb[i][kk] = ldg1(b_rsrc, soff + (long)kk * p.cS * p.cC * 4, (yok && sxk >= 0 && sxk < p.sW) ? ob[i] : 0x7fff0000u);
+            }
+          } else {
           const int sx = (oxb + kb[i]) * p.cS + dx - 1;
           rb[i] = ldg(b_rsrc, soff, (yok && sx >= 0 && sx < p.sW) ? ob[i] : 0x7fff0000u);
+          }
         } else if (GATHER) {
           const int kr = row0 + kt * BK + kb[i];
           const int krc = min(kr, row_end - 1);
@@ -706,7 +720,13 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
         const int kg = kt + kbase;
         const int tap = (int)(((unsigned)kg * p.cInv) >> 16);
         const int c0 = kg * BK - tap * p.cC;
+        if (F16) {  // four consecutive k (output channels of the tap) of one column
+#pragma unroll
+          for (int kk = 0; kk < 4; kk++)
+            rb[i][kk] = ldg1(b_rsrc, ((long)(c0 + kk) * p.ldb + (long)tap * p.N) * 4, ob[i]);
+        } else {
         rb[i] = ldg(b_rsrc, ((long)c0 * p.ldb + (long)tap * p.N) * 4, ob[i]);
+        }
       } else if (F16) {  // NN: B rows are k
 #pragma unroll
         for (int kk = 0; kk < 4; kk++) rb[i][kk] = ldg1(b_rsrc, ((long)kt * BK + kk) * p.ldb * EB, ob[i]);
@@ -1384,6 +1404,10 @@ int launch_tn_h16(const GemmParams& p, int tile, int bk, int io, dim3 grid, hipS
 int launch_nt_b3(const GemmParams& p, int epi, int tile, dim3 grid, hipStream_t st);
 int launch_nn_b3(const GemmParams& p, int epi, int tile, dim3 grid, hipStream_t st);
 int launch_tn_b3(const GemmParams& p, int tile, dim3 grid, hipStream_t st);
+// implicit-GEMM 3x3 convolutions in the bf16x3 form (128x128 tile, k-step 16; weight gradient: the row-aligned gather only)
+int launch_nt_b3_conv(const GemmParams& p, int epi, dim3 grid, hipStream_t st);
+int launch_nn_b3_conv(const GemmParams& p, dim3 grid, hipStream_t st);
+int launch_tn_b3_conv(const GemmParams& p, dim3 grid, hipStream_t st);
 
 
 inline void tile_dims(int tile, int& bm, int& bn) {

@@ -13,9 +13,23 @@ FWD_TOL, BWD_TOL = 1e-4, 1e-3
 
 @pytest.mark.parametrize('B,H,W,Cin,Cout,stride', [
     (2, 16, 16, 128, 128, 1), (1, 32, 32, 256, 256, 1), (2, 9, 13, 128, 64, 1), (1, 16, 16, 128, 128, 2),
-    (2, 7, 5, 256, 96, 2), (1, 4, 4, 768, 256, 2), (1, 1, 1, 128, 128, 2), (3, 2, 2, 128, 256, 1)])
-def test_conv3x3_nhwc_fwd_bwd_vs_torch(B, H, W, Cin, Cout, stride):
+    (2, 7, 5, 256, 96, 2), (1, 4, 4, 768, 256, 2), (1, 1, 1, 128, 128, 2), (3, 2, 2, 128, 256, 1),
+    (1, 32, 32, 128, 128, 2), (1, 64, 48, 256, 256, 1), (2, 32, 64, 256, 128, 1)])
+@pytest.mark.parametrize('arith', ['bf16x3', 'f32'])
+def test_conv3x3_nhwc_fwd_bwd_vs_torch(B, H, W, Cin, Cout, stride, arith):
+    """both arithmetics of the implicit-GEMM convolutions (sm3_conv3x3_set_arith): the bf16x3 form (k-step 16; its weight
+    gradient on the row-aligned gather when the output width is a multiple of 16) and the native fp32 MFMA form"""
+    from sm3det_amd import _lib
+    from sm3det_amd import _lib_backbone as LB
     from sm3det_amd.fpn import conv3x3_nhwc
+    _lib.check(_lib.lib().sm3_conv3x3_set_arith({'bf16x3': 2, 'f32': 0}[arith]), 'conv3x3_set_arith')
+    try:
+        _conv_case(B, H, W, Cin, Cout, stride, conv3x3_nhwc)
+    finally:
+        _lib.lib().sm3_conv3x3_set_arith(LB.ARITH32)
+
+
+def _conv_case(B, H, W, Cin, Cout, stride, conv3x3_nhwc):
     g = torch.Generator().manual_seed(B * 1000 + H * 10 + Cin)
     x = torch.randn(B, Cin, H, W, generator=g)
     w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05
