@@ -603,6 +603,39 @@ def full_model_bench():
         print(f'[bench] full model: hipGraph capture failed ({type(e).__name__}: {e})', file=sys.stderr)
         out['hip_graph'] = False
     torch.cuda.synchronize()
+    # roofline of the full step ("ceilings for backbone-only and full-model separately"): one more eager step with
+    # HIP events around every C-ABI launch; the contraction family = backbone / head GEMMs + the implicit-GEMM 3x3 convolutions
+    try:
+        from sm3det_amd import _lib_backbone as LB
+        best = None
+        for _ in range(2):
+            LB.PROFILE = []
+            step()
+            torch.cuda.synchronize()
+            rec, LB.PROFILE = LB.PROFILE, None
+            tot = sum(e0.elapsed_time(e1) for _n, _f, _b, e0, e1 in rec)
+            if best is None or tot < best[0]:
+                best = (tot, rec)
+        fam = [(n, f, e0.elapsed_time(e1)) for n, f, _b, e0, e1 in best[1] if n.startswith('gemm_f') or n.startswith('conv3x3_')]
+        g_ms, g_fl = sum(t for _, _, t in fam), sum(f for _, f, _ in fam)
+        other = {}
+        for n, _f, _b, e0, e1 in best[1]:
+            if not (n.startswith('gemm_f') or n.startswith('conv3x3_')):
+                other[n.split(' ')[0]] = other.get(n.split(' ')[0], 0.0) + e0.elapsed_time(e1)
+        b3 = LB.ARITH32 == 2
+        peak = MI355X_BF16X3_PEAK_TFLOPS if b3 else MI355X_FP32_MFMA_PEAK_TFLOPS
+        ach = g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
+        out['roofline'] = dict(
+            bound='mfma', kernel='gemm_f32_kernel family (backbone / head GEMMs + implicit-GEMM 3x3 convolutions), ' +
+            ('bf16x3 form' if b3 else 'native fp32 MFMA'), achieved=round(ach, 2), peak=round(peak, 1), unit='TFLOP/s',
+            frac=round(ach / peak, 4), algorithmic_gflop_per_step=round(g_fl / 1e9, 1), launches_per_step=len(fam),
+            gemm_ms_per_step=round(g_ms, 3), conv3x3_ms_per_step=round(sum(t for n, _, t in fam if n.startswith('conv3x3_')), 3),
+            other_library_kernels_ms_per_step=round(sum(other.values()), 3),
+            torch_glue_and_gaps_ms_per_step=round(max(ms - g_ms - sum(other.values()), 0.0), 3),
+            top_other_ms={k: round(v, 3) for k, v in sorted(other.items(), key=lambda kv: -kv[1])[:10]},
+            note='per-launch HIP-event brackets of one eager step (they add launch gaps); ms_per_step_graph is the replayed step')
+    except Exception as e:  # noqa: BLE001
+        out['roofline'] = dict(error=f'{type(e).__name__}: {e}'[:200])
     out['losses_first_step'] = first
     out['losses_last_step'] = {k: round(float(v), 5) for k, v in logs.items()}
     out['imgs_per_sec'] = round(sum(mix.values()) / (ms * 1e-3), 2)

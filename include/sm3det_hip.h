@@ -407,6 +407,11 @@ size_t sm3_row_reduce_workspace_bytes(int C);
  * side stream, since the results are parameter gradients (ncols = 2C, 2C, C respectively). */
 int sm3_row_partial_blocks(long T, int C);
 int sm3_row_partials_reduce(const float* partials, int nblocks, int ncols, float* out, sm3_stream_t stream);
+/* n such reductions in one launch (chunks of 64): partials / outs / nblocks / ncols are HOST arrays of n entries (device
+ * pointers and sizes as for sm3_row_partials_reduce); the table travels in the kernel arguments, so the call is capturable.
+ * Used to run the parameter-gradient reductions of a whole backward pass together when the pass ends. */
+int sm3_row_partials_reduce_multi(const float* const* partials, float* const* outs, const int* nblocks, const int* ncols,
+                                  int n, sm3_stream_t stream);
 int sm3_layernorm_bwd(const float* dy, const float* x, const float* w, const float* mean, const float* rstd,
                       float* dx, float* dwdb, long T, int C, int out_mode, int H, int W, int accumulate_dx,
                       void* workspace, size_t workspace_bytes, sm3_stream_t stream);

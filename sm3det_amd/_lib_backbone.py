@@ -61,6 +61,7 @@ def signatures():
         'sm3_sumpool2x_add': (I, [P, P, P, I, I, I, I, P]),
         'sm3_row_partial_blocks': (I, [LL, I]),
         'sm3_row_partials_reduce': (I, [P, I, I, P, P]),
+        'sm3_row_partials_reduce_multi': (I, [P, P, P, P, I, P]),
         'sm3_moe_router_partial_rows': (I, [I]),
         'sm3_moe_router_fwd': (I, [P, I, I, P, P, P, I, I, I, I, P, P, P, P, P, P, P, P, P]),
         'sm3_moe_router_bwd': (I, [P, I, I, P, P, P, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P]),

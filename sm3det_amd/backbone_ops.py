@@ -87,11 +87,55 @@ def _join_side(device):
         torch.cuda.current_stream(device).wait_stream(_side_stream(device))
 
 
-def _deferred_reduce(ws, T, C, ncols, out):
-    """column reduction of a row kernel's per-workgroup partials (parameter gradients) on the side stream"""
+# The column reductions of the row kernels' per-workgroup partials produce PARAMETER gradients (d LayerNorm weight / bias,
+# d layer scale, d bias): nothing in the backward chain reads them.  They are collected while the backward pass runs and
+# reduced by ONE launch when it ends (autograd's end-of-pass callback), instead of one ~5 us launch each -- 36 per
+# ConvNeXt-T training step, all at the launch floor.  SM3_BATCH_REDUCE=0 restores the per-call launches.
+BATCH_REDUCE = os.environ.get('SM3_BATCH_REDUCE', '1') == '1'
+_PENDING_REDUCE = {}  # device index -> [(workspace, rows, columns, out)]
+
+
+def flush_deferred_reductions(device=None):
+    """run the collected reductions now (autograd calls this at the end of a backward pass; call it yourself if the
+    backward functions of this module are driven without autograd)"""
+    import ctypes
+    from . import _lib
+    for di in ([device.index if hasattr(device, 'index') else device] if device is not None else list(_PENDING_REDUCE)):
+        items = _PENDING_REDUCE.pop(di, [])
+        if not items:
+            continue
+        n = len(items)
+        P = (ctypes.c_void_p * n)(*[it[0].data_ptr() for it in items])
+        O = (ctypes.c_void_p * n)(*[it[3] for it in items])
+        NB = (ctypes.c_int * n)(*[it[1] for it in items])
+        NC = (ctypes.c_int * n)(*[it[2] for it in items])
+        with torch.cuda.device(di), LB._Prof('row_partials_reduce'):
+            _lib.check(_lib.lib().sm3_row_partials_reduce_multi(P, O, NB, NC, n, _lib.stream_ptr()), 'row_partials_reduce_multi')
+
+
+def _deferred_reduce(ws, T, C, ncols, out, params=()):
+    """column reduction of a row kernel's per-workgroup partials (parameter gradients): batched at the end of the backward
+    pass, or (SM3_BATCH_REDUCE=0) one launch now, on the side stream when that is on.  `params`: the parameters `out` is
+    the gradient of -- if one already HAS a gradient, autograd will add `out` to it as soon as this backward function
+    returns, so the reduction cannot wait (gradient accumulation; never the case in the training step, which adopts
+    gradients)."""
     from . import _lib
     nblk = _lib.lib().sm3_row_partial_blocks(T, C)
-    _on_side(out.device, lambda: call('row_partials_reduce', ws, nblk, ncols, out))
+    if not BATCH_REDUCE or OVERLAP_WGRAD or any(getattr(q, 'grad', None) is not None for q in params):
+        _on_side(out.device, lambda: call('row_partials_reduce', ws, nblk, ncols, out))
+        return
+    lst = _PENDING_REDUCE.setdefault(out.device.index, [])
+    if not lst:
+        try:
+            di = out.device.index
+            torch.autograd.Variable._execution_engine.queue_callback(lambda: flush_deferred_reductions(di))
+        except RuntimeError:  # not inside a backward pass (a backward function called by hand): reduce now
+            call('row_partials_reduce', ws, nblk, ncols, out)
+            return
+    # the workspace tensor and the output's STORAGE are kept alive until the flush -- the storage, not the tensor: another
+    # reference to the gradient tensor itself would make autograd's AccumulateGrad clone it (before it is filled) instead of
+    # adopting it as p.grad
+    lst.append((ws, nblk, ncols, out.data_ptr(), out.untyped_storage()))
 
 
 def _tn(dy, x, M, N, rows, **kw):
@@ -293,7 +337,7 @@ def _dw_ln_backward(dxn, dout, x, u, w49, lnw, mean, rstd, B, H, W, C):
     dwdb = _e(2, C, like=x)
     ws, nb = LB.row_ws(C, x)
     call('layernorm_bwd', dxn, u, lnw, mean, rstd, du, None, T, C, 0, H, W, 0, ws, nb, nbytes=12.0 * T * C)
-    _deferred_reduce(ws, T, C, 2 * C, dwdb)  # d(ln weight) | d(ln bias); joined by the caller
+    _deferred_reduce(ws, T, C, 2 * C, dwdb, params=(lnw,))  # d(ln weight) | d(ln bias); joined by the caller
     dwb = _e(50, C, like=x)  # [dw49 (49,C); dbias (C)] in one buffer: one fill inside the kernel wrapper
     dw49, dbdw = dwb[:49], dwb[49]
     _on_side(x.device, lambda: call('dwconv7_bwd_weight', x, du, dw49, dbdw, B, H, W, C,
@@ -338,7 +382,7 @@ class _DenseBlock(Function):
         ws, nb = LB.row_ws(C, x)
         dev = x.device
         call('scale_bwd_prep', dout, y, gamma, rs, H * W, dy, None, T, C, ws, nb, nbytes=12.0 * T * C)
-        _deferred_reduce(ws, T, C, 2 * C, dgdb)
+        _deferred_reduce(ws, T, C, 2 * C, dgdb, params=(gamma,))
         dgamma, db2 = dgdb[0], dgdb[1]
         dw2 = _on_side(dev, lambda: _tn(dy, act, C, Hd, T))
         dh, db1 = _e(T, Hd, like=x, dtype=hpre.dtype), _e(Hd, like=x)
@@ -471,7 +515,7 @@ class _MoEBlock(Function):
         ws, nb = LB.row_ws(C, x)
         call('moe_combine_bwd', dout, yslot, token_slot, gates, gamma, rs, H * W, dyslot, dgate, None, T, C, k, ws, nb,
              nbytes=4.0 * (2 * k + 1) * T * C)
-        _deferred_reduce(ws, T, C, C, dgamma)
+        _deferred_reduce(ws, T, C, C, dgamma, params=(gamma,))
         # experts backward (every expert gets a -- possibly zero -- gradient: DDP-safe); weight gradients on the side
         # stream, the dx chain on this one
         dev = x.device

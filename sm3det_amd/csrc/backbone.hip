@@ -749,6 +749,54 @@ int sm3_layernorm_fwd(const float* x, const float* w, const float* b, float eps,
   return launch_status();
 }
 
+// The same reduction for up to PRM_MAX (partials, out) pairs in ONE launch: the parameter gradients the row kernels of a
+// whole backward pass leave as per-workgroup partial rows (d LayerNorm weight / bias, d layer scale, d bias of every block:
+// 36 pairs per ConvNeXt-T step) are only needed by the optimizer, so their reductions are collected and run together when
+// the backward pass ends (36 launches of ~5 us at the launch floor -> 1).  The table travels by value in the kernel
+// arguments: nothing to upload, capturable.
+constexpr int PRM_MAX = 64;
+struct PartialsTable {
+  const float* partials[PRM_MAX];
+  float* out[PRM_MAX];
+  int nblocks[PRM_MAX], ncols[PRM_MAX], block0[PRM_MAX + 1];
+  int n;
+};
+__global__ __launch_bounds__(PR_THREADS) void partials_reduce_multi_kernel(const PartialsTable t) {
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  __shared__ v4 red[64][17];
+  int e = 0;
+  while (e + 1 < t.n && (int)blockIdx.x >= t.block0[e + 1]) e++;
+  const float* __restrict__ partials = t.partials[e];
+  const int nblocks = t.nblocks[e], ncols = t.ncols[e], bx = blockIdx.x - t.block0[e];
+  const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = bx * 64 + 4 * cq;
+  v4 s[8];
+#pragma unroll
+  for (int u = 0; u < 8; u++) s[u] = v4{0.f, 0.f, 0.f, 0.f};
+  if (c < ncols) {
+    for (int b = rl; b < nblocks; b += 512) {
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int r = b + 64 * u;
+        const v4 v = *reinterpret_cast<const v4*>(partials + (long)min(r, nblocks - 1) * ncols + c);
+        if (r < nblocks) s[u] += v;
+      }
+    }
+  }
+  red[rl][cq] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));  // same order as the single form
+  __syncthreads();
+  if (threadIdx.x < 256) {
+    const int col = threadIdx.x >> 2, part = threadIdx.x & 3;
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; i++) v += red[16 * part + i][col >> 2][col & 3];
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    const int oc = bx * 64 + col;
+    if (part == 0 && oc < ncols) t.out[e][oc] = v;
+  }
+}
+
 // number of per-workgroup partial rows the row kernels (layernorm_bwd, scale_bwd_prep, moe_combine_bwd) leave in the
 // workspace for (T, C); with the reduction output pointer NULL those kernels skip their own reduce and the caller
 // runs sm3_row_partials_reduce -- on another stream if it likes (the results are parameter gradients).
@@ -764,6 +812,26 @@ int sm3_row_partial_blocks(long T, int C) {
 int sm3_row_partials_reduce(const float* partials, int nblocks, int ncols, float* out, sm3_stream_t stream) {
   if (!partials || !out || nblocks <= 0 || ncols <= 0 || (ncols & 3)) return SM3_ERR_INVALID_ARG;  // 16-byte column quads
   partials_reduce_kernel<<<(ncols + 63) / 64, PR_THREADS, 0, (hipStream_t)stream>>>(partials, nblocks, ncols, out);
+  return launch_status();
+}
+
+int sm3_row_partials_reduce_multi(const float* const* partials, float* const* outs, const int* nblocks, const int* ncols,
+                                  int n, sm3_stream_t stream) {
+  if (n < 0 || (n > 0 && (!partials || !outs || !nblocks || !ncols))) return SM3_ERR_INVALID_ARG;
+  for (int i0 = 0; i0 < n; i0 += PRM_MAX) {
+    PartialsTable t;
+    t.n = n - i0 < PRM_MAX ? n - i0 : PRM_MAX;
+    int blocks = 0;
+    for (int i = 0; i < t.n; i++) {
+      const int j = i0 + i;
+      if (!partials[j] || !outs[j] || nblocks[j] <= 0 || ncols[j] <= 0 || (ncols[j] & 3)) return SM3_ERR_INVALID_ARG;
+      t.partials[i] = partials[j]; t.out[i] = outs[j]; t.nblocks[i] = nblocks[j]; t.ncols[i] = ncols[j];
+      t.block0[i] = blocks;
+      blocks += (ncols[j] + 63) / 64;
+    }
+    t.block0[t.n] = blocks;
+    partials_reduce_multi_kernel<<<blocks, PR_THREADS, 0, (hipStream_t)stream>>>(t);
+  }
   return launch_status();
 }
 

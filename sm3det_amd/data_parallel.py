@@ -138,6 +138,10 @@ class BucketedGradReducer:
         b = self.buckets[self._index[p]]
         b['pending'] -= 1
         if b['pending'] == 0 and self.comm and self.overlap:
+            # parameter gradients whose column reductions are batched at the end of the backward pass (backbone_ops) must
+            # hold their values before this bucket is packed in the middle of it
+            from . import backbone_ops
+            backbone_ops.flush_deferred_reductions()
             self._pack(b)
             b['handle'] = dist.all_reduce(b['flat'], op=self._op, group=self.group, async_op=True)
 
