@@ -1112,6 +1112,10 @@ def main():
                        'grad_buckets': reducer.num_buckets, 'hip_graph': bool(use_graph),
                        'wgrad_side_stream': bool(overlap_was), 'split_backward': bool(split and use_graph),
                        'dist_backend': (backend if multi else None), 'collective_avg': bool(reducer._avg),
+                       # share of the gradient bytes the backward kernels wrote straight into the bucket slices (no pack copy)
+                       'grad_bytes_in_place_frac': (round(reducer.pack_stats['in_place_bytes'] /
+                                                          max(reducer.pack_stats['in_place_bytes'] +
+                                                              reducer.pack_stats['copied_bytes'], 1), 4) if multi else None),
                        'replica_checksum_spread': replica_spread},
             'loss': float(loss.detach()),
             'roofline': roofline,

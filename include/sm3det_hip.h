@@ -445,12 +445,13 @@ int sm3_moe_router_fwd(const float* hcat, int ldh, int P, const float* snorm, co
                        int T, int E, int k, int train, int32_t* top_idx, float* top_val, float* gates, float* clean,
                        float* sigma, float* hnorm, float* partials, const int32_t* forced_topk, sm3_stream_t stream);
 /* backward: dgate (T,k) from the combine, dimp/dload (E) from the aux loss.  Writes dhcat (T,ldh) = [dh | draw | 0],
- * dcn (T,E) = dclean/max(|h|,eps) and ds_part (sm3_moe_router_partial_rows(T), DOUBLE) partial sums of d(scale). */
+ * dcn (T,E) = dclean/max(|h|,eps) and ds_part (sm3_moe_router_partial_rows(T), DOUBLE) partial sums of d(scale); ds_sq (same
+ * size, may be NULL): per workgroup the sum of the SQUARED per-token terms of that sum (its conditioning, for tests). */
 int sm3_moe_router_bwd(const float* hcat, int ldh, int P, const float* snorm, const float* scale, const float* noise,
                        int T, int E, int k, int train, const int32_t* top_idx, const float* top_val,
                        const float* gates, const float* clean, const float* sigma, const float* hnorm,
                        const float* dgate, const float* dimp, const float* dload, float* dhcat, float* dcn,
-                       double* ds_part, sm3_stream_t stream);
+                       double* ds_part, double* ds_sq, sm3_stream_t stream);
 
 /* Gate parameter preparation, one launch (CosineTopKGate.forward :96-105 + the `x @ w_noise` operand :199-201):
  * wcat (PC,C) = [cosine_projector.weight (P,C); w_noise^T (E,C); 0], bcat (PC) = [cosine_projector.bias; 0],

@@ -48,6 +48,8 @@ PY
                   python -c "import json; r=json.loads([l for l in open('$O/bench_full.json') if l.startswith('{')][-1]); print(r['ms_per_step']); print(json.dumps(r.get('full_model'))[:1500])"; tail -3 $O/bench_full.err ;;
     heads2)       timeout 900 python -m pytest tests/test_assign_gpu.py tests/test_gfl_gpu.py tests/test_rpn_gpu.py tests/test_detector_gpu.py tests/test_detector_slice_gpu.py tests/test_losses_gpu.py -x -q 2>&1 | tail -6 | tee $O/heads2_tests.txt ;;
     fpn)          timeout 900 python -m pytest tests/test_fpn_gpu.py tests/test_gfl_gpu.py -x -q 2>&1 | tail -8 | tee $O/fpn_tests.txt ;;
+    dp)           timeout 1500 python -m pytest tests/test_dp_rccl_gpu.py -x -q 2>&1 | tail -8 | tee $O/dp_tests.txt ;;
+    amp_full)     timeout 1500 python -m pytest tests/test_fullsize_gpu.py -x -q -k amp 2>&1 | tail -5 | tee $O/amp_full_tests.txt ;;
     smoke)        timeout 600 python __graft_entry__.py --smoke 2>&1 | tail -3 ;;
     *) echo "unknown step $step" ;;
   esac

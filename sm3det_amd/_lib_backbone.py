@@ -64,7 +64,7 @@ def signatures():
         'sm3_row_partials_reduce_multi': (I, [P, P, P, P, I, P]),
         'sm3_moe_router_partial_rows': (I, [I]),
         'sm3_moe_router_fwd': (I, [P, I, I, P, P, P, I, I, I, I, P, P, P, P, P, P, P, P, P]),
-        'sm3_moe_router_bwd': (I, [P, I, I, P, P, P, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+        'sm3_moe_router_bwd': (I, [P, I, I, P, P, P, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
         'sm3_moe_gate_prep_fwd': (I, [P, P, P, P, P, F, I, I, I, I, P, P, P, P, P]),
         'sm3_moe_gate_prep_bwd': (I, [P, P, P, P, I, P, P, F, I, I, I, P, P, P, P, P, P]),
         'sm3_moe_aux_loss_fwd': (I, [P, I, I, F, P, P, P]),

@@ -138,22 +138,34 @@ def _deferred_reduce(ws, T, C, ncols, out, params=()):
     lst.append((ws, nblk, ncols, out.data_ptr(), out.untyped_storage()))
 
 
-def _tn(dy, x, M, N, rows, **kw):
+def _bucket_out(param, *shape):
+    """the slice of the data-parallel gradient bucket that belongs to `param` (BucketedGradReducer hangs it on the
+    parameter), as a FRESH tensor object over that memory -- or None.  A weight-gradient GEMM that writes there makes the
+    reducer's pack pass a no-op for that tensor (the FFN / expert weights are 95 % of the gradient bytes), and autograd
+    adopts the fresh object as p.grad without a copy (another reference to the same tensor object would make it clone)."""
+    v = getattr(param, '_sm3_grad_view', None)
+    if v is None or tuple(v.shape) != tuple(shape) or v.dtype != torch.float32 or not v.is_contiguous():
+        return None
+    return v.detach()
+
+
+def _tn(dy, x, M, N, rows, out=None, **kw):
     """dW[M,N] = dy[rows,M]^T @ x[rows,N] (split-K)."""
     groups = kw.get('num_groups', 1)
-    out = _e(groups, M, N, like=dy) if groups > 1 or kw.get('offsets') is not None else _e(M, N, like=dy)
+    if out is None:
+        out = _e(groups, M, N, like=dy) if groups > 1 or kw.get('offsets') is not None else _e(M, N, like=dy)
     gemm(LB.TN, dy, x, out, M, N, rows, **kw)  # split-K factor and fix-up chosen by the library
     return out
 
 
-def _tn_bias(dy, x, M, N, rows, db, **kw):
+def _tn_bias(dy, x, M, N, rows, db, out=None, **kw):
     """dW = dy^T x and db = column sums of dy in one launch: the TN kernel sums the rows of its A operand while it
     loads them (no separate column-sum kernel, no zero-fill, dy is read once).  Only an fp16-STORED dy keeps the
     separate kernel (the C-wide gradients of the AMP data path are fp32)."""
     if dy.dtype == torch.float32:
-        return _tn(dy, x, M, N, rows, colsum_out=db, **kw)
+        return _tn(dy, x, M, N, rows, out=out, colsum_out=db, **kw)
     colsum(dy, rows, M, db, offsets=kw.get('offsets'), num_groups=kw.get('num_groups', 1))
-    return _tn(dy, x, M, N, rows, **kw)
+    return _tn(dy, x, M, N, rows, out=out, **kw)
 
 
 # ------------------------------------------------------------------------------------------------ linear
@@ -356,6 +368,7 @@ class _DenseBlock(Function):
         Hd = w1.shape[0]
         u, xn, mean, rstd = _dw_ln_forward(x, w49, bdw, lnw, lnb, eps, B, H, W, C)
         hpre, act = _e(T, Hd, like=x, dtype=xn.dtype), _e(T, Hd, like=x, dtype=xn.dtype)
+        ctx.wparams = (w1, w2)  # the parameters themselves (their data-parallel bucket slices receive the gradients)
         w1, w2 = _shadow(w1), _shadow(w2)
         gemm(LB.NT, xn, w1, act, T, Hd, C, epilogue=LB.EPI_BIAS_GELU, bias=b1, aux_out=hpre)  # hpre := gelu'(h)
         y, out = _e(T, C, like=x), _e(T, C, like=x)
@@ -384,10 +397,11 @@ class _DenseBlock(Function):
         call('scale_bwd_prep', dout, y, gamma, rs, H * W, dy, None, T, C, ws, nb, nbytes=12.0 * T * C)
         _deferred_reduce(ws, T, C, 2 * C, dgdb, params=(gamma,))
         dgamma, db2 = dgdb[0], dgdb[1]
-        dw2 = _on_side(dev, lambda: _tn(dy, act, C, Hd, T))
+        pw1, pw2 = getattr(ctx, 'wparams', (None, None))
+        dw2 = _on_side(dev, lambda: _tn(dy, act, C, Hd, T, out=_bucket_out(pw2, C, Hd)))
         dh, db1 = _e(T, Hd, like=x, dtype=hpre.dtype), _e(Hd, like=x)
         gemm(LB.NN, dy, w2, dh, T, Hd, C, epilogue=LB.EPI_GELU_BWD, aux_in=hpre, colsum_out=db1)
-        dw1 = _on_side(dev, lambda: _tn(dh, xn, Hd, C, T))
+        dw1 = _on_side(dev, lambda: _tn(dh, xn, Hd, C, T, out=_bucket_out(pw1, Hd, C)))
         dxn = _e(T, C, like=x)  # not dy's buffer: the side-stream wgrad may still be reading dy
         gemm(LB.NN, dh, w1, dxn, T, C, Hd)
         dx, dw49, dbdw, dlnw, dlnb = _dw_ln_backward(dxn, dout, x, u, w49, lnw, mean, rstd, B, H, W, C)
@@ -471,6 +485,7 @@ class _MoEBlock(Function):
             call('moe_dispatch', xn, slot_token, xslot, S, C, nbytes=8.0 * S * C)
         # experts: grouped GEMM pair over the expert-major slots
         hpre, act = _e(S, Hd, like=x, dtype=xn.dtype), _e(S, Hd, like=x, dtype=xn.dtype)
+        ctx.wparams = (w1, w2)  # the parameters themselves (their data-parallel bucket slices receive the gradients)
         w1, w2 = _shadow(w1), _shadow(w2)
         gemm(LB.NT, xslot, w1, act, S, Hd, C, epilogue=LB.EPI_BIAS_GELU, bias=b1, aux_out=hpre, offsets=offsets,
              num_groups=E)
@@ -521,20 +536,23 @@ class _MoEBlock(Function):
         dev = x.device
         db2 = _e(E, C, like=x)
 
-        dw2 = _on_side(dev, lambda: _tn_bias(dyslot, act, C, Hd, S, db2, offsets=offsets, num_groups=E))
+        pw1, pw2 = getattr(ctx, 'wparams', (None, None))
+        dw2 = _on_side(dev, lambda: _tn_bias(dyslot, act, C, Hd, S, db2, out=_bucket_out(pw2, E, C, Hd), offsets=offsets,
+                                             num_groups=E))
         dh, db1 = _e(S, Hd, like=x, dtype=hpre.dtype), _e(E, Hd, like=x)
         gemm(LB.NN, dyslot, w2, dh, S, Hd, C, epilogue=LB.EPI_GELU_BWD, aux_in=hpre, offsets=offsets, num_groups=E,
              colsum_out=db1)
-        dw1 = _on_side(dev, lambda: _tn(dh, xslot, Hd, C, S, offsets=offsets, num_groups=E))
+        dw1 = _on_side(dev, lambda: _tn(dh, xslot, Hd, C, S, out=_bucket_out(pw1, E, Hd, C), offsets=offsets, num_groups=E))
         dxslot = _e(S, C, like=x)  # not dyslot's buffer: the side-stream wgrad may still be reading it
         gemm(LB.NN, dh, w1, dxslot, S, C, Hd, offsets=offsets, num_groups=E)
         # router backward
         nblk = _lib.lib().sm3_moe_router_partial_rows(T)
         dhcat, dcn, ds_part = _e(T, PC, like=x), _e(T, E, like=x), _e(nblk, like=x, dtype=torch.float64)
+        ds_sq = _e(nblk, like=x, dtype=torch.float64) if DEBUG_DSCALE is not None else None
         call('moe_router_bwd', hcat, PC, P, snorm, scale, noise, T, E, k, int(train), top_idx, top_val, gates, clean,
-             sigma, hnorm, dgate, dimp_load, dimp_load[E:], dhcat, dcn, ds_part, nbytes=4.0 * T * (2 * PC + 6 * E))
-        if DEBUG_DSCALE is not None:
-            DEBUG_DSCALE.append(ds_part)
+             sigma, hnorm, dgate, dimp_load, dimp_load[E:], dhcat, dcn, ds_part, ds_sq, nbytes=4.0 * T * (2 * PC + 6 * E))
+        if DEBUG_DSCALE is not None:  # (per-workgroup sums, per-workgroup sums of the squared per-token terms)
+            DEBUG_DSCALE.append((ds_part, ds_sq))
         # gate parameters ([Wp; Wn^T] rows, normalize and exp(clamp) backward in one launch) -- side stream
         if sim is None:  # linear gate: wp is w_gate (C, E)
             dwp, dwn = _e(C, E, like=x), _e(C, E, like=x)

@@ -279,7 +279,7 @@ __global__ __launch_bounds__(RT_THREADS) void moe_router_bwd_kernel(
     const float* __restrict__ top_val, const float* __restrict__ gates, const float* __restrict__ clean_i,
     const float* __restrict__ sigma_i, const float* __restrict__ hnorm_i, const float* __restrict__ dgate,
     const float* __restrict__ dimp, const float* __restrict__ dload, float* __restrict__ dhcat,
-    float* __restrict__ dcn, double* __restrict__ ds_part) {
+    float* __restrict__ dcn, double* __restrict__ ds_part, double* __restrict__ ds_sq) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* s_s = sm;
   float* hs = sm + (long)P * ET;  // [16][P+1]: h on the way in, dh on the way out
@@ -435,10 +435,16 @@ __global__ __launch_bounds__(RT_THREADS) void moe_router_bwd_kernel(
       for (int c = P + E; c < ldh; c++) dh[c] = 0.f;
     }
   }
-  double a = ds_local;
+  double a = ds_local, q = ds_local * ds_local;  // q: the PER-TOKEN terms' squares (conditioning of the sum, tests)
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
-  if (threadIdx.x == 0) ds_part[blockIdx.x] = a;
+  for (int o = 32; o > 0; o >>= 1) {
+    a += __shfl_xor(a, o, 64);
+    q += __shfl_xor(q, o, 64);
+  }
+  if (threadIdx.x == 0) {
+    ds_part[blockIdx.x] = a;
+    if (ds_sq) ds_sq[blockIdx.x] = q;
+  }
 }
 
 }  // namespace
@@ -473,7 +479,7 @@ int sm3_moe_router_bwd(const float* hcat, int ldh, int P, const float* snorm, co
                        int T, int E, int k, int train, const int32_t* top_idx, const float* top_val,
                        const float* gates, const float* clean, const float* sigma, const float* hnorm,
                        const float* dgate, const float* dimp, const float* dload, float* dhcat, float* dcn,
-                       double* ds_part, sm3_stream_t stream) {
+                       double* ds_part, double* ds_sq, sm3_stream_t stream) {
   if (!hcat || (snorm && !scale) || !top_idx || !top_val || !gates || !clean || !hnorm || !dgate || !dimp || !dload ||
       !dhcat || !dcn || !ds_part)
     return SM3_ERR_INVALID_ARG;
@@ -485,7 +491,7 @@ int sm3_moe_router_bwd(const float* hcat, int ldh, int P, const float* snorm, co
 #define CALL(ET)                                                                                                   \
   moe_router_bwd_kernel<ET><<<nblk, RT_THREADS, ((size_t)P * ET + (size_t)RT_TOKENS * (P + 1)) * sizeof(float), st>>>( \
       hcat, ldh, P, snorm, scale, noise, T, E, k, train, top_idx, top_val, gates, clean, sigma, hnorm, dgate, dimp,    \
-      dload, dhcat, dcn, ds_part)
+      dload, dhcat, dcn, ds_part, ds_sq)
   if (E <= 4) CALL(4);
   else if (E <= 8) CALL(8);
   else if (E <= 16) CALL(16);

@@ -65,6 +65,7 @@ class BucketedGradReducer:
                 cur_bytes += nbytes
             if cur:
                 self._close(cur, gi)
+        self.pack_stats = dict(copied_bytes=0, in_place_bytes=0)  # cumulative over the packs issued from Python
         self._index = {}
         for bi, b in enumerate(self.buckets):
             for p in b['params']:
@@ -85,6 +86,9 @@ class BucketedGradReducer:
             for p in plist:
                 n = p.numel()
                 views.append(flat[off:off + n].view_as(p))
+                # backward kernels that know their parameter write the gradient straight into the bucket slice
+                # (backbone_ops._bucket_out: the FFN / expert weight gradients, 95 % of the bytes) -> _pack copies nothing
+                p._sm3_grad_view = views[-1]
                 off += n
         self.buckets.append(dict(flat=flat, params=plist, views=views, pending=len(plist), handle=None,
                                  packed=False, group=group))
@@ -111,6 +115,9 @@ class BucketedGradReducer:
             elif p.grad.data_ptr() != v.data_ptr():
                 src.append(p.grad)
                 dst.append(v)
+                self.pack_stats['copied_bytes'] += p.numel() * p.element_size()
+            else:  # the backward wrote this gradient into the bucket slice itself
+                self.pack_stats['in_place_bytes'] += p.numel() * p.element_size()
         if src:
             torch._foreach_copy_(dst, src)
         b['packed'] = True

@@ -36,6 +36,9 @@ def test_split_backward_graph_replay_with_rccl_collectives_world_size_1():
     assert cfg['dist_backend'] == 'nccl' and cfg['collective_avg'] is True
     assert cfg['hip_graph'] is True and cfg['split_backward'] is True
     assert cfg['grad_buckets'] >= 2 and cfg['replica_checksum_spread'] == 0.0
+    # the FFN / expert weight gradients (95 % of the bytes) are written by the weight-gradient GEMMs straight into their
+    # bucket slices: the pack pass copies only the small tensors
+    assert cfg['grad_bytes_in_place_frac'] >= 0.9, cfg['grad_bytes_in_place_frac']
     plain, _ = _bench({})
     assert plain['config']['dist_backend'] is None and plain['config']['split_backward'] is False
     # identical data, seeds and step count: the averaged (1-rank) gradients are the gradients
