@@ -650,6 +650,166 @@ def full_model_bench():
     return out
 
 
+def full_model_dp_main(args, world, rank, multi, backend, force_dist):
+    """`--workload full_model`: the data-parallel training step of the WHOLE detector (BASELINE configs #3 / #5 are detector
+    DDP runs): every rank holds the 178 M-parameter TriSourceDetector and its own synthetic native mix (2 SAR + 1 RGB + 1 IR
+    @1024^2); graph 1 = forward + all losses + backward, gradients landing in / packed into 64 MiB buckets; then ONE
+    all-reduce of the stacked log_vars (mmdet's `_parse_losses` issues one blocking all-reduce + .item() per loss: ~15) and
+    the bucket all-reduces (RCCL, ReduceOp.AVG); graph 2 = the dynamic-lr policy on the REDUCED losses (as the reference's hook
+    sees them) + grad-clip + AdamW.  Same timing contract as the headline; prints the one JSON line."""
+    import copy
+    import numpy as np
+    import torch.distributed as dist
+    from sm3det_amd import detector  # noqa: F401
+    from sm3det_amd import _lib_backbone as LB
+    from sm3det_amd.data_parallel import BucketedGradReducer
+    from sm3det_amd.optim import DeviceDynamicLr, MultiTensorAdamW
+    from sm3det_amd.registry import MODELS
+    from tests import synth
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    cfg_entry = load_config(DEFAULT_CONFIG)
+    m = copy.deepcopy(cfg_entry['model'])
+    m['backbone'].pop('init_cfg', None)
+    torch.manual_seed(2)
+    det = MODELS.build(m).cuda().train()
+    for h in (det.rgb_rpn_head, det.rgb_roi_head, det.ifr_rpn_head, det.ifr_roi_head):
+        h.init_weights()
+    with torch.no_grad():
+        for n, q in det.backbone.named_parameters():
+            if n.endswith('gamma'):
+                q.fill_(1.0)
+    mix = dict(sar=2, rgb=1, ifr=1)
+    g = torch.Generator().manual_seed(3 + rank)  # every rank its own shard
+    img = {s_: torch.randn(n, 3, RES, RES, generator=g).cuda() for s_, n in mix.items()}
+    metas = {s_: [dict(img_shape=(RES, RES, 3), pad_shape=(RES, RES, 3)) for _ in range(n)] for s_, n in mix.items()}
+    gtb = {s_: [dev(synth.hboxes(8, 80 + i + 100 * rank, extent=float(RES))) if s_ == 'sar' else
+                dev(synth.rotated_boxes(8, 90 + i + 5 * (s_ == 'ifr') + 100 * rank)) for i in range(n)] for s_, n in mix.items()}
+    gtl = {s_: [torch.randint(0, 26, (8,), generator=g).cuda() for _ in range(n)] for s_, n in mix.items()}
+    named = [(n, q) for n, q in det.named_parameters() if q.requires_grad]
+    params = [q for _, q in named]
+    reducer = BucketedGradReducer(params, bucket_mb=64.0, force_comm=force_dist)
+    reducer.broadcast_parameters(0, module=det)
+    reducer.overlap = False
+    opt = MultiTensorAdamW([dict(params=[q]) for q in params], lr=1e-4, betas=(0.9, 0.999), weight_decay=0.05, max_grad_norm=35.0)
+    lrc = dict(cfg_entry.get('lr_config') or {})
+    lrc.pop('policy', None)
+    for q in params:
+        q.grad = torch.zeros_like(q)
+    dla = DeviceDynamicLr(opt, [n for n, _ in named], **lrc)
+    state = {}
+
+    def fwd_bwd():
+        reducer.zero_grad()
+        losses = det.forward_train_gathered(img, metas, gtb, gtl)
+        total, lv = det.parse_losses(losses)
+        total.backward()
+        reducer.pack_all()
+        state['keys'] = list(lv)
+        state['lv'] = torch.stack([v.detach().float().reshape(()) for v in lv.values()])  # one vector: one collective
+
+    def reduce_and_step():
+        lv = state['lv']
+        if multi and world > 1:
+            dist.all_reduce(lv, op=dist.ReduceOp.SUM)
+            lv = lv / world
+        state['lv_mean'] = lv
+        reducer.finalize(repack=False)
+        dla.update({k: lv[i] for i, k in enumerate(state['keys'])})
+        opt.step()
+
+    def step():
+        fwd_bwd()
+        reduce_and_step()
+
+    def fence():
+        if multi:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()
+        torch.cuda.synchronize()
+        dla.fast_forward(int(lrc.get('warmup_iters') or 0))
+        step()
+    torch.cuda.current_stream().wait_stream(side)
+    fence()
+    run, use_graph = step, False
+    if not args.no_graph:
+        cap_kw = dict(capture_error_mode='thread_local') if multi else {}
+        try:
+            g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1, **cap_kw):
+                fwd_bwd()
+            keep = [q.grad for q in params]  # noqa: F841
+            g1.replay()
+            reducer.finalize(repack=False)
+            opt.refresh_grad_pointers()
+            lv_buf = state['lv']
+            with torch.cuda.graph(g2, pool=g1.pool(), **cap_kw):
+                dla.update({k: lv_buf[i] for i, k in enumerate(state['keys'])})
+                opt.step()
+
+            def run():
+                g1.replay()
+                if multi and world > 1:  # the stacked log_vars: summed in place, the policy divides by reading the mean
+                    dist.all_reduce(lv_buf, op=dist.ReduceOp.SUM)
+                    lv_buf.div_(world)
+                reducer.finalize(repack=False)
+                g2.replay()
+            use_graph = True
+        except Exception as e:  # noqa: BLE001
+            print(f'[bench] full model DP: hipGraph capture failed ({type(e).__name__}: {e}); running eagerly', file=sys.stderr)
+            torch.cuda.synchronize()
+            run = step
+    for _ in range(args.warmup):
+        run()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    fence()
+    dt = time.perf_counter() - t0
+    if multi:
+        t = torch.tensor([dt], device='cuda', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    spread = 0.0
+    if multi:
+        chk = torch.stack([q.detach().double().sum() for q in params]).sum().reshape(1)
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        spread = float((hi - lo).item())
+    n_img = sum(mix.values())
+    if rank == 0:
+        lv = state['lv'].detach().cpu().tolist()
+        result = {
+            'metric': f'train imgs/sec SM3Det ConvNeXt-T e8t2 @{RES}^2, whole detector (TriSourceDetector of main_SM3Det.py), '
+                      f'{n_img} images/GPU native mix',
+            'value': round(world * n_img * args.steps / dt, 3), 'unit': 'imgs/sec', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'full_model: ' + full_model_dp_main.__doc__.split('\n')[0].strip(),
+                       'name': DEFAULT_CONFIG, 'global_batch': world * n_img, 'resolution': RES, 'parallelism': f'dp{world}',
+                       'params_m': round(sum(q.numel() for q in params) / 1e6, 2), 'grad_buckets': reducer.num_buckets,
+                       'hip_graph': use_graph, 'dist_backend': (backend if multi else None),
+                       'collective_avg': bool(reducer._avg), 'log_var_collectives_per_step': 1 if (multi and world > 1) else 0,
+                       'grad_bytes_in_place_frac': round(reducer.pack_stats['in_place_bytes'] /
+                                                         max(reducer.pack_stats['in_place_bytes'] + reducer.pack_stats['copied_bytes'], 1), 4)
+                       if multi else None,
+                       'replica_checksum_spread': spread, 'gemm_arith': LB.gemm_arith(),
+                       'dynamic_lr': 'DeviceDynamicLr on the rank-averaged losses (sm3_dla_lr)'},
+            'loss_terms': dict(zip(state['keys'], [round(v, 5) for v in lv])),
+            'roofline': None, 'cpu_baseline': None,
+        }
+        print(json.dumps(result), flush=True)
+    if multi:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def _self_launch(n):
     """`python bench.py --gpus N` without a launcher: start N ranks of this very command line under torch.distributed.run
     (one process per GPU, rendezvous on 127.0.0.1 -- tools/dist_train.sh:8-19 of the reference does the same with
@@ -760,6 +920,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-ops', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a captured hipGraph')
+    ap.add_argument('--workload', choices=['backbone', 'full_model'], default='backbone',
+                    help="'backbone' (default): the headline hot path; 'full_model': the whole detector's data-parallel training step")
     ap.add_argument('--config', default=DEFAULT_CONFIG, help='BASELINE.json configuration (a key of '
                     'sm3det_amd/configs/baseline_configs.json): main_SM3Det (#2, default), SM3Det_convnext_t (#3), e16t2 (#4), '
                     'SM3Det_convnext_b (#5), simple_joint (#1)')
@@ -808,6 +970,8 @@ def main():
     from sm3det_amd import _lib, _lib_backbone as LB
     from sm3det_amd.data_parallel import BucketedGradReducer
     _lib.lib()  # fail loudly if the HIP extension is missing
+    if args.workload == 'full_model':
+        return full_model_dp_main(args, world, rank, multi, backend, force_dist)
 
     net = build_model(args.config).cuda().train()
     desc = describe_backbone(net)
