@@ -116,3 +116,75 @@ def test_detector_skips_the_branch_of_an_absent_source_and_sar_inference_runs():
         assert sum(a.shape[0] for a in res[0]) <= 2000
         dets = np.concatenate(res[0])
         assert np.isfinite(dets).all() and (dets[:, 5] > 0.05).all()
+
+
+def test_rgb_branch_losses_inside_the_detector_equal_the_pinned_oracles():
+    """Detector-level numeric check of the two-stage (RGB) branch: inside `TriSourceDetector.forward_train` the Oriented-RPN
+    and RoI-head losses are re-derived on the CPU by the oracles that the reference's own head classes pin
+    (oracle/loss_oracle.py via tests/test_oracle_losses.py: `_get_targets_single` / `get_targets` / `loss` run live) -- from
+    the tensors the detector actually handed to the heads (FPN outputs of the MoE backbone, the gts of the RGB sample) and
+    the anchors / RoIs its samplers actually drew.  Values within 1e-4."""
+    from oracle import loss_oracle as LO
+    from sm3det_amd import detector  # noqa: F401
+    from sm3det_amd.registry import MODELS
+    from tests import losses_common as LC
+    torch.manual_seed(0)
+    det = MODELS.build(_model_cfg()).cuda().train()
+    for h in (det.rgb_rpn_head, det.rgb_roi_head, det.ifr_rpn_head, det.ifr_roi_head):
+        h.init_weights()
+    with torch.no_grad():
+        for n, p in det.backbone.named_parameters():
+            if n.endswith('gamma'):
+                p.fill_(1.0)
+    cap = {}
+    rpn, roi = det.rgb_rpn_head, det.rgb_roi_head
+    rpn_loss, roi_train = rpn.loss, roi.forward_train
+
+    def loss_wrap(cls_scores, bbox_preds, gt_bboxes, img_metas, gt_bboxes_ignore=None, **kw):
+        losses, smp = rpn_loss(cls_scores, bbox_preds, gt_bboxes, img_metas, gt_bboxes_ignore, return_samples=True, **kw)
+        cap['rpn'] = dict(cls=[c.detach().float().cpu() for c in cls_scores], reg=[r.detach().float().cpu() for r in bbox_preds],
+                          gts=[g.detach().float().cpu() for g in gt_bboxes], smp={k: v.detach().cpu() for k, v in smp.items()},
+                          losses=losses)
+        return losses
+
+    def roi_wrap(x, img_metas, proposal_list, gt_bboxes, gt_labels, *a, **kw):
+        losses, smp = roi_train(x, img_metas, proposal_list, gt_bboxes, gt_labels, *a, return_samples=True, **kw)
+        with torch.no_grad():
+            res = roi._bbox_forward(x, smp['rois'])
+        cap['roi'] = dict(smp={k: v.detach().cpu() for k, v in smp.items() if torch.is_tensor(v)}, losses=losses,
+                          cls=res['cls_score'].float().cpu(), reg=res['bbox_pred'].float().cpu())
+        return losses
+
+    rpn.loss, roi.forward_train = loss_wrap, roi_wrap
+    img, metas, gtb, gtl = _batch(['sar', 'sar', 'rgb', 'ifr'])
+    losses = det.forward_train(img, metas, gtb, gtl)
+    # ---- Oriented RPN: oracle on the captured head outputs, the captured anchors and the sampler's picks
+    r = cap['rpn']
+    smp = r['smp']
+    sizes = [tuple(c.shape[-2:]) for c in r['cls']]
+    counts = [h * w * 3 for h, w in sizes]
+    anchors = list(smp['anchors'].split(counts))
+    idx, is_pos, valid = smp['idx'], smp['is_pos'].bool(), smp['valid'].bool()
+    pos = [idx[i][is_pos[i] & valid[i]] for i in range(idx.shape[0])]
+    neg = [idx[i][(~is_pos[i]) & valid[i]] for i in range(idx.shape[0])]
+    assert all(p.numel() > 0 for p in pos) and all(n.numel() > 0 for n in neg)
+    oc, ob = LO.rpn_loss(r['cls'], r['reg'], anchors, smp['inside'].bool(), r['gts'], pos, neg, LC.RPN_MEANS, LC.RPN_STDS,
+                         beta=1.0 / 9.0, assign_cfg=LC.RPN_ASSIGN)
+    for key, exp in (('rgb_loss_rpn_cls', oc), ('rgb_loss_rpn_bbox', ob)):
+        a, b = float(sum(losses[key])), float(sum(exp))
+        assert abs(a - b) <= 1e-4 * max(1.0, abs(b)), (key, a, b)
+    # ---- RoI head: oracle on the head's scores / deltas for the RoIs its sampler drew
+    q = cap['roi']
+    s_ = q['smp']
+    C = roi.bbox_head.num_classes
+    lab, val = s_['labels'], s_['valid'].bool()
+    rois, gts_s = s_['rois'], s_['gts']
+    assert bool(val.any()) and int((rois[:, 0] != 0).sum()) == 0  # one RGB image in the batch
+    p_ = (lab < C) & val
+    n_ = (lab >= C) & val
+    exp = LO.rcnn_loss(q['cls'][val], q['reg'][val], [rois[p_][:, 1:]], [rois[n_][:, 1:]], [gts_s[p_]], [lab[p_]], C,
+                       LC.RCNN_MEANS, LC.RCNN_STDS)
+    for key in ('loss_cls', 'loss_bbox', 'acc'):
+        a, b = float(losses['rgb_' + key]), float(exp[key])
+        assert abs(a - b) <= 1e-4 * max(1.0, abs(b)), (key, a, b)
+    assert float(losses['rgb_loss_bbox']) > 0
