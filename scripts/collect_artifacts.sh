@@ -14,6 +14,7 @@ T0=$(date +%s)
 say() { echo "[$(( $(date +%s) - T0 )) s] $*" | tee -a $O/${TAG}_summary.txt; }
 python $R/bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
 say "bench default: $(head -c 420 $O/${TAG}_bench.json)"
+export SM3_BENCH_NATIVE=0  # only the default line above carries the native-fp32-MFMA companion run
 for CFG in e16t2 SM3Det_convnext_t SM3Det_convnext_b; do
   python $R/bench.py --config $CFG --no-cpu-baseline --no-ops > $O/${TAG}_bench_$CFG.json 2> $O/${TAG}_bench_$CFG.err
   say "bench $CFG: $(head -c 420 $O/${TAG}_bench_$CFG.json)"
@@ -50,6 +51,11 @@ profile() {  # profile <suffix> <bench args...>: stats (serial [+ overlap]) and 
   unset SM3_WGRAD_STREAM
 }
 profile ""
+# the full detector alone (the third named workload): kernel statistics of SM3_BENCH_OPS=full
+rm -rf /tmp/prof_full
+SM3_BENCH_OPS=full rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_full -o p -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/${TAG}_rocprof_full.log 2>&1
+find /tmp/prof_full -name "*kernel_stats.csv" -exec cp {} $O/${TAG}_full_model_kernel_stats.csv \;
+say "full model stats: $(wc -l < $O/${TAG}_full_model_kernel_stats.csv) kernels"
 python $R/scripts/pmc_traffic.py $O/${TAG}_pmc_FETCH_SIZE_summary.json $O/${TAG}_pmc_WRITE_SIZE_summary.json $O/${TAG}_bench.json $O/${TAG}_mfma_bench_summary.json > $O/${TAG}_pmc_traffic.json 2> $O/${TAG}_pmc_traffic.err
 say "fp32 profile done: $(grep -A3 gemm_family\" $O/${TAG}_pmc_traffic.json | tr -d '\n ')"
 profile _amp --config SM3Det_convnext_t

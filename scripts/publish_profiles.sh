@@ -12,7 +12,7 @@ for f in bench bench_e16t2 bench_SM3Det_convnext_t bench_SM3Det_convnext_b bench
          pmc_WRITE_SIZE_summary_amp mfma_bench_summary mfma_bench_summary_amp pmc_tcc_summary pmc_tcc_summary_amp; do
   [ -s $G/${TAG}_$f.json ] && cp $G/${TAG}_$f.json $P/$f.json
 done
-for f in kernel_stats_serial kernel_stats_overlap kernel_stats_serial_amp; do
+for f in kernel_stats_serial kernel_stats_overlap kernel_stats_serial_amp full_model_kernel_stats; do
   [ -s $G/${TAG}_$f.csv ] && cp $G/${TAG}_$f.csv $P/$f.csv
 done
 for f in pmc_FETCH_SIZE_top pmc_WRITE_SIZE_top mfma_bench_top pmc_FETCH_SIZE_top_amp pmc_WRITE_SIZE_top_amp mfma_bench_top_amp pmc_tcc_top pmc_tcc_top_amp summary; do

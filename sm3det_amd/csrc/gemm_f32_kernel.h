@@ -122,8 +122,11 @@ using T64x128 = Tile<2, 2, 1, 2>;
 #ifndef SM3_F16_OCC
 #define SM3_F16_OCC 3  // A/B builds: python -m sm3det_amd.build --variant f16_occ2
 #endif
+#ifndef SM3_B3_SIGNED
+#define SM3_B3_SIGNED 1  // bf16x3 form: odd k-tiles accumulate NEGATED products in a second accumulator set, which cancels the
+#endif                   // bf16 MFMA's downward accumulation bias (see `SIGNED` in the kernel); 0 = one set (A/B: --variant b3_unsigned)
 #ifndef SM3_B3_OCC
-#define SM3_B3_OCC 3  // bf16x3 form: workgroups per CU the launch bounds ask for
+#define SM3_B3_OCC (SM3_B3_SIGNED ? 2 : 3)  // bf16x3 form: workgroups per CU the launch bounds ask for
 #endif
 template <class TL, int BK, int F16 = 0>
 constexpr int occupancy() {
@@ -746,7 +749,7 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
   // live == false (uniform, tail steps only): the tile does not exist (index >= nk) and zeros are stored instead -- the
   // k-loop runs an even number of steps without a branch between them, so the step after the last tile of an odd nk
   // multiplies this all-zero stage
-  auto store_piece = [&](const f32x4 (&ra_)[PA], const f32x4 (&rb_)[PB], int q, int buf, bool live) {
+  auto store_piece = [&](const f32x4 (&ra_)[PA], const f32x4 (&rb_)[PB], int q, int buf, bool live, bool negate = false) {
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
     f32x4 ra[PA], rb[PB];
     if (q < PA) ra[q] = live ? ra_[q] : z4;
@@ -767,7 +770,8 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
       typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
       return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
     };
-    auto split3 = [&](const f32x4& v, uint32_t* dst, int plane) {
+    auto split3 = [&](const f32x4& v, uint32_t* dst, int plane, bool neg) {
+      const uint32_t sgn = neg ? 0x80008000u : 0u;  // both halves of a packed pair change sign
       typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
       auto lo_f = [](uint32_t w) { return __builtin_bit_cast(float, w << 16); };
       auto hi_f = [](uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); };
@@ -778,16 +782,16 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
       return;
 #endif
       const uint32_t h0 = cvt2(v[0], v[1]), h1 = cvt2(v[2], v[3]);
-      *reinterpret_cast<u32x2*>(dst) = u32x2{h0, h1};
+      *reinterpret_cast<u32x2*>(dst) = u32x2{h0 ^ sgn, h1 ^ sgn};
       const float r0 = v[0] - lo_f(h0), r1 = v[1] - hi_f(h0), r2 = v[2] - lo_f(h1), r3 = v[3] - hi_f(h1);  // exact
       const uint32_t m0 = cvt2(r0, r1), m1 = cvt2(r2, r3);
-      *reinterpret_cast<u32x2*>(dst + plane) = u32x2{m0, m1};
+      *reinterpret_cast<u32x2*>(dst + plane) = u32x2{m0 ^ sgn, m1 ^ sgn};
       const float s0 = r0 - lo_f(m0), s1 = r1 - hi_f(m0), s2 = r2 - lo_f(m1), s3 = r3 - hi_f(m1);          // exact
-      *reinterpret_cast<u32x2*>(dst + 2 * plane) = u32x2{cvt2(s0, s1), cvt2(s2, s3)};
+      *reinterpret_cast<u32x2*>(dst + 2 * plane) = u32x2{cvt2(s0, s1) ^ sgn, cvt2(s2, s3) ^ sgn};
     };
     if (B3) {
-      if (q < PA) split3(ra[q], Aw + buf * A_STG + ha[q], A_ST16);
-      else split3(rb[q - PA], Bw + buf * B_STG + hb[q - PA], B_ST16);
+      if (q < PA) split3(ra[q], Aw + buf * A_STG + ha[q], A_ST16, negate);
+      else split3(rb[q - PA], Bw + buf * B_STG + hb[q - PA], B_ST16, false);
     } else if (q < PA) {
       if (F16 && A16 && A_TRANS) {
         typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -836,6 +840,27 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
   };
 
   f32x16 acc[TI][TJ];
+  // bf16x3, SM3_B3_SIGNED: v_mfma_f32_32x32x16_bf16 adds its 16 products to the accumulator with a truncation TOWARDS MINUS
+  // INFINITY (measured, scripts/probes/b3_bias.py: mean signed error -0.1 ulp at K = 384, -0.4 ulp at K = 3072, the same
+  // sign for positive and negative results; the native fp32 instruction is unbiased) -- harmless per element, but coherent
+  // over the ~1e5 tokens a bias / LayerNorm gradient sums.  Odd k-tiles therefore store the NEGATED A pieces and accumulate
+  // into a second set: it holds -S_odd with the same downward bias, and S = S_even - (-S_odd) cancels the two biases.
+  // Cost (same box, training step): 16.83 ms against 16.36 ms with one set -- 230 VGPRs instead of 166 at 128x128, two
+  // workgroups per CU instead of three.  Benefit: mean signed error +0.002 / +0.03 ulp (K = 384 / 3072; one set: -0.12 / -0.38),
+  // mean |error| 0.63 / 1.5 ulp (one set 1.2 / 2.8, the native fp32 instruction 1.5 / 4.2); worst full-size gradient
+  // 2.9e-4 instead of 6-8e-4 of the 1e-3 bar (profiles/r05/gemm_b3_bias.txt).  An alternative that keeps one set --
+  // flipping the sign of the whole accumulation every four k-tiles (64 v_xor per flip) -- measured slower than both.
+  constexpr bool SIGNED = B3 && SM3_B3_SIGNED == 1;
+  f32x16 accn[SIGNED ? TI : 1][SIGNED ? TJ : 1];
+  auto negate_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < TI; i++)
+#pragma unroll
+      for (int j = 0; j < TJ; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+          acc[i][j][r] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, acc[i][j][r]) ^ 0x80000000u);
+  };
 
   // Two register sets: while tile kt is multiplied out of LDS, the global loads of tile kt+2 are ISSUED into one set
   // (first k-pairs) and tile kt+1 -- loaded one iteration earlier, long landed -- is WRITTEN to the other LDS buffer
@@ -967,7 +992,7 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
     for (int j = 0; j < TJ; j++) fb[dst][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4b*>(b_w + 32 * j * 4));
   };
   // operands swapped as in the fp32 form: D = (B fragment) x (A fragment) = the transposed 32x32 tile
-  auto prod = [&](int sa_, int sb_) {
+  auto prod = [&](int sa_, int sb_, int par) {
 #ifdef SM3_ABL_NOMFMA
 #pragma unroll
     for (int i = 0; i < TI; i++) asm volatile("" ::"v"(fa[sa_][i]));
@@ -977,15 +1002,20 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
 #pragma unroll
     for (int i = 0; i < TI; i++)
 #pragma unroll
-      for (int j = 0; j < TJ; j++)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[sb_][j], fa[sa_][i], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < TJ; j++) {
+        if (SIGNED && par)
+          accn[SIGNED ? i : 0][SIGNED ? j : 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+              fb[sb_][j], fa[sa_][i], accn[SIGNED ? i : 0][SIGNED ? j : 0], 0, 0, 0);
+        else
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[sb_][j], fa[sa_][i], acc[i][j], 0, 0, 0);
+      }
 #endif
   };
   static_assert(!B3 || NP <= 4, "bf16x3 body: one piece per product slot, four slots");
-  auto b3_piece = [&](f32x4 (&ra)[PA], f32x4 (&rb)[PB], int q, int stage, bool live, int kt_load, bool tail) {
+  auto b3_piece = [&](f32x4 (&ra)[PA], f32x4 (&rb)[PB], int q, int stage, bool live, int kt_load, bool tail, bool neg) {
     if (q >= NP) return;
 #ifndef SM3_ABL_NOSTORE
-    store_piece(ra, rb, q, stage, live);
+    store_piece(ra, rb, q, stage, live, neg);
 #endif
 #ifndef SM3_ABL_NOLOAD
     load_piece(ra, rb, q, kt_load, tail);
@@ -1008,26 +1038,27 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
     const int st = par, nx = par ^ 1;
     const bool live = tail ? t + 1 < nk : true;
     const int kt_load = tail ? min(t + 3, nk - 1) : t + 3;
+    const bool neg_store = SIGNED && par == 0;  // tile t + 1 (stored by this body) is odd <=> t is even
 #pragma unroll
     for (int s_ = 0; s_ < 3; s_++) {
       rd_a(st, s_, s_);
       rd_b(st, s_, s_);
     }
     __builtin_amdgcn_sched_barrier(0);
-    prod(1, 1);
-    b3_piece(ra, rb, 0, nx, live, kt_load, tail);
+    prod(1, 1, par);
+    b3_piece(ra, rb, 0, nx, live, kt_load, tail, neg_store);
     slot_mix();
-    prod(2, 0);
-    b3_piece(ra, rb, 1, nx, live, kt_load, tail);
+    prod(2, 0, par);
+    b3_piece(ra, rb, 1, nx, live, kt_load, tail, neg_store);
     slot_mix();
-    prod(0, 2);
-    b3_piece(ra, rb, 2, nx, live, kt_load, tail);
+    prod(0, 2, par);
+    b3_piece(ra, rb, 2, nx, live, kt_load, tail, neg_store);
     slot_mix();
-    prod(1, 0);
-    b3_piece(ra, rb, 3, nx, live, kt_load, tail);
+    prod(1, 0, par);
+    b3_piece(ra, rb, 3, nx, live, kt_load, tail, neg_store);
     slot_mix();
-    prod(0, 1);
-    prod(0, 0);
+    prod(0, 1, par);
+    prod(0, 0, par);
     __syncthreads();
   };
   if (B3) {
@@ -1049,6 +1080,14 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
       for (int j = 0; j < TJ; j++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    if (SIGNED) {
+#pragma unroll
+      for (int i = 0; i < TI; i++)
+#pragma unroll
+        for (int j = 0; j < TJ; j++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) accn[SIGNED ? i : 0][SIGNED ? j : 0][r] = 0.f;
+    }
     if (B3) {
       // tile 0 -> stage 0; the register sets then hold tiles 1 (sa1: stored by body 0) and 2 (sa0: stored by body 1)
       if (nk > 0) {
@@ -1114,6 +1153,12 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
     }
   }
 
+  if (SIGNED) {  // S = S_even - (-S_odd)
+#pragma unroll
+    for (int i = 0; i < TI; i++)
+#pragma unroll
+      for (int j = 0; j < TJ; j++) acc[i][j] -= accn[SIGNED ? i : 0][SIGNED ? j : 0];
+  }
   SM3_TR(2);
   if (CSUM && do_cs && F16) {  // an F16 piece = four k of ONE column (unit idx = k-quad * BM + column): [BK / 4][BM]
     float* red = smem;
