@@ -852,15 +852,6 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
   // flipping the sign of the whole accumulation every four k-tiles (64 v_xor per flip) -- measured slower than both.
   constexpr bool SIGNED = B3 && SM3_B3_SIGNED == 1;
   f32x16 accn[SIGNED ? TI : 1][SIGNED ? TJ : 1];
-  auto negate_acc = [&]() {
-#pragma unroll
-    for (int i = 0; i < TI; i++)
-#pragma unroll
-      for (int j = 0; j < TJ; j++)
-#pragma unroll
-        for (int r = 0; r < 16; r++)
-          acc[i][j][r] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, acc[i][j][r]) ^ 0x80000000u);
-  };
 
   // Two register sets: while tile kt is multiplied out of LDS, the global loads of tile kt+2 are ISSUED into one set
   // (first k-pairs) and tile kt+1 -- loaded one iteration earlier, long landed -- is WRITTEN to the other LDS buffer
@@ -974,7 +965,8 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
   // (the smallest terms lead).  Tile t + 1 is written to the other stage -- split into its three bf16 planes: 22 VALU
   // instructions and three 8-byte stores per piece, one piece per product slot, interleaved with that slot's MFMAs -- and the
   // registers a piece came from are refilled at once with tile t + 3 (two bodies of prefetch on two register sets: a body
-  // is 768 matrix-pipe cycles, a third of the fp32 form's).  166 VGPRs at 128x128: three workgroups per CU.
+  // is 768 matrix-pipe cycles, a third of the fp32 form's).  230 VGPRs at 128x128 with the second accumulator set (below): two
+  // workgroups per CU (166 VGPRs and three with one set).
   // Measured alternatives, all within +-3 % of this form or worse (profiles/r05/gemm_b3_variants.txt): fragment reads one
   // tile ahead with plane 0 double-buffered (207 VGPRs, two workgroups per CU), compiler-ordered body, no interleave hint.
   // Phase ablations (profiles/r05/gemm_b3_ablations.txt): the conversion arithmetic is free beside the bf16 MFMAs; the
