@@ -848,8 +848,11 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
   // Cost (same box, training step): 16.83 ms against 16.36 ms with one set -- 230 VGPRs instead of 166 at 128x128, two
   // workgroups per CU instead of three.  Benefit: mean signed error +0.002 / +0.03 ulp (K = 384 / 3072; one set: -0.12 / -0.38),
   // mean |error| 0.63 / 1.5 ulp (one set 1.2 / 2.8, the native fp32 instruction 1.5 / 4.2); worst full-size gradient
-  // 2.9e-4 instead of 6-8e-4 of the 1e-3 bar (profiles/r05/gemm_b3_bias.txt).  An alternative that keeps one set --
-  // flipping the sign of the whole accumulation every four k-tiles (64 v_xor per flip) -- measured slower than both.
+  // 2.9e-4 instead of 6-8e-4 of the 1e-3 bar (profiles/r05/gemm_b3_bias.txt).  The alternative that keeps one set --
+  // flipping the sign of the whole accumulation (64 v_xor in the shadow of a body's fragment reads, 161 VGPRs, three
+  // workgroups per CU) -- measured slower than both, every four k-tiles and every k-tile alike: same box 17.61 ms (flip per
+  // tile) / 17.19 (two sets) / 16.77 (one set), and its |error| stays the one-set form's (1.17 ulp at K = 384): the xors
+  // take the issue slots of the wave's own MFMAs.
   constexpr bool SIGNED = B3 && SM3_B3_SIGNED == 1;
   f32x16 accn[SIGNED ? TI : 1][SIGNED ? TJ : 1];
 
