@@ -252,7 +252,10 @@ def test_layernorm_patch_major_is_the_downsample_im2col():
 
 
 @pytest.mark.parametrize('B,H,W,C', [(2, 16, 16, 96), (1, 8, 24, 192), (1, 8, 8, 768), (2, 32, 32, 32),
-                                     (2, 32, 48, 96), (1, 64, 32, 192), (2, 16, 32, 768), (1, 20, 16, 64)])
+                                     (2, 32, 48, 96), (1, 64, 32, 192), (2, 16, 32, 768), (1, 20, 16, 64),
+                                     # more tiles than workgroup slots: the several-tiles-per-workgroup kernel (2 and 3 tiles;
+                                     # the last: 9 tiles per image chunk, so tile pairs straddle channel chunks and images)
+                                     (2, 128, 128, 192), (2, 256, 256, 96), (2, 48, 48, 928)])
 def test_dwconv7_fwd_and_grads(B, H, W, C):
     from sm3det_amd import _lib_backbone as LB
     x = torch.randn(B, H, W, C, device='cuda')
