@@ -416,7 +416,10 @@ __global__ __launch_bounds__(256) void dwconv7_lds_bwd_weight_kernel(const float
 }  // namespace
 
 // C++ entry points used by backbone.hip's C ABI functions (same library)
-bool sm3_dwconv7_lds_supported(int H, int W, int C) { return (C % CB) == 0 && (H % TH) == 0 && (W % TW) == 0; }
+// (one image must stay below 2 GiB: the prefetching kernels address it through a buffer resource with 32-bit byte offsets)
+bool sm3_dwconv7_lds_supported(int H, int W, int C) {
+  return (C % CB) == 0 && (H % TH) == 0 && (W % TW) == 0 && (long)H * W * C * 4 < 0x7fff0000L;
+}
 
 void sm3_dwconv7_lds_fwd(const float* x, const float* w49, const float* bias, const float* addend, float* y, int B,
                          int H, int W, int C, int flip, hipStream_t st) {
