@@ -394,6 +394,9 @@ int sm3_stem_patchify(const float* x, float* a, int B, int H, int W, sm3_stream_
  * out_mode 2 (forward only): y[t] stored as fp16 (_Float16* passed as float*): the AMP data path's GEMM operand.
  * mean/rstd (T) are saved for the backward (may be NULL).  bwd: dwdb = [dw (C) | db (C)], overwritten;
  * accumulate_dx != 0 adds into dx. */
+/* out_mode | SM3_LN_X_F16 (forward and backward): the rows of `x` are stored as fp16 (the depthwise output of the AMP data
+ * path, what autocast makes of ConvNeXtBlock.depthwise_conv: convnext_moe.py:347); statistics and arithmetic stay fp32. */
+#define SM3_LN_X_F16 16
 int sm3_layernorm_fwd(const float* x, const float* w, const float* b, float eps, float* y, float* mean, float* rstd,
                       long T, int C, int out_mode, int H, int W, sm3_stream_t stream);
 /* dst (n halves) = round-to-nearest-even fp16 of src (n floats, n % 4 == 0): the fp16 shadow of a weight tensor that the
@@ -421,6 +424,9 @@ int sm3_layernorm_bwd(const float* dy, const float* x, const float* w, const flo
  * w49 (49,C) = weight (C,1,7,7) permuted to tap-major; y = conv(x) + bias (+ addend).  flip != 0 reads the taps
  * reversed (w49[48 - t]): the input gradient is this kernel with flip = 1 and addend = the residual branch gradient.
  * bwd_weight: dw49 (49,C) and dbias (C) overwritten (one fill when dbias == dw49 + 49*C, i.e. a (50,C) buffer). */
+/* flip | SM3_DW_OUT_F16: y is stored as fp16 (AMP data path; the LDS-tiled kernels only -- C % 32 == 0, H and W multiples
+ * of 16, one image below 2 GiB -- otherwise SM3_ERR_UNSUPPORTED). */
+#define SM3_DW_OUT_F16 32
 int sm3_dwconv7_fwd(const float* x, const float* w49, const float* bias, const float* addend, float* y, int B, int H,
                     int W, int C, int flip, sm3_stream_t stream);
 int sm3_dwconv7_bwd_weight(const float* x, const float* du, float* dw49, float* dbias, int B, int H, int W, int C,

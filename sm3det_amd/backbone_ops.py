@@ -329,15 +329,33 @@ def _shadow(w):
     return s
 
 
+# AMP data path: the depthwise output `u` as fp16 in HBM -- what autocast makes of ConvNeXtBlock.depthwise_conv
+# (convnext_moe.py:347: nn.Conv2d returns half; F.layer_norm re-promotes, :30-47): the convolution's write, the LayerNorm's
+# read and the LayerNorm backward's read of `u` move 2 B per element instead of 4.  LDS-tiled depthwise kernels only
+# (C % 32 == 0, H and W multiples of 16: every stage at 1024^2).  OFF by default, SM3_AMP_DW16=1 turns it on: parity-green
+# (tests/test_amp_gpu.py bit-equality of the kernels; the full-size AMP case of config #2 passes with it) but it buys nothing --
+# same box, config #3: 11.21 ms with `u` in fp32, 11.22 ms in half (depthwise forward 0.806 / 0.806, LayerNorm forward 0.382 /
+# 0.379, LayerNorm backward 0.605 / 0.658 ms: these launches are not bound by their bytes, and 8-byte loads per lane are the
+# less efficient access) -- profiles/r05/bench_amp_dw16_{0,1}.json.
+AMP_DW16 = os.environ.get('SM3_AMP_DW16', '0') == '1'
+
+
+def _u_half(H, W, C):
+    return (AMP_DW16 and _half() == torch.float16 and C % 32 == 0 and H % 16 == 0 and W % 16 == 0
+            and H * W * C * 4 < 0x7fff0000)
+
+
 def _dw_ln_forward(x, w49, bdw, lnw, lnb, eps, B, H, W, C):
     T = B * H * W
-    u = _e(T, C, like=x)
-    call('dwconv7_fwd', x, w49, bdw, None, u, B, H, W, C, 0, nbytes=8.0 * T * C)
+    u16 = _u_half(H, W, C)
+    u = _e(T, C, like=x, dtype=torch.float16 if u16 else torch.float32)
+    call('dwconv7_fwd', x, w49, bdw, None, u, B, H, W, C, 32 if u16 else 0, nbytes=(4.0 + u.element_size()) * T * C)
     hd = _half()
     xn = _e(T, C, like=x, dtype=hd)
     mean, rstd = _e(T, like=x), _e(T, like=x)
-    call('layernorm_fwd', u, lnw, lnb, float(eps), xn, mean, rstd, T, C, 2 if hd == torch.float16 else 0, H, W,
-         nbytes=(4.0 + xn.element_size()) * T * C)
+    call('layernorm_fwd', u, lnw, lnb, float(eps), xn, mean, rstd, T, C,
+         (2 if hd == torch.float16 else 0) | (16 if u16 else 0), H, W,
+         nbytes=(u.element_size() + xn.element_size()) * T * C)
     return u, xn, mean, rstd
 
 
@@ -348,7 +366,8 @@ def _dw_ln_backward(dxn, dout, x, u, w49, lnw, mean, rstd, B, H, W, C):
     du = _e(T, C, like=x)
     dwdb = _e(2, C, like=x)
     ws, nb = LB.row_ws(C, x)
-    call('layernorm_bwd', dxn, u, lnw, mean, rstd, du, None, T, C, 0, H, W, 0, ws, nb, nbytes=12.0 * T * C)
+    call('layernorm_bwd', dxn, u, lnw, mean, rstd, du, None, T, C, 16 if u.dtype == torch.float16 else 0, H, W, 0, ws, nb,
+         nbytes=(8.0 + u.element_size()) * T * C)
     _deferred_reduce(ws, T, C, 2 * C, dwdb, params=(lnw,))  # d(ln weight) | d(ln bias); joined by the caller
     dwb = _e(50, C, like=x)  # [dw49 (49,C); dbias (C)] in one buffer: one fill inside the kernel wrapper
     dw49, dbdw = dwb[:49], dwb[49]

@@ -127,7 +127,15 @@ __device__ __forceinline__ long ln_out_offset(long tok, int C, int mode, int H, 
   return row * (4L * C) + (long)(((h & 1) << 1) | (w & 1)) * C;
 }
 
-template <int G, int NV>
+// X16: the rows of x are stored as fp16 (the depthwise output of the AMP data path); statistics and arithmetic in fp32 as
+// F.layer_norm under autocast (convnext_moe.py:30-47)
+__device__ __forceinline__ f32x4 ld4h(const float* base, long o) {
+  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+  const f16x4 h = *reinterpret_cast<const f16x4*>(reinterpret_cast<const _Float16*>(base) + o);
+  return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+}
+
+template <int G, int NV, int X16>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ b, float eps,
                                                            float* __restrict__ y, float* __restrict__ mean_o,
@@ -147,7 +155,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 #pragma unroll
     for (int i = 0; i < NV; i++) {
       const int q = lg + i * G;
-      v[i] = (tv && q < nq) ? ld4(x + tok * C + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+      v[i] = (tv && q < nq) ? (X16 ? ld4h(x, tok * C + 4 * q) : ld4(x + tok * C + 4 * q)) : f32x4{0.f, 0.f, 0.f, 0.f};
       s += hsum4(v[i]);
     }
     const float mean = group_sum<G>(s) / (float)C;
@@ -187,7 +195,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 
 // backward: dx = rstd * (dyh - mean(dyh) - xh * mean(dyh * xh)), dyh = dy * w ; dw += dy * xh ; db += dy
 // `dy` is read through the same out_mode mapping the forward wrote y with.  dwdb (2C) must be zeroed by the caller.
-template <int G, int NV>
+template <int G, int NV, int X16>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                            const float* __restrict__ w,
                                                            const float* __restrict__ mean_i,
@@ -226,7 +234,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
       for (int i = 0; i < NV; i++) {
         const int q = lg + i * G;
         const bool ok = tv[u] && q < nq;
-        xh[u][i] = ok ? ld4(x + tok[u] * C + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+        xh[u][i] = ok ? (X16 ? ld4h(x, tok[u] * C + 4 * q) : ld4(x + tok[u] * C + 4 * q)) : f32x4{0.f, 0.f, 0.f, 0.f};
         g[u][i] = ok ? ld4(dy + ob[u] + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
       mean[u] = tv[u] ? mean_i[tok[u]] : 0.f;
@@ -738,12 +746,15 @@ int sm3_cast_f32_f16(const float* src, void* dst, long n, sm3_stream_t stream) {
 
 int sm3_layernorm_fwd(const float* x, const float* w, const float* b, float eps, float* y, float* mean, float* rstd,
                       long T, int C, int out_mode, int H, int W, sm3_stream_t stream) {
+  const int x16 = out_mode & 16;  // SM3_LN_X_F16
+  out_mode &= ~16;
   if (!x || !w || !b || !y || T < 0 || C <= 0 || (C & 3) || out_mode < 0 || out_mode > 2) return SM3_ERR_INVALID_ARG;
   if (out_mode == 1 && ((H & 1) || (W & 1))) return SM3_ERR_INVALID_ARG;
   if (T == 0) return SM3_OK;
   hipStream_t st = (hipStream_t)stream;
-#define CALL(G, NV)                                                                                        \
-  layernorm_fwd_kernel<G, NV><<<row_blocks(T, G), 256, 0, st>>>(x, w, b, eps, y, mean, rstd, T, C, out_mode, H, W)
+#define CALL(G, NV)                                                                                                      \
+  if (x16) layernorm_fwd_kernel<G, NV, 1><<<row_blocks(T, G), 256, 0, st>>>(x, w, b, eps, y, mean, rstd, T, C, out_mode, H, W); \
+  else layernorm_fwd_kernel<G, NV, 0><<<row_blocks(T, G), 256, 0, st>>>(x, w, b, eps, y, mean, rstd, T, C, out_mode, H, W)
   SM3_ROW_DISPATCH(C, CALL);
 #undef CALL
   return launch_status();
@@ -840,7 +851,9 @@ size_t sm3_row_reduce_workspace_bytes(int C) { return (size_t)ROW_MAX_BLOCKS * 2
 int sm3_layernorm_bwd(const float* dy, const float* x, const float* w, const float* mean, const float* rstd,
                       float* dx, float* dwdb, long T, int C, int out_mode, int H, int W, int accumulate_dx,
                       void* workspace, size_t workspace_bytes, sm3_stream_t stream) {
-  if (!dy || !x || !w || !mean || !rstd || !dx || !workspace || T <= 0 || C <= 0 || (C & 3))
+  const int x16 = out_mode & 16;  // SM3_LN_X_F16
+  out_mode &= ~16;
+  if (!dy || !x || !w || !mean || !rstd || !dx || !workspace || T <= 0 || C <= 0 || (C & 3) || out_mode < 0 || out_mode > 2)
     return SM3_ERR_INVALID_ARG;
   if (workspace_bytes < sm3_row_reduce_workspace_bytes(C)) return SM3_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
@@ -849,7 +862,10 @@ int sm3_layernorm_bwd(const float* dy, const float* x, const float* w, const flo
   const size_t lds = (size_t)4 * 2 * C * sizeof(float);
 #define CALL(G, NV)                                                                                                 \
   nb = row_blocks_capped(T, G);                                                                                     \
-  layernorm_bwd_kernel<G, NV><<<nb, 256, lds, st>>>(dy, x, w, mean, rstd, dx, part, T, C, out_mode, H, W, accumulate_dx)
+  if (x16)                                                                                                          \
+    layernorm_bwd_kernel<G, NV, 1><<<nb, 256, lds, st>>>(dy, x, w, mean, rstd, dx, part, T, C, out_mode, H, W, accumulate_dx); \
+  else                                                                                                              \
+    layernorm_bwd_kernel<G, NV, 0><<<nb, 256, lds, st>>>(dy, x, w, mean, rstd, dx, part, T, C, out_mode, H, W, accumulate_dx)
   SM3_ROW_DISPATCH(C, CALL);
 #undef CALL
   if (dwdb) partials_reduce_kernel<<<(2 * C + 63) / 64, PR_THREADS, 0, st>>>(part, nb, 2 * C, dwdb);
@@ -858,7 +874,8 @@ int sm3_layernorm_bwd(const float* dy, const float* x, const float* w, const flo
 
 int sm3_dwconv7_fwd(const float* x, const float* w49, const float* bias, const float* addend, float* y, int B, int H,
                     int W, int C, int flip, sm3_stream_t stream) {
-  if (!x || !w49 || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || C > 1024) return SM3_ERR_INVALID_ARG;
+  if (!x || !w49 || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || C > 1024 || (flip & ~33)) return SM3_ERR_INVALID_ARG;
+  if ((flip & 32) && !sm3_dwconv7_lds_supported(H, W, C)) return SM3_ERR_UNSUPPORTED;  // fp16 output: the LDS-tiled kernels only
   if (sm3_dwconv7_lds_supported(H, W, C)) {
     sm3_dwconv7_lds_fwd(x, w49, bias, addend, y, B, H, W, C, flip, (hipStream_t)stream);
     return launch_status();

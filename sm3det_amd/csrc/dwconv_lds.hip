@@ -17,6 +17,17 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+// output element `o` of a tensor stored as fp32, or (OUT16) as fp16 (round to nearest even): the AMP data path keeps the
+// convolution output in half, as autocast makes of ConvNeXtBlock.depthwise_conv (convnext_moe.py:347)
+template <int OUT16>
+__device__ __forceinline__ void st4o(float* y, long o, f32x4 v) {
+  if (OUT16) {
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(y) + o) = f16x4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+  } else {
+    st4(y + o, v);
+  }
+}
 
 #ifndef SM3_DW_MULTITILE
 #define SM3_DW_MULTITILE 1  // large maps: workgroups walk several tiles with the next patch in flight (0: A/B build --variant dw_onetile)
@@ -60,6 +71,7 @@ __device__ __forceinline__ void load_patch(const float* __restrict__ x, int b, i
 }
 
 // y = conv(x) + bias (+ addend); grid = (W/16 * H/16, C/32, B)
+template <int OUT16>
 __global__ __launch_bounds__(256) void dwconv7_lds_fwd_kernel(const float* __restrict__ x,
                                                              const float* __restrict__ w49,
                                                              const float* __restrict__ bias,
@@ -147,7 +159,7 @@ __global__ __launch_bounds__(256) void dwconv7_lds_fwd_kernel(const float* __res
       const long o = (((long)b * H + y0 + ry + r) * W + x0 + rx + c) * C + c0 + 4 * cq;
       f32x4 v = acc[r][c];
       if (addend) v += ld4(addend + o);
-      st4(y + o, v);
+      st4o<OUT16>(y, o, v);
     }
 }
 
@@ -206,6 +218,7 @@ __device__ __forceinline__ void patch_commit(const f32x4 (&v)[nit_patch<ROWS>()]
 }
 
 // tiles are numbered ((b * C/32 + chunk) * tiles_y + ty) * tiles_x + tx; grid = ceil(total / nt)
+template <int OUT16>
 __global__ __launch_bounds__(256, 2) void dwconv7_lds_fwd_mt_kernel(const float* __restrict__ x,
                                                                 const float* __restrict__ w49,
                                                                 const float* __restrict__ bias,
@@ -321,7 +334,7 @@ __global__ __launch_bounds__(256, 2) void dwconv7_lds_fwd_mt_kernel(const float*
 #pragma unroll
     for (int r = 0; r < 2; r++)
 #pragma unroll
-      for (int c = 0; c < 4; c++) st4(y + o0 + ((long)r * W + c) * C, acc[r][c]);
+      for (int c = 0; c < 4; c++) st4o<OUT16>(y, o0 + ((long)r * W + c) * C, acc[r][c]);
     __syncthreads();  // the patch (and the taps) are free
     b = nb; c0 = nc0; y0 = ny0; x0 = nx0;
   }
@@ -421,20 +434,26 @@ bool sm3_dwconv7_lds_supported(int H, int W, int C) {
   return (C % CB) == 0 && (H % TH) == 0 && (W % TW) == 0 && (long)H * W * C * 4 < 0x7fff0000L;
 }
 
+// `flags`: bit 0 = reversed taps (input gradient), bit 5 (32) = y is stored as fp16
 void sm3_dwconv7_lds_fwd(const float* x, const float* w49, const float* bias, const float* addend, float* y, int B,
-                         int H, int W, int C, int flip, hipStream_t st) {
+                         int H, int W, int C, int flags, hipStream_t st) {
+  const int flip = flags & 1;
+  const bool out16 = (flags & 32) != 0;
   const size_t lds = (size_t)LDS_PATCH * sizeof(float);
 #if SM3_DW_MULTITILE
   // more tiles than workgroup slots (2 per CU): one round of workgroups walking nt tiles each, loads ahead of the arithmetic
   const int total = (W / TW) * (H / TH) * (C / CB) * B;
   const int nt = (total + 511) / 512;
   if (nt >= 3 || (nt == 2 && addend)) {  // (two tiles without an addend: 22.0 vs 20.9 us at 2x128x128x192, same box)
-    dwconv7_lds_fwd_mt_kernel<<<(total + nt - 1) / nt, 256, lds, st>>>(x, w49, bias, addend, y, H, W, C, flip, nt, total);
+    const int grid = (total + nt - 1) / nt;
+    if (out16) dwconv7_lds_fwd_mt_kernel<1><<<grid, 256, lds, st>>>(x, w49, bias, addend, y, H, W, C, flip, nt, total);
+    else dwconv7_lds_fwd_mt_kernel<0><<<grid, 256, lds, st>>>(x, w49, bias, addend, y, H, W, C, flip, nt, total);
     return;
   }
 #endif
   dim3 grid((W / TW) * (H / TH), C / CB, B);
-  dwconv7_lds_fwd_kernel<<<grid, 256, lds, st>>>(x, w49, bias, addend, y, H, W, C, flip);
+  if (out16) dwconv7_lds_fwd_kernel<1><<<grid, 256, lds, st>>>(x, w49, bias, addend, y, H, W, C, flip);
+  else dwconv7_lds_fwd_kernel<0><<<grid, 256, lds, st>>>(x, w49, bias, addend, y, H, W, C, flip);
 }
 
 void sm3_dwconv7_lds_bwd_weight(const float* x, const float* du, float* dw49, float* dbias, int B, int H, int W, int C,
