@@ -94,8 +94,11 @@ int sm3_nms_rotated(const float* dets, int dets_stride, const float* scores, con
  *   pytorch/cpu/roi_align_rotated.cpp:115-212 (fwd), :272-372 (bwd).
  *   input/grad_input (batch,channels,height,width); layout 0 = NCHW contiguous, 1 = NHWC (torch
  *   channels_last) memory.  rois (n_rois,6) [batch_idx,cx,cy,w,h,theta]; output/grad_output
- *   (n_rois,channels,pooled_h,pooled_w) NCHW contiguous.  grad_input must arrive zero-filled
- *   (mmcv/ops/roi_align_rotated.py:92) and is accumulated with fp32 atomics. */
+ *   (n_rois,channels,pooled_h,pooled_w) NCHW contiguous.  sm3_roi_align_rotated_backward is the SCATTER form: grad_input
+ *   must arrive zero-filled (mmcv/ops/roi_align_rotated.py:92) and is accumulated with fp32 atomics.  It is the fallback
+ *   only (adaptive sampling grids, channels % 4 != 0, NCHW maps too small to pay for an NHWC pass): since round 4 the
+ *   default path of the `mmcv._ext` mirror is the sorted GATHER form sm3_roi_align_rotated_backward_tiled below (no atomic
+ *   accumulation; optional overwrite mode that needs no zero fill). */
 int sm3_roi_align_rotated_forward(const float* input, const float* rois, float* output, int n_rois,
                                   int batch, int channels, int height, int width, int pooled_h,
                                   int pooled_w, float spatial_scale, int sampling_ratio, int aligned,
@@ -111,7 +114,8 @@ int sm3_roi_align_rotated_backward(const float* grad_output, const float* rois, 
  * spatial scale; no nonzero()/gather/scatter per level, no host sync.  inputs / grad_inputs / heights / widths /
  * scales are HOST arrays of num_levels (<= 8) entries (device pointers, ints, floats); all levels share
  * `channels` and the layout flag.  levels_out (n_rois int32, may be NULL) receives the chosen levels.
- * backward accumulates into grad_inputs[l] with fp32 atomics (zero them first). */
+ * The multilevel backward declared here is the scatter form (fp32 atomics into zero-filled grad_inputs[l]); the fused
+ * extractor's default backward is sm3_roi_align_rotated_backward_tiled (sorted gather, below). */
 int sm3_roi_align_rotated_multilevel_forward(const float* const* inputs, const int* heights, const int* widths,
                                              const float* scales, int num_levels, float finest_scale,
                                              const float* rois, float* output, int32_t* levels_out, int n_rois,
@@ -592,9 +596,13 @@ int sm3_conv3x3_set_arith(int compute);
  * tensor or -1 for shared (backbone / neck) tensors, base_lr[n_params] = the groups' initial lr, sched[1] = the step-decay
  * factor gamma^exp of get_lr.  state = n + 2 doubles, zero before the first call: loss EMAs, number of EMA updates,
  * iteration index (all advanced here).  Writes lr[n_params] -- the vector sm3_adamw_multi reads -- without any host read:
- * warm-up iterations (< warmup_iters) get the linear warm-up factor, later ones base_lr * sched * (sub-network weight |
- * backbone-policy weight).  head_policy 0 normal / 1 reverse / 2 'None'; backbone_policy 0 min / 1 avg / 2 max / 3 kl /
- * 4 sigmoid_kl / 5 none.  n <= 32, n_subnets <= 63. */
+ * warm-up iterations (warmup_iters > 0, iteration < warmup_iters) get base_lr * (1 - (1 - it / warmup_iters) * (1 -
+ * warmup_ratio)) while the EMAs update -- warmup_ratio = 1 reproduces what a reference run does (the hook never installs
+ * `regular_lr` under IterBasedRunner, so the lr stays the initial lr during the warm-up: sm3det_amd/optim.py), a ratio < 1 is
+ * mmcv's documented linear ramp; later iterations get base_lr * sched * (sub-network weight | backbone-policy weight).
+ * warmup_iters < 0: no warm-up, but the hook's head-weight gate `EMA updates < warmup_iters` (:124) reads |warmup_iters|.
+ * head_policy 0 normal / 1 reverse / 2 'None'; backbone_policy 0 min / 1 avg / 2 max / 3 kl / 4 sigmoid_kl / 5 none.
+ * n <= 32, n_subnets <= 63. */
 int sm3_dla_lr(const float* losses, int n, const int32_t* loss_subnet, int n_subnets, const int32_t* param_subnet,
                const float* base_lr, int n_params, const float* sched, double* state, int head_policy,
                int backbone_policy, int warmup_iters, float warmup_ratio, float T, float b, float ema_beta, float* lr,

@@ -1,7 +1,10 @@
-"""Import the REFERENCE dynamic-lr hook (``mmrotate/core/hook/dynamic_lr.py``) unmodified from /root/reference.  TEST
-INFRASTRUCTURE ONLY (pins ``sm3det_amd.optim.DynamicLrPolicy`` on CPU).  Stand-ins during the import: ``mmcv.is_list_of``,
-``mmcv.runner`` / ``mmcv.runner.hooks(.hook)`` with an ``LrUpdaterHook`` that only stores ``by_epoch`` /
-``warmup_iters`` (the fields ``get_dynamic_lr`` reads) and an identity ``HOOKS`` registry."""
+"""Import the REFERENCE dynamic-lr hook (``mmrotate/core/hook/dynamic_lr.py``) unmodified from /root/reference, on top of
+the reference's OWN ``LrUpdaterHook`` (``mmcv/mmcv/runner/hooks/lr_updater.py``, also loaded unmodified: ``load(real_base=
+True)``, the default since round 6 -- the warm-up behaviour of an iteration-based run lives in that base class).  TEST
+INFRASTRUCTURE ONLY (pins ``sm3det_amd.optim.DynamicLrPolicy`` / ``dynamic_lr_after_train_iter`` on CPU).  Stand-ins during
+the import: ``mmcv.is_list_of``, ``mmcv.runner.BaseRunner``, the ``Hook`` base class (no method of it is reached) and an
+identity ``HOOKS`` registry.  ``load(real_base=False)`` keeps round 5's restated base (``_LrUpdaterHook`` below), which
+implements the warm-up mmcv's docstring describes rather than what an IterBasedRunner run does."""
 import importlib.util
 import os
 import sys
@@ -34,13 +37,46 @@ def available():
     return os.path.exists(REF_FILE)
 
 
-def load():
+LR_FILE = os.path.join(REF_ROOT, 'mmcv', 'mmcv', 'runner', 'hooks', 'lr_updater.py')
+
+
+def _real_lr_updater():
+    """the reference's own mmcv LrUpdaterHook class, from its file"""
+    name = '_sm3det_ref_mmcv_hooks.lr_updater'
+    if name in sys.modules:
+        return sys.modules[name].LrUpdaterHook
+    pkg = _mod('_sm3det_ref_mmcv_hooks')
+    pkg.__path__ = []
+    hook = _mod('_sm3det_ref_mmcv_hooks.hook', HOOKS=_Registry(), Hook=type('Hook', (), {}))
+    shims = {'_sm3det_ref_mmcv_hooks': pkg, '_sm3det_ref_mmcv_hooks.hook': hook,
+             'mmcv': _mod('mmcv', is_list_of=lambda seq, t: isinstance(seq, list) and all(isinstance(x, t) for x in seq)),
+             'mmcv.runner': _mod('mmcv.runner', BaseRunner=object)}
+    shims['mmcv'].runner = shims['mmcv.runner']
+    saved = {k: sys.modules.get(k) for k in shims}
+    sys.modules.update(shims)
+    try:
+        spec = importlib.util.spec_from_file_location(name, LR_FILE)
+        mod = importlib.util.module_from_spec(spec)
+        mod.__package__ = '_sm3det_ref_mmcv_hooks'
+        sys.modules[name] = mod
+        spec.loader.exec_module(mod)
+    finally:
+        for k, v in saved.items():
+            if k.startswith('mmcv'):
+                if v is None:
+                    sys.modules.pop(k, None)
+                else:
+                    sys.modules[k] = v
+    return mod.LrUpdaterHook
+
+
+def load(real_base=True):
     if not available():
         raise FileNotFoundError(REF_FILE)
-    name = '_sm3det_ref_dynamic_lr'
+    name = '_sm3det_ref_dynamic_lr' + ('' if real_base else '_restated_base')
     if name in sys.modules:
         return sys.modules[name]
-    hooks = _mod('mmcv.runner.hooks', LrUpdaterHook=_LrUpdaterHook)
+    hooks = _mod('mmcv.runner.hooks', LrUpdaterHook=_real_lr_updater() if real_base else _LrUpdaterHook)
     shims = {
         'mmcv': _mod('mmcv', is_list_of=lambda seq, t: isinstance(seq, list) and all(isinstance(x, t) for x in seq)),
         'mmcv.runner': _mod('mmcv.runner', hooks=hooks, BaseRunner=object),

@@ -24,6 +24,9 @@ for K in (384, 3072):
             C = torch.empty(M, N, device='cuda')
             LB.gemm(LB.NT, A, B, C, M, N, K)
             e = (C.double() - ref) / ulp(ref.float()).double()
-            out.append((float(e.mean()), float(e.abs().mean()), float(e.abs().max())))
-        print(f'K={K:5d} {name:11s} native: mean {out[0][0]:+.3f} |mean| {out[0][1]:.3f} max {out[0][2]:.2f} ulp   '
-              f'bf16x3: mean {out[1][0]:+.3f} |mean| {out[1][1]:.3f} max {out[1][2]:.2f} ulp')
+            # what a bias / LayerNorm gradient does with such an output: the sum over the token rows, in units of the
+            # quadrature sum of the rows' ulps (a coherent -0.1 ulp bias over 4096 rows shows as -0.1 * sqrt(4096) = -6.4)
+            cs = (C.double().sum(0) - ref.sum(0)) / ulp(ref.float()).double().pow(2).sum(0).sqrt()
+            out.append((float(e.mean()), float(e.abs().mean()), float(e.abs().max()), float(cs.mean()), float(cs.abs().max())))
+        print(f'K={K:5d} {name:11s} native: mean {out[0][0]:+.3f} |mean| {out[0][1]:.3f} max {out[0][2]:.2f} ulp colsum mean {out[0][3]:+.2f} max {out[0][4]:.2f}   '
+              f'bf16x3: mean {out[1][0]:+.3f} |mean| {out[1][1]:.3f} max {out[1][2]:.2f} ulp colsum mean {out[1][3]:+.2f} max {out[1][4]:.2f}')

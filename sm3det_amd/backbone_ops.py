@@ -93,6 +93,7 @@ def _join_side(device):
 # ConvNeXt-T training step, all at the launch floor.  SM3_BATCH_REDUCE=0 restores the per-call launches.
 BATCH_REDUCE = os.environ.get('SM3_BATCH_REDUCE', '1') == '1'
 _PENDING_REDUCE = {}  # device index -> [(workspace, rows, columns, out)]
+_PENDING_TASK = {}    # device index -> id of the backward pass (graph task) whose end-of-pass callback is registered
 
 
 def flush_deferred_reductions(device=None):
@@ -104,6 +105,12 @@ def flush_deferred_reductions(device=None):
         items = _PENDING_REDUCE.pop(di, [])
         if not items:
             continue
+        # the row kernels that produced the partials may have run on other streams than the one current here (the engine
+        # runs its final callbacks under the caller's streams BEFORE it joins them with the backward streams)
+        with torch.cuda.device(di):
+            here = torch.cuda.current_stream()
+            for st in {it[5] for it in items if it[5] is not None and it[5] != here}:
+                here.wait_stream(st)
         n = len(items)
         P = (ctypes.c_void_p * n)(*[it[0].data_ptr() for it in items])
         O = (ctypes.c_void_p * n)(*[it[3] for it in items])
@@ -124,18 +131,31 @@ def _deferred_reduce(ws, T, C, ncols, out, params=()):
     if not BATCH_REDUCE or OVERLAP_WGRAD or any(getattr(q, 'grad', None) is not None for q in params):
         _on_side(out.device, lambda: call('row_partials_reduce', ws, nblk, ncols, out))
         return
-    lst = _PENDING_REDUCE.setdefault(out.device.index, [])
-    if not lst:
+    # One end-of-pass callback per BACKWARD PASS, not per non-empty list: the engine drops its final callbacks when a pass
+    # raises (an OOM that is caught and retried, an error in a later node), which would leave the list non-empty with no
+    # callback behind it -- every later pass would append without ever reducing.  The pass is identified by the engine's
+    # graph-task id where torch exposes it; entries left over from a pass that never flushed are reduced first (their
+    # workspaces are still alive, so this is merely late, never wrong), and the flush itself is idempotent.
+    di = out.device.index
+    lst = _PENDING_REDUCE.setdefault(di, [])
+    try:
+        task = torch._C._current_graph_task_id()
+    except Exception:  # noqa: BLE001  (private API: fall back to "one callback per entry", still correct)
+        task = None
+    if task is None or task < 0 or _PENDING_TASK.get(di) != task:
+        if lst and task is not None and task >= 0:
+            flush_deferred_reductions(di)  # leftovers of a pass whose callback never ran
+            lst = _PENDING_REDUCE.setdefault(di, [])
         try:
-            di = out.device.index
             torch.autograd.Variable._execution_engine.queue_callback(lambda: flush_deferred_reductions(di))
         except RuntimeError:  # not inside a backward pass (a backward function called by hand): reduce now
             call('row_partials_reduce', ws, nblk, ncols, out)
             return
+        _PENDING_TASK[di] = task
     # the workspace tensor and the output's STORAGE are kept alive until the flush -- the storage, not the tensor: another
     # reference to the gradient tensor itself would make autograd's AccumulateGrad clone it (before it is filled) instead of
     # adopting it as p.grad
-    lst.append((ws, nblk, ncols, out.data_ptr(), out.untyped_storage()))
+    lst.append((ws, nblk, ncols, out.data_ptr(), out.untyped_storage(), torch.cuda.current_stream(out.device)))
 
 
 def _bucket_out(param, *shape):
@@ -145,6 +165,12 @@ def _bucket_out(param, *shape):
     adopts the fresh object as p.grad without a copy (another reference to the same tensor object would make it clone)."""
     v = getattr(param, '_sm3_grad_view', None)
     if v is None or tuple(v.shape) != tuple(shape) or v.dtype != torch.float32 or not v.is_contiguous():
+        return None
+    # The slice may only be written when autograd will ADOPT the result.  If the parameter still holds a gradient (gradient
+    # accumulation, zero_grad(set_to_none=False), or a second backward without reducer.zero_grad(): after finalize() p.grad
+    # IS this slice) the GEMM would overwrite the old gradient and AccumulateGrad would then add the slice to itself --
+    # 2 * new instead of old + new.  In that case the gradient goes to a fresh tensor and autograd accumulates as usual.
+    if getattr(param, 'grad', None) is not None:
         return None
     return v.detach()
 

@@ -123,17 +123,20 @@ using T64x128 = Tile<2, 2, 1, 2>;
 #define SM3_F16_OCC 3  // A/B builds: python -m sm3det_amd.build --variant f16_occ2
 #endif
 #ifndef SM3_B3_SIGNED
-#define SM3_B3_SIGNED 1  // bf16x3 form: odd k-tiles accumulate NEGATED products in a second accumulator set, which cancels the
-#endif                   // bf16 MFMA's downward accumulation bias (see `SIGNED` in the kernel); 0 = one set (A/B: --variant b3_unsigned)
+#define SM3_B3_SIGNED 2  // bf16x3 form, the bf16 MFMA's downward accumulation bias (see `SIGNED` / `CHECKER` in the kernel):
+#endif                   // 2 = one accumulator set, the SIGN of the accumulated value alternates over the 32-row blocks of the
+                         // token rows of the output (round 6, default); 1 = odd k-tiles accumulate negated products in a second
+                         // set (round 5; --variant b3_two_sets); 0 = one set, no cancellation (--variant b3_unsigned)
 #ifndef SM3_B3_OCC
-#define SM3_B3_OCC (SM3_B3_SIGNED ? 2 : 3)  // bf16x3 form: workgroups per CU the launch bounds ask for
+#define SM3_B3_OCC (SM3_B3_SIGNED == 1 ? 2 : 3)  // bf16x3 form: workgroups per CU the launch bounds ask for
 #endif
-template <class TL, int BK, int F16 = 0>
+template <class TL, int BK, int F16 = 0, int CSUM = 0>
 constexpr int occupancy() {
   // F16: the fp16 LDS image of a k-step-32 tile is 34 KB (the fp32 image 66 KB), so three workgroups fit a CU and the
   // loop -- bound by load latency, not by the matrix pipe -- gets a third wave per SIMD to hide it; k-step 64 (68 KB,
   // twice the MFMAs per barrier) runs two
-  if (F16 == 2) return (TL::TI * TL::TJ >= 6) ? 2 : SM3_B3_OCC;
+  // (128x128 with the column-sum by-product: 8 more live registers; at 168 it spills INTO the k-loop)
+  if (F16 == 2) return (TL::TI * TL::TJ >= 6 || (CSUM && TL::TI * TL::TJ >= 4)) ? 2 : SM3_B3_OCC;
   if (F16) return BK == 64 ? 2 : SM3_F16_OCC;
   // 128x128 at k-step 16 needs ~150 VGPRs to keep its LDS read bases out of the loop: 3 waves per SIMD without spills
   // instead of 4 with scratch reloads and address arithmetic between the MFMAs
@@ -188,7 +191,7 @@ __device__ __forceinline__ void gelu_erf_both(float h, float& y, float& dy) {
 constexpr int IO_A16 = 1, IO_B16 = 2, IO_C16 = 4, IO_X16 = 8;  // A operand, B operand, C output, aux_in / aux_out
 
 template <int MODE, int EPI, int BK, class TL, int GATHER, int F16 = 0, int CSUM = 0, int IO = 0>
-__global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32_kernel(GemmParams p) {
+__global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16, CSUM>())) void gemm_f32_kernel(GemmParams p) {
   constexpr int BM = TL::BM, BN = TL::BN, TI = TL::TI, TJ = TL::TJ, WN = TL::WN, WM = TL::WM;
   constexpr bool A16 = (IO & IO_A16) != 0, B16 = (IO & IO_B16) != 0, C16 = (IO & IO_C16) != 0, X16 = (IO & IO_X16) != 0;
   static_assert(IO == 0 || (F16 && !GATHER), "fp16 storage only with fp16 operands");
@@ -317,6 +320,11 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
   int gy[PA], gx[PA];    // GATHER (NT/NN): grid coordinates of this thread's A rows
   unsigned m9[PA];       // GATHER (NT/NN): bit t set <=> tap t of this row reads a pixel inside the image
   int tn_tap = 0;        // GATHER (TN): the tap this N-tile belongs to (cC % BN == 0)
+  // bf16x3 CHECKER: sign word of the A pieces of this thread in NT / NN launches -- A rows (= token rows of the output) that
+  // lie in an odd 32-row block of the tile are stored NEGATED (see `CHECKER` below).  The transposed loader gives a wave 16
+  // consecutive rows per piece, so the sign is wave-uniform: it lives in an SGPR and costs no vector register.
+  uint32_t ga[PA];
+  auto blk_sign = [](int r) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(r & 32) << 26)); };  // 0x80000000 on odd blocks
   // direct pieces of the fp16 / bf16x3 images: unit idx -> (k-quad g4, column c) of an operand with R columns, column
   // fastest: a wave's 4-byte loads then cover 256 contiguous bytes of a k-row.  (Measured for the bf16x3 form: a k-quad-
   // parity-fastest order, whose 8-byte LDS stores are bank-conflict free, is 0.45 ms per step SLOWER -- two 128-byte row
@@ -333,10 +341,12 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
     ka[i] = 0;
     ha[i] = 0;
     pa[i] = nullptr;
+    ga[i] = 0;
     if (A_TRANS) {
       const int rl = t_r + T_ROWS * i;
       sa[i] = (4 * t_kq) * LDA_S + min(rl, BM - 1);  // surplus lanes repeat row BM-1 (same data, same slot)
       ha[i] = ((t_kq >> 1) * LDA16 + min(rl, BM - 1)) * 4 + 2 * (t_kq & 1);
+      ga[i] = blk_sign(min(rl, BM - 1));
     } else {
       constexpr int QR = BM / 4;
       const int idx = tid + NTHREADS * i;
@@ -770,8 +780,7 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
       typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
       return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
     };
-    auto split3 = [&](const f32x4& v, uint32_t* dst, int plane, bool neg) {
-      const uint32_t sgn = neg ? 0x80008000u : 0u;  // both halves of a packed pair change sign
+    auto split3 = [&](const f32x4& v, uint32_t* dst, int plane, uint32_t sgn) {  // sgn: 0 or 0x80008000 (both halves of a pair)
       typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
       auto lo_f = [](uint32_t w) { return __builtin_bit_cast(float, w << 16); };
       auto hi_f = [](uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); };
@@ -790,8 +799,21 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
       *reinterpret_cast<u32x2*>(dst + 2 * plane) = u32x2{cvt2(s0, s1) ^ sgn, cvt2(s2, s3) ^ sgn};
     };
     if (B3) {
-      if (q < PA) split3(ra[q], Aw + buf * A_STG + ha[q], A_ST16, negate);
-      else split3(rb[q - PA], Bw + buf * B_STG + hb[q - PA], B_ST16, false);
+      constexpr bool CHK = SM3_B3_SIGNED == 2 && MODE != MODE_TN;
+      if (q < PA) {
+        f32x4 va = ra[q];
+        if (CHK) {  // -x splits into exactly the negated pieces of x (round-to-nearest-even is symmetric): four v_xor with an
+                    // SGPR operand before the split instead of six on the packed planes after it
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            const float t = va[e];  // (a scalar temporary: see ldg2 on __builtin_bit_cast of a vector element)
+            va[e] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, t) ^ ga[q]);
+          }
+        }
+        split3(va, Aw + buf * A_STG + ha[q], A_ST16, (!CHK && negate) ? 0x80008000u : 0u);
+      } else {
+        split3(rb[q - PA], Bw + buf * B_STG + hb[q - PA], B_ST16, 0u);
+      }
     } else if (q < PA) {
       if (F16 && A16 && A_TRANS) {
         typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -854,6 +876,18 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
   // tile) / 17.19 (two sets) / 16.77 (one set), and its |error| stays the one-set form's (1.17 ulp at K = 384): the xors
   // take the issue slots of the wave's own MFMAs.
   constexpr bool SIGNED = B3 && SM3_B3_SIGNED == 1;
+  // CHECKER (round 6, the default): ONE accumulator set; the bias is cancelled ACROSS the token rows of the output instead of
+  // inside every element.  What made the bias visible was its coherence over the ~1e5 token rows that a bias / LayerNorm
+  // gradient sums (a -0.1 ulp mean over 131 072 rows is 36 sigma of the rows' rounding noise); everything else sums a few
+  // hundred or thousand terms, where it is 1e-7 relative.  So in the NT / NN launches (output rows = tokens) the A rows of the
+  // odd 32-row blocks of a tile are stored NEGATED: those blocks accumulate -S with the same downward truncation, and after
+  // the sign is restored (once, after the k-loop) their error has mean +b where the even blocks have -b -- a sum over token
+  // rows adds equal numbers of both.  TN launches (weight gradients: the token sum is the k-loop itself, split over up to 256
+  // slices of a few hundred rows each) need nothing.  Cost: 8 v_xor per body in NT / NN (SGPR sign word), none in TN.
+  // 168 VGPRs at 128x128: three workgroups per CU (the two-set form: 230, two).  Per-element mean |error| is the one-set
+  // form's (1.2 / 2.8 ulp at K = 384 / 3072; two sets 0.63 / 1.5; the native fp32 instruction 1.5 / 4.2):
+  // tests/test_gemm_gpu.py guardrail, scripts/probes/b3_bias.py for the column sums.
+  constexpr bool CHECKER = B3 && SM3_B3_SIGNED == 2 && MODE != MODE_TN;
   f32x16 accn[SIGNED ? TI : 1][SIGNED ? TJ : 1];
 
   // Two register sets: while tile kt is multiplied out of LDS, the global loads of tile kt+2 are ISSUED into one set
@@ -1153,6 +1187,17 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16>())) void gemm_f32
     for (int i = 0; i < TI; i++)
 #pragma unroll
       for (int j = 0; j < TJ; j++) acc[i][j] -= accn[SIGNED ? i : 0][SIGNED ? j : 0];
+  }
+  if (CHECKER) {  // the row blocks of this wave that lie in odd 32-row blocks of the tile hold -S
+    const int pw = (wm0 >> 5) & 1;  // wave-uniform
+#pragma unroll
+    for (int i = 0; i < TI; i++)
+#pragma unroll
+      for (int j = 0; j < TJ; j++) {
+        // (a multiplication by +-1, exact; NOT a bit_cast of `acc[i][j][r]` xor a sign word: hipcc 7.2 evaluates
+        // __builtin_bit_cast applied directly to a vector-element expression as element 0 -- see ldg2 above)
+        acc[i][j] *= ((pw ^ i) & 1) ? -1.0f : 1.0f;
+      }
   }
   SM3_TR(2);
   if (CSUM && do_cs && F16) {  // an F16 piece = four k of ONE column (unit idx = k-quad * BM + column): [BK / 4][BM]

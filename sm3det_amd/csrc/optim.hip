@@ -199,7 +199,8 @@ struct DlaCfg {
   int n, n_subnets, n_params;
   int head_policy;      // 0 normal (history / current), 1 reverse, 2 'None'
   int backbone_policy;  // 0 min, 1 avg, 2 max, 3 kl, 4 sigmoid_kl, 5 other (1.0)
-  int warmup_iters;     // LrUpdaterHook.warmup_iters (0: no warm-up)
+  int warmup_iters;     // LrUpdaterHook.warmup_iters; > 0: warm-up for that many iterations; < 0: no warm-up, but the head-weight
+                        // gate `history.steps < warmup_iters` (dynamic_lr.py:124) still reads |warmup_iters|
   float warmup_ratio, T, b, beta;
 };
 __global__ __launch_bounds__(256) void dla_lr_kernel(DlaCfg c, const float* __restrict__ losses,
@@ -219,12 +220,14 @@ __global__ __launch_bounds__(256) void dla_lr_kernel(DlaCfg c, const float* __re
       hist[i] = steps > 0 ? state[i] : 1e-3;  // EMA_meter.get()
     }
     s_all = -1.0;
+    const double gate_iters = (double)(c.warmup_iters < 0 ? -c.warmup_iters : c.warmup_iters);
     if (c.warmup_iters > 0 && it < (double)c.warmup_iters) {
-      // :203-216 -- linear warm-up of the regular lr (mmcv LrUpdaterHook.get_warmup_lr), the EMAs keep updating
+      // :203-216 -- warm-up: the EMAs keep updating; the lr is base * (1 - k) (mmcv LrUpdaterHook.get_warmup_lr).  The host
+      // passes ratio 1 (k = 0: the lr stays the initial lr) for the reference's as-run behaviour, see sm3det_amd/optim.py
       const double k = (1.0 - it / c.warmup_iters) * (1.0 - (double)c.warmup_ratio);
       s_all = 1.0 - k;
     } else {
-      if (steps < (double)c.warmup_iters || c.head_policy == 2) {
+      if (steps < gate_iters || c.head_policy == 2) {
         for (int i = 0; i < n; i++) bw[i] = 1.0;
       } else {
         double mx = -1e300, sum = 0;
@@ -274,7 +277,7 @@ __global__ __launch_bounds__(256) void dla_lr_kernel(DlaCfg c, const float* __re
   for (int p = threadIdx.x; p < c.n_params; p += blockDim.x) {
     const int sn = param_subnet[p];
     const double mult = s_all >= 0.0 ? s_all : (sn >= 0 ? s_w[sn] : s_w[63]);
-    lr[p] = (float)((double)base_lr[p] * sch * mult);
+    lr[p] = (float)((double)base_lr[p] * sch * mult);  // (warm-up ends long before the first decay step: sch == 1 there)
   }
 }
 

@@ -124,117 +124,103 @@ def box_iou_rotated(bboxes1, bboxes2, mode='iou', aligned=False, clockwise=True)
 
 
 # ------------------------------------------------------------------------------------------------ nms family
-class NMSop(Function):
-    """mmcv/mmcv/ops/nms.py:16-34"""
-
-    @staticmethod
-    def forward(ctx, bboxes, scores, iou_threshold, offset, score_threshold, max_num):
-        is_filtering_by_score = score_threshold > 0
-        if is_filtering_by_score:
-            valid_mask = scores > score_threshold
-            bboxes, scores = bboxes[valid_mask], scores[valid_mask]
-            valid_inds = torch.nonzero(valid_mask, as_tuple=False).squeeze(dim=1)
-        inds = ext_module.nms(bboxes.contiguous(), scores.contiguous(), iou_threshold=float(iou_threshold),
-                              offset=offset)
-        if max_num > 0:
-            inds = inds[:max_num]
-        if is_filtering_by_score:
-            inds = valid_inds[inds]
-        return inds
+# Same call surface as mmcv/mmcv/ops/nms.py (``nms`` :125-183, ``nms_rotated`` :422-477, ``batched_nms`` :264-382) -- the
+# names, argument meaning, return pairs and the native calls issued are the reference's (tests/test_ref_wrappers.py checks
+# the native calls one for one against the reference's own wrappers) -- but the bodies are this package's: no autograd
+# Function around an index-returning operator, and ONE kernel launch per ``batched_nms`` whatever the box count.
+def _as_device_tensor(x):
+    """the reference accepts numpy arrays and moves them to the GPU (nms.py:160-166)"""
+    if isinstance(x, np.ndarray):
+        return torch.from_numpy(x).cuda(), True
+    if not isinstance(x, torch.Tensor):
+        raise AssertionError(f'expected a torch.Tensor or numpy array, got {type(x)}')
+    return x, False
 
 
 def nms(boxes, scores, iou_threshold=None, offset=0, score_threshold=0, max_num=-1, iou_thr=None):
-    """Horizontal NMS; returns ``(dets (K,5), inds (K,))``.  ``iou_thr`` is the deprecated alias."""
+    """Horizontal NMS of ``(x1, y1, x2, y2)`` boxes -> ``(dets (K,5) = boxes | score, kept indices (K,))`` in descending
+    score order.  ``iou_thr`` is the deprecated spelling of ``iou_threshold``; ``score_threshold`` drops boxes before the
+    operator runs, ``max_num`` truncates the keep list."""
     if iou_thr is not None:
+        if iou_threshold is not None:
+            raise AssertionError('pass iou_threshold or the deprecated iou_thr, not both')
         warnings.warn('"iou_thr" is deprecated in `nms`, please use "iou_threshold" instead', DeprecationWarning)
-        assert iou_threshold is None
         iou_threshold = iou_thr
-    assert isinstance(boxes, (torch.Tensor, np.ndarray))
-    assert isinstance(scores, (torch.Tensor, np.ndarray))
-    is_numpy = False
-    if isinstance(boxes, np.ndarray):
-        is_numpy = True
-        boxes = torch.from_numpy(boxes).cuda()
-    if isinstance(scores, np.ndarray):
-        scores = torch.from_numpy(scores).cuda()
-    assert boxes.size(1) == 4
-    assert boxes.size(0) == scores.size(0)
-    assert offset in (0, 1)
-    inds = NMSop.apply(boxes, scores, iou_threshold, offset, score_threshold, max_num)
-    dets = torch.cat((boxes[inds], scores[inds].reshape(-1, 1)), dim=1)
-    if is_numpy:
-        dets = dets.cpu().numpy()
-        inds = inds.cpu().numpy()
-    return dets, inds
+    boxes, from_numpy = _as_device_tensor(boxes)
+    scores, _ = _as_device_tensor(scores)
+    if boxes.dim() != 2 or boxes.size(1) != 4 or boxes.size(0) != scores.size(0) or offset not in (0, 1):
+        raise AssertionError(f'nms: boxes (N,4), scores (N,), offset 0|1; got {tuple(boxes.shape)}, '
+                             f'{tuple(scores.shape)}, {offset}')
+    survivors = None
+    cand_boxes, cand_scores = boxes, scores
+    if score_threshold > 0:  # pre-filter: the operator then indexes the filtered list
+        above = scores > score_threshold
+        survivors = above.nonzero(as_tuple=False).squeeze(1)
+        cand_boxes, cand_scores = boxes[above], scores[above]
+    kept = ext_module.nms(cand_boxes.contiguous(), cand_scores.contiguous(), iou_threshold=float(iou_threshold),
+                          offset=offset)
+    if max_num > 0:
+        kept = kept[:max_num]
+    if survivors is not None:
+        kept = survivors[kept]
+    dets = torch.cat((boxes[kept], scores[kept].unsqueeze(1)), dim=1)
+    return (dets.cpu().numpy(), kept.cpu().numpy()) if from_numpy else (dets, kept)
 
 
 def nms_rotated(dets, scores, iou_threshold, labels=None, clockwise=True):
-    """Rotated NMS; returns ``(dets (K,6), keep_inds)``; mmcv/mmcv/ops/nms.py:422-477."""
+    """Rotated NMS of ``(cx, cy, w, h, angle)`` boxes -> ``(dets (K,6), kept indices)``; with ``labels`` only boxes of one
+    label suppress each other.  Counter-clockwise angles are negated for the operator, the returned boxes are the caller's."""
     if dets.shape[0] == 0:
         return dets, None
+    op_boxes = dets
     if not clockwise:
-        flip_mat = dets.new_ones(dets.shape[-1])
-        flip_mat[-1] = -1
-        dets_cw = dets * flip_mat
-    else:
-        dets_cw = dets
-    multi_label = labels is not None
-    dets_wl = torch.cat((dets_cw, labels.unsqueeze(1)), 1) if multi_label else dets_cw
-    _, order = scores.sort(0, descending=True)
-    dets_sorted = dets_wl.index_select(0, order)
-    keep_inds = ext_module.nms_rotated(dets_wl.contiguous(), scores.contiguous(), order, dets_sorted,
-                                       iou_threshold, multi_label)
-    dets = torch.cat((dets[keep_inds], scores[keep_inds].reshape(-1, 1)), dim=1)
-    return dets, keep_inds
+        sign = dets.new_ones(dets.shape[-1])
+        sign[-1] = -1
+        op_boxes = dets * sign
+    with_labels = labels is not None
+    if with_labels:
+        op_boxes = torch.cat((op_boxes, labels.unsqueeze(1)), 1)
+    order = scores.sort(0, descending=True)[1]
+    kept = ext_module.nms_rotated(op_boxes.contiguous(), scores.contiguous(), order, op_boxes.index_select(0, order),
+                                  iou_threshold, with_labels)
+    return torch.cat((dets[kept], scores[kept].unsqueeze(1)), dim=1), kept
 
 
 _NMS_OPS = {'nms': nms, 'nms_rotated': nms_rotated}
 
 
+def _class_separated(boxes, idxs):
+    """boxes moved so that different classes cannot overlap: class c is shifted by c * (extent + 1) along both axes (rotated
+    boxes: the centre is shifted, extent = largest centre coordinate + largest side)"""
+    if boxes.size(-1) == 5:
+        extent = boxes[..., :2].max() + boxes[..., 2:4].max()
+        shift = idxs.to(boxes) * (extent + torch.tensor(1).to(boxes))
+        return torch.cat([boxes[..., :2] + shift[:, None], boxes[..., 2:5]], dim=-1)
+    shift = idxs.to(boxes) * (boxes.max() + torch.tensor(1).to(boxes))
+    return boxes + shift[:, None]
+
+
 def batched_nms(boxes, scores, idxs, nms_cfg, class_agnostic=False):
-    """Per-class NMS through the coordinate-offset trick; mmcv/mmcv/ops/nms.py:264-382."""
+    """NMS within each class ``idxs`` -> ``(boxes | score (K,5|6), kept indices)``, descending score.
+
+    The reference loops over the classes (one operator call and a host read of ``torch.unique`` per class) once the box count
+    reaches ``split_thr``; both of its paths run the operator on the class-separated boxes, where boxes of different classes
+    never intersect, so they keep the same set -- here it is always ONE call (``split_thr`` is accepted and ignored)."""
     if nms_cfg is None:
-        scores, inds = scores.sort(descending=True)
-        boxes = boxes[inds]
-        return torch.cat([boxes, scores[:, None]], -1), inds
-    nms_cfg_ = nms_cfg.copy()
-    class_agnostic = nms_cfg_.pop('class_agnostic', class_agnostic)
-    if class_agnostic:
-        boxes_for_nms = boxes
-    elif boxes.size(-1) == 5:
-        max_coordinate = boxes[..., :2].max() + boxes[..., 2:4].max()
-        offsets = idxs.to(boxes) * (max_coordinate + torch.tensor(1).to(boxes))
-        boxes_ctr_for_nms = boxes[..., :2] + offsets[:, None]
-        boxes_for_nms = torch.cat([boxes_ctr_for_nms, boxes[..., 2:5]], dim=-1)
-    else:
-        max_coordinate = boxes.max()
-        offsets = idxs.to(boxes) * (max_coordinate + torch.tensor(1).to(boxes))
-        boxes_for_nms = boxes + offsets[:, None]
-    nms_type = nms_cfg_.pop('type', 'nms')
-    if nms_type not in _NMS_OPS:
-        raise NotImplementedError(f'nms type {nms_type!r} is outside the SM3Det hot path')
-    nms_op = _NMS_OPS[nms_type]
-    split_thr = nms_cfg_.pop('split_thr', 10000)
-    if boxes_for_nms.shape[0] < split_thr:
-        dets, keep = nms_op(boxes_for_nms, scores, **nms_cfg_)
-        boxes = boxes[keep]
-        scores = dets[:, -1]
-    else:
-        max_num = nms_cfg_.pop('max_num', -1)
-        total_mask = scores.new_zeros(scores.size(), dtype=torch.bool)
-        scores_after_nms = scores.new_zeros(scores.size())
-        for id in torch.unique(idxs):
-            mask = (idxs == id).nonzero(as_tuple=False).view(-1)
-            dets, keep = nms_op(boxes_for_nms[mask], scores[mask], **nms_cfg_)
-            total_mask[mask[keep]] = True
-            scores_after_nms[mask[keep]] = dets[:, -1]
-        keep = total_mask.nonzero(as_tuple=False).view(-1)
-        scores, inds = scores_after_nms[keep].sort(descending=True)
-        keep = keep[inds]
-        boxes = boxes[keep]
-        if max_num > 0:
-            keep = keep[:max_num]
-            boxes = boxes[:max_num]
-            scores = scores[:max_num]
-    boxes = torch.cat([boxes, scores[:, None]], -1)
-    return boxes, keep
+        scores, order = scores.sort(descending=True)
+        return torch.cat([boxes[order], scores[:, None]], -1), order
+    cfg = dict(nms_cfg)
+    class_agnostic = cfg.pop('class_agnostic', class_agnostic)
+    kind = cfg.pop('type', 'nms')
+    if kind not in _NMS_OPS:
+        raise NotImplementedError(f'nms type {kind!r} is outside the SM3Det hot path')
+    cfg.pop('split_thr', None)
+    max_num = cfg.pop('max_num', -1)
+    if kind == 'nms' and max_num > 0:
+        cfg['max_num'] = max_num  # the horizontal operator truncates itself (nms.py:150)
+    dets, kept = _NMS_OPS[kind](boxes if class_agnostic else _class_separated(boxes, idxs), scores, **cfg)
+    if kind != 'nms' and max_num > 0 and kept is not None:
+        dets, kept = dets[:max_num], kept[:max_num]
+    if kept is None:  # nms_rotated on an empty input
+        return torch.cat([boxes, scores[:, None]], -1), kept
+    return torch.cat([boxes[kept], dets[:, -1:]], -1), kept

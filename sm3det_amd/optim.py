@@ -358,19 +358,32 @@ class DynamicLrPolicy:
 
 
 def dynamic_lr_after_train_iter(policy, log_vars, param_names, base_lrs, it, step, gamma=0.1, warmup_iters=0,
-                                warmup_ratio=0.1):
-    """Host form of ``DynamicLrUpdaterHook.after_train_iter`` (dynamic_lr.py:192-217) for iteration index `it`: during the
-    linear warm-up the loss EMAs keep updating and every group gets ``regular_lr * (1 - k)`` (mmcv
-    ``LrUpdaterHook.get_warmup_lr``, mmcv/mmcv/runner/hooks/lr_updater.py:75-92), afterwards ``get_dynamic_lr``.  `policy` is a
-    ``DynamicLrPolicy`` (it carries the EMAs).  -> list of lrs, one per name.  Pinned on the reference hook by
-    tests/test_dla_cpu.py; the device kernel (``DeviceDynamicLr``) is compared with it on the GPU."""
+                                warmup_ratio=0.1, warmup='linear', as_run=True):
+    """Host form of ``DynamicLrUpdaterHook.after_train_iter`` (dynamic_lr.py:192-217) for iteration index `it`.  `policy` is
+    a ``DynamicLrPolicy`` (it carries the EMAs; its ``warmup_iters`` is the hook's, which gates the head weights whether or
+    not a warm-up is configured).  -> list of lrs, one per name.
+
+    Warm-up (``warmup='linear'``, ``it < warmup_iters``): the loss EMAs update and
+
+    * ``as_run=True`` (default): the lr is left alone, i.e. every group keeps its INITIAL lr.  This is what the reference
+      does when run: the hook overrides ``before_train_iter`` with ``pass`` (:189-190), mmcv's ``before_train_epoch`` returns
+      before it sets ``regular_lr`` when ``by_epoch=False`` (lr_updater.py:134-135; IterBasedRunner forces it and calls
+      ``before_epoch`` anyway), so ``regular_lr`` stays ``[]``, ``get_warmup_lr`` returns ``[]`` and ``_set_lr`` writes
+      nothing -- the first `warmup_iters` iterations train at the full base lr.
+    * ``as_run=False``: the ramp mmcv documents, ``regular_lr * (1 - (1 - it / warmup_iters) * (1 - warmup_ratio))``
+      (lr_updater.py:75-92) -- what the config's author presumably intended; kept as an option.
+
+    Pinned on the reference hook over the reference's own ``LrUpdaterHook`` driven the way IterBasedRunner drives it by
+    tests/test_dla_cpu.py; the device kernel (``DeviceDynamicLr``) is compared with this function on the GPU."""
     e = (it // step) if isinstance(step, int) else next((i for i, s_ in enumerate(step) if it < s_), len(step))
     regular = [b * gamma ** e for b in base_lrs]
-    if warmup_iters and it < warmup_iters:
+    if warmup is not None and warmup_iters and it < warmup_iters:
         names = [k for k in log_vars if k in policy.reweight_losses]
         for i, k in enumerate(names):
             v = log_vars[k]
             policy.history[i].update(float(sum(v) if isinstance(v, list) else v))
+        if as_run:
+            return list(base_lrs)
         k_ = (1 - it / warmup_iters) * (1 - warmup_ratio)
         return [r * (1 - k_) for r in regular]
     mult = policy.multipliers(log_vars, param_names)
@@ -399,7 +412,7 @@ class DeviceDynamicLr:
     keys of ``reweight_losses`` count, in the dict's order (as the reference walks ``log_vars``)."""
 
     def __init__(self, optimizer, param_names, step, gamma=0.1, min_lr=None, extra_args=None, reweight_losses=None,
-                 warmup=None, warmup_iters=0, warmup_ratio=0.1, by_epoch=False, **_unused):
+                 warmup=None, warmup_iters=0, warmup_ratio=0.1, by_epoch=False, warmup_as_run=True, **_unused):
         if by_epoch:
             raise NotImplementedError('the dynamic policy asserts by_epoch=False (dynamic_lr.py:217)')
         if warmup not in (None, 'linear'):
@@ -412,8 +425,14 @@ class DeviceDynamicLr:
         self.gamma, self.min_lr = gamma, min_lr
         if min_lr is not None:
             raise NotImplementedError('min_lr clipping is per-tensor host arithmetic in the reference; no SM3Det config sets it')
-        self.warmup_iters = int(warmup_iters) if warmup else 0
-        self.warmup_ratio = float(warmup_ratio)
+        # warmup_iters is kept even without a warm-up: the hook's `history.steps < warmup_iters` gate on the head weights
+        # (dynamic_lr.py:124) reads it either way.  warmup_as_run (default): during the warm-up the lr stays the initial lr,
+        # as in a reference run (see dynamic_lr_after_train_iter) -- passed to the kernel as warm-up ratio 1; False: mmcv's
+        # documented linear ramp from `warmup_ratio`.
+        self.warmup = warmup
+        self.warmup_iters = int(warmup_iters or 0)
+        self.warmup_as_run = bool(warmup_as_run)
+        self.warmup_ratio = 1.0 if (warmup and self.warmup_as_run) else float(warmup_ratio)
         self.opt = optimizer
         if not optimizer._built:
             optimizer._build()
@@ -463,7 +482,8 @@ class DeviceDynamicLr:
         ea = self.extra
         LB.call('dla_lr', cur, len(keys), self._loss_subnet, len(self.subnets), self._param_subnet, self._base_lr,
                 self._base_lr.numel(), self._sched, self._state, _HEAD_POLICY[str(ea['head_policy'])],
-                _BACKBONE_POLICY.get(ea['backbone_policy'], 5), self.warmup_iters, self.warmup_ratio, float(ea['T']),
+                _BACKBONE_POLICY.get(ea['backbone_policy'], 5), self.warmup_iters if self.warmup else -self.warmup_iters,
+                self.warmup_ratio, float(ea['T']),
                 float(ea['b']), float(ea['ema']), self.opt._lr)
         self.opt._dla_owns_lr = True  # the optimizer must not overwrite the device lr vector from its host-side groups
 

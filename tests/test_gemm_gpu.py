@@ -447,3 +447,79 @@ def test_single_term_products_carry_all_24_operand_bits():
             assert rel <= 2.0 ** -22, (ar, rel)
     finally:
         LB.ARITH32 = old
+
+
+# ------------------------------------------------------------------------------------------ bf16x3: the edges of the split
+def _b3_vs_native(A, B):
+    """(max relative-to-scale error of the bf16x3 form, of the native form) for C = A . B^T against the fp64 product"""
+    LB = _mods()
+    ref = A.double() @ B.double().t()
+    out = []
+    old = LB.ARITH32
+    try:
+        for ar in (2, 0):
+            LB.ARITH32 = ar
+            C = torch.full((A.shape[0], B.shape[0]), float('nan'), device='cuda')
+            LB.gemm(LB.NT, A, B, C, A.shape[0], B.shape[0], A.shape[1])
+            out.append(((C.double() - ref).abs().max() / ref.abs().max()).item())
+    finally:
+        LB.ARITH32 = old
+    return out
+
+
+@pytest.mark.parametrize('ea,eb', [(100, -100), (-100, 100), (60, 60), (-60, -60), (-100, 60)])
+def test_bf16x3_extreme_but_normal_magnitudes(ea, eb):
+    """bf16 has fp32's exponent range, so the three-piece split needs no scaling: with operands scaled by 2^+-100 (every
+    piece still a NORMAL bf16: the lowest piece of x sits ~2^-17 below x, i.e. above 2^-126 for |x| >= 2^-109) the error
+    is that of the unscaled problem -- the same 1.5 x native guardrail as on the step's shapes."""
+    A = _rand(512, 384, seed=51) * 2.0 ** ea
+    B = _rand(256, 384, seed=52) * 2.0 ** eb
+    b3, nat = _b3_vs_native(A, B)
+    assert b3 <= 1.5 * nat, (b3, nat)
+
+
+def test_bf16x3_subnormal_low_pieces_degrade_gracefully():
+    """Below |x| ~ 2^-110 the second and third pieces of x (2^-8 and 2^-16 below it) are bf16 SUBNORMALS or underflow to
+    zero, so the operand keeps fewer than 24 bits: the result is still correct to the leading piece and a half (measured
+    and pinned here: relative error <= 2^-7; the native fp32 form keeps ~2^-22).  Documented in DESIGN.md section 4; no tensor
+    of the training step is near this range (activations and weights are O(1e-3..1e2))."""
+    A = _rand(512, 384, seed=53) * 2.0 ** -120
+    B = _rand(256, 384, seed=54) * 2.0 ** 100
+    b3, nat = _b3_vs_native(A, B)
+    assert nat <= 1e-5
+    assert b3 <= 2.0 ** -7, b3
+
+
+def test_bf16x3_non_finite_and_overflowing_operands():
+    """What the default arithmetic does with operands outside the split's domain -- pinned so that a change is noticed:
+    (i) an inf or NaN operand element gives NaN in every output it touches (the split computes inf - inf; the native form
+    would give +-inf for an inf operand) and leaves all other outputs exact; (ii) a FINITE operand above the largest bf16
+    (3.3895e38, the top 0.4 % of the fp32 range) rounds its first piece to bf16-inf and gives a non-finite output, where the
+    native form stays finite.  `SM3_GEMM_ARITH=f32` / `sm3_gemm_desc.compute = 0` selects the native form for such data."""
+    LB = _mods()
+    old = LB.ARITH32
+    try:
+        LB.ARITH32 = 2
+        A, B = _rand(256, 96, seed=55), _rand(128, 96, seed=56)
+        ref = (A.double() @ B.double().t())
+        for bad in (float('inf'), float('-inf'), float('nan')):
+            A2 = A.clone()
+            A2[7, 13] = bad
+            C = torch.empty(256, 128, device='cuda')
+            LB.gemm(LB.NT, A2, B, C, 256, 128, 96)
+            assert torch.isnan(C[7]).all(), bad
+            rest = torch.cat([C[:7], C[8:]]).double()
+            refr = torch.cat([ref[:7], ref[8:]])
+            assert torch.isfinite(rest).all() and ((rest - refr).abs().max() / refr.abs().max()).item() < 1e-5
+        A3 = torch.zeros(256, 96, device='cuda')
+        B3 = torch.zeros(128, 96, device='cuda')
+        A3[:, 0] = 3.4e38      # finite in fp32, above the largest finite bf16
+        B3[:, 0] = 2.0 ** -10  # the exact product 3.3e35 is finite
+        C = torch.empty(256, 128, device='cuda')
+        LB.gemm(LB.NT, A3, B3, C, 256, 128, 96)
+        assert not torch.isfinite(C).any()
+        LB.ARITH32 = 0
+        LB.gemm(LB.NT, A3, B3, C, 256, 128, 96)
+        assert torch.isfinite(C).all() and abs(C[0, 0].item() / (3.4e38 * 2.0 ** -10) - 1) < 1e-6
+    finally:
+        LB.ARITH32 = old

@@ -74,7 +74,8 @@ def test_graph_capture_and_dynamic_lr_policy():
 
 @pytest.mark.parametrize('backbone_policy,head_policy', [('sigmoid_kl', 'normal'), ('min', 'reverse'), ('kl', 'None'),
                                                          ('avg', 'normal'), ('max', 'normal')])
-def test_device_dynamic_lr_matches_the_host_flow_pinned_on_the_reference_hook(backbone_policy, head_policy):
+@pytest.mark.parametrize('as_run', [True, False])  # warm-up as a reference run executes it (default) / mmcv's documented ramp
+def test_device_dynamic_lr_matches_the_host_flow_pinned_on_the_reference_hook(backbone_policy, head_policy, as_run):
     """``DeviceDynamicLr`` (sm3_dla_lr: one launch, no host read) against ``dynamic_lr_after_train_iter`` -- the host form
     that tests/test_dla_cpu.py pins on the reference's own ``DynamicLrUpdaterHook.after_train_iter`` -- over a recorded loss
     sequence that crosses the linear warm-up, both step-decay milestones and has list-valued losses (the GFL head's
@@ -91,7 +92,7 @@ def test_device_dynamic_lr_matches_the_host_flow_pinned_on_the_reference_hook(ba
     extra = {'T': 3, 'b': 0.4, 'ema': 0.001, 'backbone_policy': backbone_policy, 'head_policy': head_policy}
     W, steps_at = 5, [9, 12]
     dla = DeviceDynamicLr(opt, names, step=steps_at, gamma=0.1, extra_args=extra, warmup='linear', warmup_iters=W,
-                          warmup_ratio=1.0 / 3)
+                          warmup_ratio=1.0 / 3, warmup_as_run=as_run)
     pol = DynamicLrPolicy(T=3, b=0.4, ema=0.001, backbone_policy=backbone_policy, head_policy=head_policy, warmup_iters=W)
     keys = ['sar_loss_cls', 'sar_loss_bbox', 'sar_loss_dfl', 'rgb_loss_rpn_cls', 'rgb_loss_rpn_bbox', 'rgb_loss_cls',
             'rgb_loss_bbox', 'ifr_loss_rpn_cls', 'ifr_loss_rpn_bbox', 'ifr_loss_cls', 'ifr_loss_bbox']
@@ -110,7 +111,8 @@ def test_device_dynamic_lr_matches_the_host_flow_pinned_on_the_reference_hook(ba
                 host[k] = float(v[i])
         dla.set_iter(it)
         dla.update(dev)
-        want = dynamic_lr_after_train_iter(pol, host, names, base, it, steps_at, 0.1, W, 1.0 / 3)
+        want = dynamic_lr_after_train_iter(pol, host, names, base, it, steps_at, 0.1, W, 1.0 / 3, warmup='linear',
+                                           as_run=as_run)
         got = opt._lr.cpu().tolist()
         for a, b, n in zip(got, want, names):
             assert abs(a - b) <= 1e-6 * abs(b) + 1e-12, (it, n, a, b)
