@@ -206,7 +206,19 @@ typedef struct sm3_gemm_desc {
                         epilogue none / bias / bias+scale+residual, 1|4|8 with bias+GELU}; NN {1 with none, 4|8 with
                         GELU'}; TN {2, 1|2}.  Flagged pointers address _Float16 elements; leading dimensions stay in
                         elements; weights, biases, residual and colsum outputs are always fp32 */
+  /* compute == 2: io bit 16 (A) / 32 (B) = the operand arrives as bf16x3 PLANES (sm3_split_planes_f32 below) instead of
+     fp32: NT / NN only.  A: the planes of A[M][K], lda = rows per k-octet block of the planes tensor.  B: the planes of the
+     k-contiguous form of B -- B[N][K] in NT, B^T (made with transpose = 1) in NN -- ldb = rows per octet block, stride_b =
+     rows between groups.  Results are bit-identical to the fp32-operand launch. */
 } sm3_gemm_desc;
+/* bf16x3 operand planes of an fp32 matrix x[rows][cols] (leading dimension ld): planes[p][o][r][j] = piece p (of the exact
+ * three-way bf16 split, round-to-nearest-even each) of element (r, 8 o + j) -- 3 planes x (K / 8) octet blocks x Rp rows x 8
+ * bf16, i.e. one 16-byte granule per plane, k-octet and row.  transpose != 0: the planes of x^T (K = rows of x, plane rows =
+ * columns of x).  The matrix occupies plane rows [row_off, row_off + R) so that several matrices of equal K (the experts of a
+ * layer) share one planes tensor.  What it replaces: the per-tile operand split of the bf16x3 GEMM loader for operands that
+ * many tiles / launches read (weights: once per optimizer step). */
+int sm3_split_planes_f32(const float* x, int rows, int cols, long ld, void* planes, long Rp, long row_off, int transpose,
+                         sm3_stream_t stream);
 int sm3_gemm_f32_counter_slots(void);
 size_t sm3_gemm_f32_workspace_bytes(const sm3_gemm_desc* desc);
 int sm3_gemm_f32(const sm3_gemm_desc* desc, void* workspace, size_t workspace_bytes, sm3_stream_t stream);

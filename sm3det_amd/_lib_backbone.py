@@ -33,6 +33,7 @@ def signatures():
         'sm3_gemm_f32_counter_slots': (I, []),
         'sm3_gemm_f32_workspace_bytes': (S, [D]),
         'sm3_gemm_f32': (I, [D, P, S, P]),
+        'sm3_split_planes_f32': (I, [P, I, I, LL, P, LL, LL, I, P]),
         'sm3_colsum_f32': (I, [P, I, I, I, P, I, P, P]),
         'sm3_stem_patchify': (I, [P, P, I, I, I, P]),
         'sm3_layernorm_fwd': (I, [P, P, P, F, P, P, P, LL, I, I, I, I, P]),
@@ -185,6 +186,18 @@ def gemm_counters(device):
 
 
 IO_A16, IO_B16, IO_C16, IO_X16 = 1, 2, 4, 8  # sm3_gemm_desc.io: tensors stored as fp16 (the AMP data path)
+IO_APL, IO_BPL = 16, 32                      # ... operands stored as bf16x3 planes (fp32 path, NT / NN)
+
+
+def planes(x, transpose=False, out=None, row_off=0, rows_total=None):
+    """bf16x3 operand planes of the fp32 matrix x (R, K) -- or of x^T with transpose=True -- as a (3, K / 8, rows_total, 8)
+    bfloat16 tensor (sm3_split_planes_f32); `out` / `row_off` place it inside a larger planes tensor (grouped operands)."""
+    R, K = (x.shape[1], x.shape[0]) if transpose else (x.shape[0], x.shape[1])
+    if out is None:
+        out = torch.empty(3, K // 8, rows_total or R, 8, dtype=torch.bfloat16, device=x.device)
+    call('split_planes_f32', x, x.shape[0], x.shape[1], x.stride(0), out, out.shape[2], row_off, int(transpose),
+         nbytes=10.0 * x.numel())
+    return out
 
 
 def gemm(mode, A, B, C, M, N, K, *, epilogue=EPI_NONE, bias=None, aux_in=None, aux_out=None, gamma=None,
@@ -228,7 +241,20 @@ def gemm(mode, A, B, C, M, N, K, *, epilogue=EPI_NONE, bias=None, aux_in=None, a
     aux = aux_in if aux_in is not None else aux_out
     d.io = ((IO_A16 if A.dtype == h else 0) | (IO_B16 if B.dtype == h else 0) | (IO_C16 if C.dtype == h else 0) |
             (IO_X16 if (aux is not None and aux.dtype == h) else 0))
-    if d.io and not COMPUTE:
+    pl = 0
+    if A.dtype == torch.bfloat16 or B.dtype == torch.bfloat16:  # bf16x3 operand planes (3, K / 8, rows, 8): see `planes`
+        if COMPUTE or d.compute != 2 or mode == TN:
+            from ._lib import SM3Error
+            raise SM3Error('bf16x3 operand planes are an operand form of the fp32 (bf16x3-arithmetic) NT / NN GEMMs only')
+        if A.dtype == torch.bfloat16:
+            pl |= IO_APL
+            d.lda = A.shape[2]
+        if B.dtype == torch.bfloat16:
+            pl |= IO_BPL
+            d.ldb = B.shape[2]
+            d.stride_b = N  # rows between the groups' blocks
+        d.io = pl
+    if d.io and not COMPUTE and not pl:
         from ._lib import SM3Error
         raise SM3Error('fp16 tensors reached an fp32 GEMM (outside amp.autocast)')
     ws = None

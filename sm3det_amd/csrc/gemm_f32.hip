@@ -406,13 +406,24 @@ size_t sm3_gemm_f32_workspace_bytes(const sm3_gemm_desc* d) {
 int sm3_gemm_f32(const sm3_gemm_desc* d, void* workspace, size_t workspace_bytes, sm3_stream_t stream) {
   if (!d) return SM3_ERR_INVALID_ARG;
   if (d->M < 0 || d->N <= 0 || d->K < 0) return SM3_ERR_INVALID_ARG;
-  if ((d->lda & 3) || (d->ldb & 3) || (d->N & 3)) return SM3_ERR_UNSUPPORTED;  // float4 loads
+  if ((d->N & 3) || (!(d->compute == 2 && (d->io & IO_APL)) && (d->lda & 3)) || (!(d->compute == 2 && (d->io & IO_BPL)) && (d->ldb & 3)))
+    return SM3_ERR_UNSUPPORTED;  // float4 loads (plane operands: lda / ldb count rows, any value)
   if (d->mode != MODE_TN && (d->K % 32) != 0) return SM3_ERR_UNSUPPORTED;
   if (d->mode == MODE_TN && (d->M & 3)) return SM3_ERR_UNSUPPORTED;
   if (d->mode == MODE_TN && d->epilogue != EPI_NONE) return SM3_ERR_INVALID_ARG;
   if (d->mode != MODE_NT && d->mode != MODE_NN && d->mode != MODE_TN) return SM3_ERR_INVALID_ARG;
   if (d->compute != 0 && d->compute != 1 && d->compute != 2) return SM3_ERR_INVALID_ARG;
-  if (d->io != 0 && (d->compute != 1 || d->io < 0 || d->io > 15)) return SM3_ERR_INVALID_ARG;
+  const int pl = d->compute == 2 ? (d->io & (IO_APL | IO_BPL)) : 0;  // operands as bf16x3 planes (planes.hip)
+  if (d->io != 0 && !pl && (d->compute != 1 || d->io < 0 || d->io > 15)) return SM3_ERR_INVALID_ARG;
+  if (pl) {
+    if (d->io != pl || d->mode == MODE_TN) return SM3_ERR_UNSUPPORTED;
+    if (((pl & IO_APL) && (reinterpret_cast<uintptr_t>(d->A) & 15)) || ((pl & IO_BPL) && (reinterpret_cast<uintptr_t>(d->B) & 15)))
+      return SM3_ERR_INVALID_ARG;  // 16-byte granules
+    // lda / ldb = rows per k-octet block of the planes; the three planes must stay inside a 32-bit byte offset
+    if (((pl & IO_APL) && (d->lda < d->M || 3l * (d->K / 8) * d->lda * 16 >= (1l << 31) - 65536)) ||
+        ((pl & IO_BPL) && (d->ldb < d->N || 3l * (d->K / 8) * d->ldb * 16 >= (1l << 31) - 65536)))
+      return SM3_ERR_UNSUPPORTED;
+  }
   // fp16-stored operands: 8-byte loads of k-quads (lda % 4, checked above) / 4-byte loads of column pairs (even dims)
   if (d->mode == MODE_TN && (((d->io & 1) && (d->M & 1)) || ((d->io & 2) && (d->N & 1)))) return SM3_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
@@ -485,6 +496,9 @@ int sm3_gemm_f32(const sm3_gemm_desc* d, void* workspace, size_t workspace_bytes
   if (d->compute == 1) {
     rc = d->mode == MODE_NT ? launch_nt16(p, d->epilogue, c.tile, c.bk, d->io, grid, st)
                             : launch_nn16(p, d->epilogue, c.tile, c.bk, d->io, grid, st);
+  } else if (d->compute == 2 && pl) {
+    rc = d->mode == MODE_NT ? launch_nt_b3_pl(p, d->epilogue, c.tile, pl, grid, st)
+                            : launch_nn_b3_pl(p, d->epilogue, c.tile, pl, grid, st);
   } else if (d->compute == 2) {
     rc = d->mode == MODE_NT ? launch_nt_b3(p, d->epilogue, c.tile, grid, st)
                             : launch_nn_b3(p, d->epilogue, c.tile, grid, st);

@@ -130,8 +130,18 @@ using T64x128 = Tile<2, 2, 1, 2>;
 #ifndef SM3_B3_OCC
 #define SM3_B3_OCC (SM3_B3_SIGNED == 1 ? 2 : 3)  // bf16x3 form: workgroups per CU the launch bounds ask for
 #endif
-template <class TL, int BK, int F16 = 0, int CSUM = 0>
+#ifndef SM3_PL_AB_OCC
+#define SM3_PL_AB_OCC 2  // both operands as planes at 128x128: six 16-byte pieces per register set spill at 168 VGPRs
+#endif
+template <class TL, int BK, int F16 = 0, int CSUM = 0, int IO = 0, int MODE = -1>
 constexpr int occupancy() {
+  if (F16 == 2 && IO == 48 && TL::TI * TL::TJ >= 4) return SM3_PL_AB_OCC;
+#ifndef SM3_F16_KEEP_SPILLS  // (A/B: --variant f16_spills restores round 5's bounds)
+  // fp16 operands: the instantiations that do not fit 168 registers (round 5: 4-40 spilled VGPRs, reloaded inside the tail
+  // loop = the WHOLE loop of the K = 96 / 192 launches, and inside the bulk loop of the column-sum weight gradients) run at
+  // two workgroups per CU instead -- the loop is bound by operand delivery, which did not care (7.07 vs 7.01 ms, round 3)
+  if (F16 == 1 && ((MODE == MODE_NT && TL::TI * TL::TJ >= 4 && BK == 32) || CSUM)) return 2;
+#endif
   // F16: the fp16 LDS image of a k-step-32 tile is 34 KB (the fp32 image 66 KB), so three workgroups fit a CU and the
   // loop -- bound by load latency, not by the matrix pipe -- gets a third wave per SIMD to hide it; k-step 64 (68 KB,
   // twice the MFMAs per barrier) runs two
@@ -189,12 +199,21 @@ __device__ __forceinline__ void gelu_erf_both(float h, float& y, float& dy) {
 // C-wide gradient stay fp32; the LayerNorm output that feeds the GEMMs and the three 4C-wide tensors of a block (GELU
 // output, GELU', their gradient) are fp16: half the bytes of the launches that move them.
 constexpr int IO_A16 = 1, IO_B16 = 2, IO_C16 = 4, IO_X16 = 8;  // A operand, B operand, C output, aux_in / aux_out
+// IO (F16 = 2, NT / NN): which operands arrive as bf16x3 PLANES (planes.hip: planes[p][k / 8][row][8], one 16-byte granule per
+// plane, k-octet and row) instead of fp32 -- split once by their producer, moved by the loader as they are (one 16-byte load
+// and one 16-byte LDS store per granule, no arithmetic).  A: `A` addresses the planes of A[M][K], lda = rows per octet block;
+// B: the planes of the K-CONTIGUOUS form of B -- B[N][K] in NT, B^T in NN -- ldb = rows per octet block, strideB = rows
+// between groups.  Bit-identical results to the fp32-operand launch (the split is the same arithmetic).
+constexpr int IO_APL = 16, IO_BPL = 32;
 
 template <int MODE, int EPI, int BK, class TL, int GATHER, int F16 = 0, int CSUM = 0, int IO = 0>
-__global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16, CSUM>())) void gemm_f32_kernel(GemmParams p) {
+__global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16, CSUM, IO, MODE>())) void gemm_f32_kernel(GemmParams p) {
   constexpr int BM = TL::BM, BN = TL::BN, TI = TL::TI, TJ = TL::TJ, WN = TL::WN, WM = TL::WM;
   constexpr bool A16 = (IO & IO_A16) != 0, B16 = (IO & IO_B16) != 0, C16 = (IO & IO_C16) != 0, X16 = (IO & IO_X16) != 0;
-  static_assert(IO == 0 || (F16 && !GATHER), "fp16 storage only with fp16 operands");
+  constexpr bool APL = (IO & IO_APL) != 0, BPL = (IO & IO_BPL) != 0;
+  static_assert(IO == 0 || (F16 == 1 && !GATHER && (IO & ~15) == 0) ||
+                    (F16 == 2 && !GATHER && MODE != MODE_TN && (IO & ~(IO_APL | IO_BPL)) == 0),
+                "fp16 storage only with fp16 operands; bf16x3 planes only in the plain NT / NN launches");
   // B16 in NT / NN: the B operand is an fp16 SHADOW of the weights (what wrap_fp16_model's half model holds), see gemm_h16.hip
   static_assert(!X16 || EPI == EPI_BIAS_GELU || EPI == EPI_GELU_BWD, "fp16 auxiliary tensor = GELU' only");
   constexpr int EA = A16 ? 2 : 4, EB = B16 ? 2 : 4;  // bytes per element in HBM
@@ -220,7 +239,7 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16, CSUM>())) void ge
   // instruction runs at the VECTOR rate (1/16 of the bf16 rate), this form at 6/16 of it.  k-step 16 only (the three
   // planes of a k-step-32 tile would not leave room for two workgroups per CU).
   constexpr bool B3 = (F16 == 2);
-  static_assert(!B3 || (BK == 16 && IO == 0 && !(MODE == MODE_TN && GATHER == 1)), "bf16x3 form: k-step 16, fp32 tensors; TN gather only in the row-aligned form (GATHER == 2)");
+  static_assert(!B3 || (BK == 16 && (IO & 15) == 0 && !(MODE == MODE_TN && GATHER == 1)), "bf16x3 form: k-step 16, fp32 tensors or planes; TN gather only in the row-aligned form (GATHER == 2)");
   constexpr int NIMG = B3 ? 3 : 1;
   constexpr int LDA16 = BM + 4, LDB16 = BN + 4;                          // rows per k-octet
   constexpr int A_ST16 = (BK / 8) * LDA16 * 4, B_ST16 = (BK / 8) * LDB16 * 4;  // dwords per plane and stage
@@ -292,9 +311,11 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16, CSUM>())) void ge
   const int t_kq = tid % KQ, t_r = tid / KQ;
   // direct loader (source k-major) of an operand with R columns: quad index tid + 256 i -> (k row, column quad)
   // (direct pieces of an fp16-stored operand: one piece = 4 consecutive k of TWO adjacent columns, four 4-byte loads)
-  constexpr int PA = A_TRANS ? (BM + T_ROWS - 1) / T_ROWS
+  // planes: piece q = plane q of the tile: (BK / 8) k-octets x rows granules of 16 bytes, one per thread
+  static_assert(!(APL || BPL) || (BK == 16 && 2 * BM <= NTHREADS && 2 * BN <= NTHREADS), "plane pieces: one granule per thread");
+  constexpr int PA = APL ? 3 : A_TRANS ? (BM + T_ROWS - 1) / T_ROWS
                              : ((A16 ? (BK / 4) * (BM / 2) : BK * (BM / 4)) + NTHREADS - 1) / NTHREADS;
-  constexpr int PB = B_TRANS ? (BN + T_ROWS - 1) / T_ROWS
+  constexpr int PB = BPL ? 3 : B_TRANS ? (BN + T_ROWS - 1) / T_ROWS
                              : ((B16 ? (BK / 4) * (BN / 2) : BK * (BN / 4)) + NTHREADS - 1) / NTHREADS;
   constexpr int NP = PA + PB;  // pieces (one 16-byte load per thread each) per k-tile
   constexpr int KP = BK / 2;   // k-pairs = MFMA groups per k-tile
@@ -324,6 +345,7 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16, CSUM>())) void ge
   // lie in an odd 32-row block of the tile are stored NEGATED (see `CHECKER` below).  The transposed loader gives a wave 16
   // consecutive rows per piece, so the sign is wave-uniform: it lives in an SGPR and costs no vector register.
   uint32_t ga[PA];
+  const uint32_t gapl = APL ? (((uint32_t)((tid % BM) & 32) << 10) | ((uint32_t)((tid % BM) & 32) << 26)) : 0u;  // planes: per lane
   auto blk_sign = [](int r) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(r & 32) << 26)); };  // 0x80000000 on odd blocks
   // direct pieces of the fp16 / bf16x3 images: unit idx -> (k-quad g4, column c) of an operand with R columns, column
   // fastest: a wave's 4-byte loads then cover 256 contiguous bytes of a k-row.  (Measured for the bf16x3 form: a k-quad-
@@ -342,6 +364,11 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16, CSUM>())) void ge
     ha[i] = 0;
     pa[i] = nullptr;
     ga[i] = 0;
+    if (APL) {  // plane piece i: granule (k-octet tid / BM, tile row tid % BM) of plane i (surplus threads repeat a granule)
+      sa[i] = 0;
+      ha[i] = (min(tid / BM, BK / 8 - 1) * LDA16 + tid % BM) * 4;
+      continue;
+    }
     if (A_TRANS) {
       const int rl = t_r + T_ROWS * i;
       sa[i] = (4 * t_kq) * LDA_S + min(rl, BM - 1);  // surplus lanes repeat row BM-1 (same data, same slot)
@@ -375,6 +402,11 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16, CSUM>())) void ge
     kb[i] = 0;
     hb[i] = 0;
     pb[i] = nullptr;
+    if (BPL) {
+      sb[i] = 0;
+      hb[i] = (min(tid / BN, BK / 8 - 1) * LDB16 + tid % BN) * 4;
+      continue;
+    }
     if (B_TRANS) {
       const int rl = t_r + T_ROWS * i;
       sb[i] = (4 * t_kq) * LDB_S + min(rl, BN - 1);
@@ -501,6 +533,11 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16, CSUM>())) void ge
     g = __builtin_amdgcn_readfirstlane(g);
 #pragma unroll
     for (int i = 0; i < PA; i++) {
+      if (APL) {  // byte offset of this thread's granule inside an octet block pair, rows past the tile's end repeat the last
+        const int rr = max(min(tid % BM, row_end - 1 - row0), 0);
+        oa[i] = (unsigned)(((long)min(tid / BM, BK / 8 - 1) * p.lda + rr) * 16);
+        continue;
+      }
       if (A_TRANS) {
         const int rl = t_r + T_ROWS * i;
         const int r = min(row0 + min(rl, BM - 1), row_end - 1);
@@ -550,11 +587,17 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16, CSUM>())) void ge
         }
       }
     }
-    if (MODE == MODE_TN) a_base = reinterpret_cast<const char*>(Ag) + (long)row0 * p.lda * EA;
+    if (APL) a_base = reinterpret_cast<const char*>(Ag) + (long)row0 * 16;
+    else if (MODE == MODE_TN) a_base = reinterpret_cast<const char*>(Ag) + (long)row0 * p.lda * EA;
     else if (GATHER) a_base = reinterpret_cast<const char*>(Ag) - (long)(p.sW + 1) * p.cC * 4;
     else a_base = reinterpret_cast<const char*>(Ag) + ((long)row0 * p.lda + (long)kbase * BK) * EA;
 #pragma unroll
     for (int i = 0; i < PB; i++) {
+      if (BPL) {
+        const int nn = max(min(tid % BN, p.N - 1 - n0), 0);
+        ob[i] = (unsigned)(((long)min(tid / BN, BK / 8 - 1) * p.ldb + nn) * 16);
+        continue;
+      }
       if (B_TRANS) {
         const int rl = t_r + T_ROWS * i;
         const int n = min(n0 + min(rl, BN - 1), p.N - 1);
@@ -599,7 +642,8 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16, CSUM>())) void ge
         }
       }
     }
-    if (MODE == MODE_NT) b_base = reinterpret_cast<const char*>(Bg) + ((long)n0 * p.ldb + (long)kbase * BK) * EB;
+    if (BPL) b_base = reinterpret_cast<const char*>(p.B) + ((long)g * p.strideB + n0) * 16;
+    else if (MODE == MODE_NT) b_base = reinterpret_cast<const char*>(Bg) + ((long)n0 * p.ldb + (long)kbase * BK) * EB;
     else if (MODE == MODE_NN) b_base = reinterpret_cast<const char*>(Bg) + (GATHER ? 0 : (long)kbase * BK * p.ldb) * EB;
     else if (GATHER == 2) b_base = reinterpret_cast<const char*>(Bg) - (long)(p.sW + 1) * p.cC * 4;
     else b_base = reinterpret_cast<const char*>(Bg) + (long)row0 * p.ldb * EB;
@@ -619,8 +663,11 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16, CSUM>())) void ge
                                 : (long)(p.K - (long)kbase * BK - 1) * p.ldb + p.N;
       if (!valid) a_valid = 0;
     }
-    a_rsrc = make_rsrc(a_base, a_valid, EA);
-    b_rsrc = make_rsrc(b_base, b_valid, EB);
+    // planes: the extent is what is left of the three planes behind the base (in 4-byte units)
+    if (APL) a_valid = valid ? ((long)3 * (p.K >> 3) * p.lda - row0) * 4 : 0;
+    if (BPL) b_valid = ((long)3 * (p.K >> 3) * p.ldb - ((long)g * p.strideB + n0)) * 4;
+    a_rsrc = make_rsrc(a_base, a_valid, APL ? 4 : EA);
+    b_rsrc = make_rsrc(b_base, b_valid, BPL ? 4 : EB);
   };
   int item = blockIdx.x;
   setup_item(item);
@@ -648,6 +695,14 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16, CSUM>())) void ge
   };
   auto load_piece = [&](f32x4 (&ra)[PA], f32x4 (&rb)[PB], int q, int kt, bool tail) {
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    if (APL && q < PA) {  // plane q, k-octets 2 (kbase + kt) and + 1: scalar offset, one 16-byte granule per thread
+      ra[q] = ldg(a_rsrc, ((long)q * (p.K >> 3) + 2 * (kt + kbase)) * p.lda * 16, oa[q]);
+      return;
+    }
+    if (BPL && q >= PA) {
+      rb[q - PA] = ldg(b_rsrc, ((long)(q - PA) * (p.K >> 3) + 2 * (kt + kbase)) * p.ldb * 16, ob[q - PA]);
+      return;
+    }
     if (q < PA) {
       if (MODE == MODE_TN && F16) {
         // rows past the segment end lie beyond the descriptor's extent and read 0: no clamp, no select, bulk or tail
@@ -753,9 +808,14 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16, CSUM>())) void ge
   // piece passes through store_piece exactly once, already masked / zeroed where the tile does not exist.
   // (CSUM is a template flag: hipcc turns the branch into predicated adds, which the plain TN launches must not pay)
   const bool do_cs = CSUM && MODE == MODE_TN && p.csum != nullptr && tile_n == 0;
-  f32x4 csa[PA];
+  f32x4 csa[(CSUM && !F16) ? PA : 1];  // fp32 image: a piece = four COLUMNS at one k -> four running sums per piece
 #pragma unroll
-  for (int i = 0; i < PA; i++) csa[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < ((CSUM && !F16) ? PA : 1); i++) csa[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // fp16 / bf16x3 images: a piece = four consecutive k of ONE column, so one running sum per piece is enough (the four
+  // lanes-of-a-vector form held PA x 4 registers: up to 40 spilled VGPRs in the k-step-64 weight-gradient kernels)
+  float cs1[(CSUM && F16) ? PA : 1];
+#pragma unroll
+  for (int i = 0; i < ((CSUM && F16) ? PA : 1); i++) cs1[i] = 0.f;
   // live == false (uniform, tail steps only): the tile does not exist (index >= nk) and zeros are stored instead -- the
   // k-loop runs an even number of steps without a branch between them, so the step after the last tile of an odd nk
   // multiplies this all-zero stage
@@ -764,7 +824,8 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16, CSUM>())) void ge
     f32x4 ra[PA], rb[PB];
     if (q < PA) ra[q] = live ? ra_[q] : z4;
     else rb[q - PA] = live ? rb_[q - PA] : z4;
-    if (CSUM && q < PA && do_cs) csa[q] += ra[q];
+    if (CSUM && !F16 && q < PA && do_cs) csa[(CSUM && !F16) ? q : 0] += ra[q];
+    if (CSUM && F16 && q < PA && do_cs) cs1[(CSUM && F16) ? q : 0] += (ra[q][0] + ra[q][1]) + (ra[q][2] + ra[q][3]);
     typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
     auto pack2 = [](float x, float y) {  // round-to-nearest-even, like a torch .half() cast
       return __builtin_bit_cast(uint32_t, f16x2{(_Float16)x, (_Float16)y});
@@ -800,7 +861,17 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16, CSUM>())) void ge
     };
     if (B3) {
       constexpr bool CHK = SM3_B3_SIGNED == 2 && MODE != MODE_TN;
-      if (q < PA) {
+      typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
+      if (APL && q < PA) {  // a granule of plane q as it is (sign of the row block applied to all eight pieces)
+        const float t0 = ra[q][0], t1 = ra[q][1], t2 = ra[q][2], t3 = ra[q][3];
+        const uint32_t sg = CHK ? gapl : 0u;
+        *reinterpret_cast<u32x4s*>(Aw + buf * A_STG + q * A_ST16 + ha[q]) =
+            u32x4s{bits(t0) ^ sg, bits(t1) ^ sg, bits(t2) ^ sg, bits(t3) ^ sg};
+      } else if (BPL && q >= PA) {
+        const int i = q - PA;
+        const float t0 = rb[i][0], t1 = rb[i][1], t2 = rb[i][2], t3 = rb[i][3];
+        *reinterpret_cast<u32x4s*>(Bw + buf * B_STG + i * B_ST16 + hb[i]) = u32x4s{bits(t0), bits(t1), bits(t2), bits(t3)};
+      } else if (q < PA) {
         f32x4 va = ra[q];
         if (CHK) {  // -x splits into exactly the negated pieces of x (round-to-nearest-even is symmetric): four v_xor with an
                     // SGPR operand before the split instead of six on the packed planes after it
@@ -1040,7 +1111,7 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16, CSUM>())) void ge
       }
 #endif
   };
-  static_assert(!B3 || NP <= 4, "bf16x3 body: one piece per product slot, four slots");
+  static_assert(!B3 || NP <= 6, "bf16x3 body: one piece per product slot, six slots (fp32 operands use four)");
   auto b3_piece = [&](f32x4 (&ra)[PA], f32x4 (&rb)[PB], int q, int stage, bool live, int kt_load, bool tail, bool neg) {
     if (q >= NP) return;
 #ifndef SM3_ABL_NOSTORE
@@ -1087,7 +1158,12 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16, CSUM>())) void ge
     b3_piece(ra, rb, 3, nx, live, kt_load, tail, neg_store);
     slot_mix();
     prod(0, 1, par);
+    if (NP > 4) {
+      b3_piece(ra, rb, 4, nx, live, kt_load, tail, neg_store);
+      slot_mix();
+    }
     prod(0, 0, par);
+    if (NP > 5) b3_piece(ra, rb, 5, nx, live, kt_load, tail, neg_store);
     __syncthreads();
   };
   if (B3) {
@@ -1207,7 +1283,7 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16, CSUM>())) void ge
       const int idx = tid + NTHREADS * i;
       int g4, c;
       unit_gc(idx, BM, g4, c);
-      if (idx < (BK / 4) * BM) red[g4 * BM + c] = (csa[i][0] + csa[i][1]) + (csa[i][2] + csa[i][3]);
+      if (idx < (BK / 4) * BM) red[g4 * BM + c] = cs1[(CSUM && F16) ? i : 0];
     }
     __syncthreads();
     if (tid < BM && m0 + tid < p.M) {
@@ -1223,7 +1299,7 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16, CSUM>())) void ge
 #pragma unroll
     for (int i = 0; i < PA; i++) {
       const int idx = tid + NTHREADS * i;
-      if (idx < BK * QRc) *reinterpret_cast<f32x4*>(red + (idx / QRc) * (BM + 4) + 4 * (idx % QRc)) = csa[i];
+      if (idx < BK * QRc) *reinterpret_cast<f32x4*>(red + (idx / QRc) * (BM + 4) + 4 * (idx % QRc)) = csa[(CSUM && !F16) ? i : 0];
     }
     __syncthreads();
     if (tid < BM && m0 + tid < p.M) {
@@ -1489,6 +1565,9 @@ int launch_tn_h16(const GemmParams& p, int tile, int bk, int io, dim3 grid, hipS
 int launch_nt_b3(const GemmParams& p, int epi, int tile, dim3 grid, hipStream_t st);
 int launch_nn_b3(const GemmParams& p, int epi, int tile, dim3 grid, hipStream_t st);
 int launch_tn_b3(const GemmParams& p, int tile, dim3 grid, hipStream_t st);
+// ... with operands as bf16x3 planes (io = IO_APL | IO_BPL bits; gemm_b3_pl_{nt,nn}.hip)
+int launch_nt_b3_pl(const GemmParams& p, int epi, int tile, int io, dim3 grid, hipStream_t st);
+int launch_nn_b3_pl(const GemmParams& p, int epi, int tile, int io, dim3 grid, hipStream_t st);
 // implicit-GEMM 3x3 convolutions in the bf16x3 form (128x128 tile, k-step 16; weight gradient: the row-aligned gather only)
 int launch_nt_b3_conv(const GemmParams& p, int epi, dim3 grid, hipStream_t st);
 int launch_nn_b3_conv(const GemmParams& p, dim3 grid, hipStream_t st);
