@@ -48,89 +48,113 @@ __device__ __forceinline__ bool hull_less(Pt A, Pt B) {
   return t > 0;
 }
 
-__device__ __forceinline__ void ins_unguarded(Pt* i) {  // libstdc++ __unguarded_linear_insert
-  Pt val = *i;
-  Pt* next = i - 1;
-  while (hull_less(val, *next)) {
-    *i = *next;
+// ---- per-lane scratch of the polygon clipping, in LDS --------------------------------------------------------------------
+// The reference algorithm indexes two 24-point arrays and an 8-entry introsort stack with run-time indices.  As plain local
+// arrays those live in private (scratch) memory: 528 bytes per lane, HBM-backed, in every kernel that computes a rotated IoU
+// (round 5; it also was the one thing the kernels that faulted under two processes sharing a GPU had in common).  Here they are
+// a slice of LDS: one 24-point array per lane (the hull candidates are shifted, sorted and scanned IN PLACE: q[i] is only
+// written at positions <= the one being read) and the sort's stack as 8 packed (lo, hi) index pairs.  Element e of lane l sits
+// at word (e * 64 + l): a wave instruction in which every lane reads a different element still touches 64 distinct 8-byte
+// slots, one per lane column -- conflict-free for ds_read_b64 / ds_write_b64.  No private segment is left.
+constexpr int IOU_PTS = 24;
+constexpr int IOU_STACK = 8;
+constexpr int IOU_LDS_WORDS_PER_WAVE = IOU_PTS * 64 * 2 + IOU_STACK * 64;  // 32-bit words: 14 336 B per wave
+struct IouScratch {
+  Pt* pts;          // this lane's column of the wave's [IOU_PTS][64] point array
+  uint32_t* stack;  // this lane's column of the wave's [IOU_STACK][64] array
+  __device__ __forceinline__ Pt get(int i) const { return pts[i * 64]; }
+  __device__ __forceinline__ void set(int i, Pt v) const { pts[i * 64] = v; }
+};
+__device__ __forceinline__ IouScratch iou_scratch(uint32_t* wave_words, int lane) {
+  return IouScratch{reinterpret_cast<Pt*>(wave_words) + lane, wave_words + IOU_PTS * 64 * 2 + lane};
+}
+
+__device__ __forceinline__ void ins_unguarded(const IouScratch& q, int i) {  // libstdc++ __unguarded_linear_insert
+  const Pt val = q.get(i);
+  int next = i - 1;
+  while (hull_less(val, q.get(next))) {
+    q.set(i, q.get(next));
     i = next;
     --next;
   }
-  *i = val;
+  q.set(i, val);
 }
-__device__ __forceinline__ void ins_sort(Pt* first, Pt* last) {  // libstdc++ __insertion_sort
+__device__ __forceinline__ void ins_sort(const IouScratch& q, int first, int last) {  // libstdc++ __insertion_sort
   if (first == last) return;
-  for (Pt* i = first + 1; i != last; ++i) {
-    if (hull_less(*i, *first)) {
-      Pt val = *i;
-      for (Pt* j = i; j != first; --j) *j = *(j - 1);
-      *first = val;
+  for (int i = first + 1; i != last; ++i) {
+    if (hull_less(q.get(i), q.get(first))) {
+      const Pt val = q.get(i);
+      for (int j = i; j != first; --j) q.set(j, q.get(j - 1));
+      q.set(first, val);
     } else {
-      ins_unguarded(i);
+      ins_unguarded(q, i);
     }
   }
 }
-__device__ __forceinline__ void pswap(Pt* a, Pt* b) {
-  Pt t = *a;
-  *a = *b;
-  *b = t;
+__device__ __forceinline__ void pswap(const IouScratch& q, int a, int b) {
+  const Pt t = q.get(a);
+  q.set(a, q.get(b));
+  q.set(b, t);
 }
 // libstdc++ std::sort (introsort, threshold 16, then final insertion sort) -- the CPU reference sorts the
 // hull candidates with it (utils.hpp:213); because the comparator is not a strict weak order the algorithm
 // itself must be reproduced for bit-exact areas.  n <= 23 here, so the depth limit is never reached.
-__device__ void gcc_std_sort(Pt* first, Pt* last) {
+__device__ void gcc_std_sort(const IouScratch& q, int first, int last) {
   if (last - first > 16) {
-    Pt* stack_lo[8];
-    Pt* stack_hi[8];
     int sp = 0;
-    Pt* lo = first;
-    Pt* hi = last;
+    int lo = first;
+    int hi = last;
     for (;;) {
       while (hi - lo > 16) {
-        Pt* mid = lo + (hi - lo) / 2;
-        Pt *a = lo + 1, *b = mid, *c = hi - 1;
-        if (hull_less(*a, *b)) {
-          if (hull_less(*b, *c)) pswap(lo, b);
-          else if (hull_less(*a, *c)) pswap(lo, c);
-          else pswap(lo, a);
-        } else if (hull_less(*a, *c)) pswap(lo, a);
-        else if (hull_less(*b, *c)) pswap(lo, c);
-        else pswap(lo, b);
-        Pt* f = lo + 1;
-        Pt* l = hi;
+        const int mid = lo + (hi - lo) / 2;
+        const int a = lo + 1, b = mid, c = hi - 1;
+        if (hull_less(q.get(a), q.get(b))) {
+          if (hull_less(q.get(b), q.get(c))) pswap(q, lo, b);
+          else if (hull_less(q.get(a), q.get(c))) pswap(q, lo, c);
+          else pswap(q, lo, a);
+        } else if (hull_less(q.get(a), q.get(c))) pswap(q, lo, a);
+        else if (hull_less(q.get(b), q.get(c))) pswap(q, lo, c);
+        else pswap(q, lo, b);
+        int f = lo + 1;
+        int l = hi;
+        const Pt pivot = q.get(lo);  // (the partition never moves *lo)
         for (;;) {
-          while (hull_less(*f, *lo)) ++f;
+          while (hull_less(q.get(f), pivot)) ++f;
           --l;
-          while (hull_less(*lo, *l)) --l;
+          while (hull_less(pivot, q.get(l))) --l;
           if (!(f < l)) break;
-          pswap(f, l);
+          pswap(q, f, l);
           ++f;
         }
-        stack_lo[sp] = lo;
-        stack_hi[sp] = f;
+        q.stack[sp * 64] = (uint32_t)lo | ((uint32_t)f << 8);
         sp++;
         lo = f;
       }
       if (sp == 0) break;
       sp--;
-      lo = stack_lo[sp];
-      hi = stack_hi[sp];
+      const uint32_t e = q.stack[sp * 64];
+      lo = (int)(e & 255u);
+      hi = (int)(e >> 8);
     }
-    ins_sort(first, first + 16);
-    for (Pt* i = first + 16; i != last; ++i) ins_unguarded(i);
+    ins_sort(q, first, first + 16);
+    for (int i = first + 16; i != last; ++i) ins_unguarded(q, i);
   } else {
-    ins_sort(first, last);
+    ins_sort(q, first, last);
   }
 }
 
 // single_box_iou_rotated<float>, box_iou_rotated_utils.hpp:344-378 with
 // get_intersection_points :77-155, convex_hull_graham (CPU branch) :157-272, polygon_area :285-297.
-__device__ float single_box_iou_rotated(const float* __restrict__ b1, const float* __restrict__ b2,
-                                        int mode_flag) {
-  double csx = (b1[0] + b2[0]) / 2.0;
-  double csy = (b1[1] + b2[1]) / 2.0;
-  float x1 = b1[0] - csx, y1 = b1[1] - csy, w1 = b1[2], h1 = b1[3], a1 = b1[4];
-  float x2 = b2[0] - csx, y2 = b2[1] - csy, w2 = b2[2], h2 = b2[3], a2 = b2[4];
+// `q`: this lane's LDS scratch (iou_scratch); every lane of a wave that calls this needs its own column.
+struct Box5 {  // (cx, cy, w, h, angle) by value: no pointer to a local array, so nothing is forced into private memory
+  float x, y, w, h, a;
+};
+__device__ __forceinline__ Box5 load_box(const float* __restrict__ b) { return Box5{b[0], b[1], b[2], b[3], b[4]}; }
+__device__ float single_box_iou_rotated(const Box5 b1, const Box5 b2, int mode_flag, const IouScratch& q) {
+  double csx = (b1.x + b2.x) / 2.0;
+  double csy = (b1.y + b2.y) / 2.0;
+  float x1 = b1.x - csx, y1 = b1.y - csy, w1 = b1.w, h1 = b1.h, a1 = b1.a;
+  float x2 = b2.x - csx, y2 = b2.y - csy, w2 = b2.w, h2 = b2.h, a2 = b2.a;
   const float area1 = w1 * h1;
   const float area2 = w2 * h2;
   if ((double)area1 < 1e-14 || (double)area2 < 1e-14) return 0.f;
@@ -143,7 +167,6 @@ __device__ float single_box_iou_rotated(const float* __restrict__ b1, const floa
     v1[i] = psub(p1[(i + 1) & 3], p1[i]);
     v2[i] = psub(p2[(i + 1) & 3], p2[i]);
   }
-  Pt pts[24], q[24];
   int num = 0;
 #pragma unroll
   for (int i = 0; i < 4; i++) {
@@ -155,8 +178,7 @@ __device__ float single_box_iou_rotated(const float* __restrict__ b1, const floa
       float t1 = cross2(v2[j], v12) / det;
       float t2 = cross2(v1[i], v12) / det;
       if (t1 >= 0.0f && t1 <= 1.0f && t2 >= 0.0f && t2 <= 1.0f) {
-        pts[num].x = p1[i].x + v1[i].x * t1;
-        pts[num].y = p1[i].y + v1[i].y * t1;
+        q.set(num, Pt{p1[i].x + v1[i].x * t1, p1[i].y + v1[i].y * t1});
         num++;
       }
     }
@@ -170,7 +192,7 @@ __device__ float single_box_iou_rotated(const float* __restrict__ b1, const floa
       float APdotAB = dot2(AP, AB);
       float APdotAD = -dot2(AP, DA);
       if ((APdotAB >= 0) && (APdotAD >= 0) && (APdotAB <= ABdotAB) && (APdotAD <= ADdotAD))
-        pts[num++] = p1[i];
+        q.set(num++, p1[i]);
     }
   }
   {
@@ -182,38 +204,50 @@ __device__ float single_box_iou_rotated(const float* __restrict__ b1, const floa
       float APdotAB = dot2(AP, AB);
       float APdotAD = -dot2(AP, DA);
       if ((APdotAB >= 0) && (APdotAD >= 0) && (APdotAB <= ABdotAB) && (APdotAD <= ADdotAD))
-        pts[num++] = p2[i];
+        q.set(num++, p2[i]);
     }
   }
   float intersection = 0.f;
   if (num > 2) {
     // convex hull (Graham scan), shift_to_zero = true
     int t = 0;
-    for (int i = 1; i < num; i++)
-      if (pts[i].y < pts[t].y || (pts[i].y == pts[t].y && pts[i].x < pts[t].x)) t = i;
-    Pt start = pts[t];
-    for (int i = 0; i < num; i++) q[i] = psub(pts[i], start);
-    Pt tmp = q[0];
-    q[0] = q[t];
-    q[t] = tmp;
-    gcc_std_sort(q + 1, q + num);
+    Pt best = q.get(0);
+    for (int i = 1; i < num; i++) {
+      const Pt c = q.get(i);
+      if (c.y < best.y || (c.y == best.y && c.x < best.x)) {
+        t = i;
+        best = c;
+      }
+    }
+    const Pt start = best;
+    for (int i = 0; i < num; i++) q.set(i, psub(q.get(i), start));
+    pswap(q, 0, t);
+    gcc_std_sort(q, 1, num);
     int k;
-    for (k = 1; k < num; k++)
-      if ((double)dot2(q[k], q[k]) > 1e-8) break;
+    for (k = 1; k < num; k++) {
+      const Pt c = q.get(k);
+      if ((double)dot2(c, c) > 1e-8) break;
+    }
     int m;
     if (k == num) {
       m = 1;
     } else {
-      q[1] = q[k];
+      q.set(1, q.get(k));
       m = 2;
       for (int i = k + 1; i < num; i++) {
-        while (m > 1 && cross2(psub(q[i], q[m - 2]), psub(q[m - 1], q[m - 2])) >= 0) m--;
-        q[m++] = q[i];
+        const Pt qi = q.get(i);
+        while (m > 1) {
+          const Pt a = q.get(m - 2);
+          if (!(cross2(psub(qi, a), psub(q.get(m - 1), a)) >= 0)) break;
+          m--;
+        }
+        q.set(m++, qi);
       }
     }
     if (m > 2) {
       float area = 0.f;
-      for (int i = 1; i < m - 1; i++) area += fabsf(cross2(psub(q[i], q[0]), psub(q[i + 1], q[0])));
+      const Pt q0 = q.get(0);
+      for (int i = 1; i < m - 1; i++) area += fabsf(cross2(psub(q.get(i), q0), psub(q.get(i + 1), q0)));
       intersection = area / 2.0f;
     }
   }
@@ -259,6 +293,7 @@ __global__ __launch_bounds__(256) void box_iou_rotated_kernel(const float* __res
                                                               int mode_flag, int aligned) {
   constexpr int CHUNK = 64 * ROUNDS;
   __shared__ unsigned short cand[4][CHUNK];
+  __shared__ uint32_t iou_lds[4][IOU_LDS_WORDS_PER_WAVE];  // per-lane polygon scratch (see IouScratch)
   const long total = aligned ? (long)n1 : (long)n1 * n2;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const long nchunks = (total + CHUNK - 1) / CHUNK;
@@ -291,7 +326,8 @@ __global__ __launch_bounds__(256) void box_iou_rotated_kernel(const float* __res
       const long idx = base + cand[wv][e];
       const long i = aligned ? idx : idx / n2;
       const long j = aligned ? idx : idx - i * n2;
-      ious[idx] = single_box_iou_rotated(boxes1 + 5 * i, boxes2 + 5 * j, mode_flag);
+      ious[idx] = single_box_iou_rotated(load_box(boxes1 + 5 * i), load_box(boxes2 + 5 * j), mode_flag,
+                                         iou_scratch(iou_lds[wv], lane));
     }
     __builtin_amdgcn_wave_barrier();  // the list is rewritten by the next chunk
   }
@@ -489,6 +525,11 @@ __global__ __launch_bounds__(256) void nms_rotated_mask_kernel(const float* __re
   __shared__ float cbox[64 * 8], rbox[64 * 8];
   __shared__ unsigned long long rowword[64];
   __shared__ unsigned short cand[4][64 * 16];
+  __shared__ int cand_n[4];
+  // per-lane polygon scratch (see IouScratch) for TWO clipping waves: the survivors of all four waves' pre-tests are clipped
+  // as ONE list, 128 pairs per round (3 % of a tile's 4096 pairs survive on the bench boxes: ~120 -- one full round instead
+  // of four rounds with 30 of 64 lanes busy), and 35 KB of LDS per workgroup keep four workgroups on a CU
+  __shared__ uint32_t iou_lds[2][IOU_LDS_WORDS_PER_WAVE];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   if (wv < 2) {
     float* dst = wv == 0 ? cbox : rbox;
@@ -523,14 +564,19 @@ __global__ __launch_bounds__(256) void nms_rotated_mask_kernel(const float* __re
     if (ok) cand[wv][cnt + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)(lane * 64 + c);
     cnt += __popcll(bal);
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  // phase 2: the surviving pairs, 64 at a time with every lane busy
-  for (int e = lane; e < cnt; e += 64) {
-    const int rc = cand[wv][e], r = rc >> 6, c = rc & 63;
-    // row box is the higher-scoring one: reference calls iou(dets[i], dets[j]) with i kept, j candidate
-    const float iou = single_box_iou_rotated(&rbox[r * 8], &cbox[c * 8], 0);
-    if (iou >= thr) atomicOr(&rowword[r], 1ull << c);  // cpu/nms_rotated.cpp:51 uses >=
+  if (lane == 0) cand_n[wv] = cnt;
+  __syncthreads();
+  // phase 2: the surviving pairs of the whole tile, 128 at a time on waves 0 and 1 with every lane busy
+  if (wv < 2) {
+    const int n0 = cand_n[0], n1 = n0 + cand_n[1], n2 = n1 + cand_n[2], total = n2 + cand_n[3];
+    for (int e = wv * 64 + lane; e < total; e += 128) {
+      const int w = (e >= n0) + (e >= n1) + (e >= n2);
+      const int rc = cand[w][e - (w == 0 ? 0 : w == 1 ? n0 : w == 2 ? n1 : n2)], r = rc >> 6, c = rc & 63;
+      // row box is the higher-scoring one: reference calls iou(dets[i], dets[j]) with i kept, j candidate
+      const float iou =
+          single_box_iou_rotated(load_box(&rbox[r * 8]), load_box(&cbox[c * 8]), 0, iou_scratch(iou_lds[wv], lane));
+      if (iou >= thr) atomicOr(&rowword[r], 1ull << c);  // cpu/nms_rotated.cpp:51 uses >=
+    }
   }
   __syncthreads();
   if (wv == 0 && ri < n) mask[(size_t)ri * nblk + cb] = rowword[lane];
@@ -1358,14 +1404,17 @@ __global__ __launch_bounds__(256) void roi_bwd_tile_kernel(const float* __restri
 // The rotated IoU is ONE out-of-line function: pass 2 finds a gt's low-quality matches by recomputing the IoU and testing
 // it for equality with the maximum pass 1 published, so both kernels must execute the very same instruction sequence (two
 // inlined copies may be scheduled / simplified differently by the compiler).
-__device__ __noinline__ float assign_iou_rotated(const float* __restrict__ g, const float* __restrict__ b) {
-  float gg[5] = {g[0], g[1], fmaxf(g[2], 1e-3f), fmaxf(g[3], 1e-3f), g[4]};
-  float bb[5] = {b[0], b[1], fmaxf(b[2], 1e-3f), fmaxf(b[3], 1e-3f), b[4]};
-  return single_box_iou_rotated(gg, bb, 0);
+__device__ __noinline__ float assign_iou_rotated(const float* __restrict__ g, const float* __restrict__ b, Pt* lds_pts,
+                                                 uint32_t* lds_stack) {
+  const Box5 gg{g[0], g[1], fmaxf(g[2], 1e-3f), fmaxf(g[3], 1e-3f), g[4]};
+  const Box5 bb{b[0], b[1], fmaxf(b[2], 1e-3f), fmaxf(b[3], 1e-3f), b[4]};
+  return single_box_iou_rotated(gg, bb, 0, IouScratch{lds_pts, lds_stack});
 }
 
-__device__ __forceinline__ float assign_iou(const float* __restrict__ g, const float* __restrict__ b, int rotated) {
-  if (rotated) return assign_iou_rotated(g, b);
+// ROT: the rotated instantiation carries the polygon scratch in LDS (57 KB per workgroup); the horizontal one none
+template <int ROT>
+__device__ __forceinline__ float assign_iou(const float* __restrict__ g, const float* __restrict__ b, const IouScratch& q) {
+  if (ROT) return assign_iou_rotated(g, b, q.pts, q.stack);
   const float a1 = (g[2] - g[0]) * (g[3] - g[1]);
   const float a2 = (b[2] - b[0]) * (b[3] - b[1]);
   const float w = fmaxf(fminf(g[2], b[2]) - fmaxf(g[0], b[0]), 0.f);
@@ -1377,12 +1426,15 @@ __device__ __forceinline__ float assign_iou(const float* __restrict__ g, const f
 
 // pass 1: max_ov[j] = max_i iou(gt_i, box_j), argmax[j] = first i reaching it; gt_max_bits[i] = max_j (as ordered
 // bits: IoUs are >= 0, so the unsigned order of the bit patterns is the float order).  gt_max_bits zeroed by the caller.
+template <int ROT>
 __global__ __launch_bounds__(256) void max_iou_pass1_kernel(const float* __restrict__ boxes, int box_stride, int n,
                                                            const float* __restrict__ gts, int gt_stride, int k,
-                                                           int rotated, float* __restrict__ max_ov,
+                                                           float* __restrict__ max_ov,
                                                            int32_t* __restrict__ argmax,
                                                            unsigned* __restrict__ gt_max_bits,
                                                            const uint8_t* __restrict__ flags) {
+  __shared__ uint32_t iou_lds[ROT ? 4 : 1][ROT ? IOU_LDS_WORDS_PER_WAVE : 1];
+  const IouScratch q = ROT ? iou_scratch(iou_lds[threadIdx.x >> 6], threadIdx.x & 63) : IouScratch{nullptr, nullptr};
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   if (flags && !flags[j]) {  // not a candidate (outside the image): no IoU, no vote for a gt's maximum
@@ -1394,7 +1446,7 @@ __global__ __launch_bounds__(256) void max_iou_pass1_kernel(const float* __restr
   float best = -1.f;
   int bi = 0;
   for (int i = 0; i < k; i++) {
-    const float ov = assign_iou(gts + (long)i * gt_stride, b, rotated);
+    const float ov = assign_iou<ROT>(gts + (long)i * gt_stride, b, q);
     if (ov > best) {
       best = ov;
       bi = i;
@@ -1411,9 +1463,10 @@ __global__ __launch_bounds__(256) void max_iou_pass1_kernel(const float* __restr
 
 // pass 2: the assignment rule (negatives, positives, low-quality matches in gt order -- a later gt overrides an
 // earlier one, as the reference's python loop does), labels of the positives
+template <int ROT>
 __global__ __launch_bounds__(256) void max_iou_pass2_kernel(const float* __restrict__ boxes, int box_stride, int n,
                                                            const float* __restrict__ gts, int gt_stride, int k,
-                                                           int rotated, const float* __restrict__ max_ov,
+                                                           const float* __restrict__ max_ov,
                                                            const int32_t* __restrict__ argmax,
                                                            const unsigned* __restrict__ gt_max_bits, float pos_thr,
                                                            float neg_thr, float min_pos, int match_low_quality,
@@ -1421,6 +1474,8 @@ __global__ __launch_bounds__(256) void max_iou_pass2_kernel(const float* __restr
                                                            int64_t* __restrict__ gt_inds,
                                                            int64_t* __restrict__ labels,
                                                            const uint8_t* __restrict__ flags) {
+  __shared__ uint32_t iou_lds[ROT ? 4 : 1][ROT ? IOU_LDS_WORDS_PER_WAVE : 1];
+  const IouScratch q = ROT ? iou_scratch(iou_lds[threadIdx.x >> 6], threadIdx.x & 63) : IouScratch{nullptr, nullptr};
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   if (flags && !flags[j]) {
@@ -1439,7 +1494,7 @@ __global__ __launch_bounds__(256) void max_iou_pass2_kernel(const float* __restr
       const float* b = boxes + (long)j * box_stride;
       for (int i = 0; i < k; i++) {
         const float gmax = __uint_as_float(gt_max_bits[i]);
-        if (gmax >= min_pos && assign_iou(gts + (long)i * gt_stride, b, rotated) == gmax) a = i + 1;
+        if (gmax >= min_pos && assign_iou<ROT>(gts + (long)i * gt_stride, b, q) == gmax) a = i + 1;
       }
     }
   }
@@ -1472,11 +1527,19 @@ int sm3_max_iou_assign_masked(const float* boxes, int box_stride, int n, const u
   unsigned* gmax = (unsigned*)((char*)workspace + align_up((size_t)n * sizeof(int32_t), 256));
   sm3_zero_async(gmax, sizeof(unsigned) * (size_t)(k > 0 ? k : 1), st);
   const int blocks = (n + 255) / 256;
-  max_iou_pass1_kernel<<<blocks, 256, 0, st>>>(boxes, box_stride, n, gts, gt_stride, k, rotated, max_overlaps, argmax,
-                                               gmax, box_flags);
-  max_iou_pass2_kernel<<<blocks, 256, 0, st>>>(boxes, box_stride, n, gts, gt_stride, k, rotated, max_overlaps, argmax,
-                                               gmax, pos_iou_thr, neg_iou_thr, min_pos_iou, match_low_quality,
-                                               gt_labels, gt_inds, labels, box_flags);
+  if (rotated) {
+    max_iou_pass1_kernel<1><<<blocks, 256, 0, st>>>(boxes, box_stride, n, gts, gt_stride, k, max_overlaps, argmax, gmax,
+                                                    box_flags);
+    max_iou_pass2_kernel<1><<<blocks, 256, 0, st>>>(boxes, box_stride, n, gts, gt_stride, k, max_overlaps, argmax, gmax,
+                                                    pos_iou_thr, neg_iou_thr, min_pos_iou, match_low_quality, gt_labels,
+                                                    gt_inds, labels, box_flags);
+  } else {
+    max_iou_pass1_kernel<0><<<blocks, 256, 0, st>>>(boxes, box_stride, n, gts, gt_stride, k, max_overlaps, argmax, gmax,
+                                                    box_flags);
+    max_iou_pass2_kernel<0><<<blocks, 256, 0, st>>>(boxes, box_stride, n, gts, gt_stride, k, max_overlaps, argmax, gmax,
+                                                    pos_iou_thr, neg_iou_thr, min_pos_iou, match_low_quality, gt_labels,
+                                                    gt_inds, labels, box_flags);
+  }
   return launch_status();
 }
 

@@ -67,3 +67,20 @@ def test_product_path_does_not_import_the_oracle():
         src = open(py).read()
         assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), py
         assert 'ops_oracle' not in src and 'moe_oracle' not in src, py
+
+
+def test_rotated_iou_and_fp16_gemm_kernels_use_no_private_memory():
+    """compile-time facts the round-5 review asked for: the rotated-IoU kernels (box_iou_rotated, nms_rotated's mask kernel,
+    the rotated MaxIoU assignment) keep their polygon scratch in LDS -- private_segment_fixed_size / scratch = 0 -- and no
+    fp16-operand GEMM instantiation spills (hipcc -Rpass-analysis=kernel-resource-usage on the shipped sources)."""
+    from scripts.kernel_resources import kernel_resources
+    rows = kernel_resources('ops_rotated.hip')
+    assert rows, 'no kernels reported'
+    for name in ('box_iou_rotated_kernel', 'nms_rotated_mask_kernel', 'max_iou_pass1_kernel', 'max_iou_pass2_kernel'):
+        sel = [r for r in rows if name in r['name']]
+        assert sel, name
+        for r in sel:
+            assert int(r['ScratchSize']) == 0 and int(r['VGPRsSpill']) == 0, r
+    for src in ('gemm_f16.hip', 'gemm_h16.hip'):
+        for r in kernel_resources(src):
+            assert int(r['VGPRsSpill']) == 0 and int(r['ScratchSize']) == 0, (src, r)

@@ -462,3 +462,49 @@ def test_roi_align_rotated_vector_forward_is_bit_identical_to_the_scalar_kernel(
     y_nchw = ops.roi_align_rotated(x, rois, 7, 0.25, 2, True, True)
     y_nhwc = ops.roi_align_rotated(x.contiguous(memory_format=torch.channels_last), rois, 7, 0.25, 2, True, True)
     assert torch.equal(y_nchw, y_nhwc)
+
+
+_TWO_PROC_WORKER = r'''
+import sys, time
+import numpy as np, torch
+sys.path.insert(0, %(root)r)
+from sm3det_amd import mmcv_ops, assign
+from oracle import ops_oracle as O
+from tests import synth
+seed = int(sys.argv[1])
+b1, b2 = synth.rotated_boxes(600, seed, cluster=True), synth.rotated_boxes(96, seed + 1, cluster=True)
+want = O.box_iou_rotated(b1, b2)
+s = synth.unique_scores(600, seed + 2)
+keep_want = O.nms_rotated(b1, s, 0.1)
+d1, d2, ds = torch.from_numpy(b1).cuda(), torch.from_numpy(b2).cuda(), torch.from_numpy(s).cuda()
+t0, n = time.time(), 0
+while time.time() - t0 < 4.0:  # both processes hammer the rotated-IoU kernels for the same few seconds
+    got = mmcv_ops.box_iou_rotated(d1, d2)
+    _, keep = mmcv_ops.nms_rotated(d1, ds, 0.1)
+    res = assign.MaxIoUAssigner(0.5, 0.4, 0.3, iou_calculator=dict(type='RBboxOverlaps2D')).assign(d1, d2[:8])
+    torch.cuda.synchronize()
+    assert np.abs(got.cpu().numpy() - want).max() <= 1e-6
+    assert np.array_equal(keep.cpu().numpy(), keep_want)
+    assert res.gt_inds.numel() == 600
+    n += 1
+print('ok', n)
+'''
+
+
+def test_two_processes_share_the_gpu_while_running_the_rotated_iou_kernels(tmp_path):
+    """Round 5 saw GPU faults when two processes ran the rotated-IoU kernels (box_iou_rotated, nms_rotated's mask kernel,
+    the rotated MaxIoU assignment) on ONE GPU at the same time; the one thing those kernels shared was 528 bytes of private
+    (scratch) memory per lane.  Their polygon scratch now lives in LDS (no private segment at all, checked by
+    tests/test_abi.py on the code object); this test runs two such processes concurrently and checks both against the oracle."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / 'worker.py'
+    script.write_text(_TWO_PROC_WORKER % dict(root=root))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    procs = [subprocess.Popen([sys.executable, str(script), str(10 * i)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                              env=env, cwd=root) for i in range(2)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, (p.returncode, o.decode()[-500:], e.decode()[-2000:])
+        assert o.decode().strip().startswith('ok')
