@@ -982,12 +982,21 @@ def main():
     # N>1: the backward is replayed in two segments -- stages 3+2 (93 % of the gradient bytes) first, whose buckets are
     # all-reduced over xGMI while the backward of stages 1+0 still runs (SM3_BENCH_SPLIT=0/1 overrides; N=1 default off)
     split = os.environ.get('SM3_BENCH_SPLIT', '1' if multi else '0') == '1'
-    LATE = ('stages.2.', 'stages.3.', 'downsample_layers.2.', 'downsample_layers.3.', 'norm2.', 'norm3.')
+    # ... in SM3_BENCH_SEGMENTS pieces (default 4: stage 3 | stage 2 | stage 1 | stage 0 + stem): the buckets of a segment are
+    # all-reduced while the NEXT segment's backward replays.  Gradient bytes by stage (ConvNeXt-T e8t2): 57 % / 37 % / 4 % / 2 %,
+    # backward time 18 % / 52 % / 19 % / 11 % -- with two segments (3+2 | 1+0) 93 % of the bytes had 30 % of the backward to
+    # hide behind; with four, stage 3's 0.32 GB travel during stage 2's backward (half of the pass).
+    n_seg = max(2, min(4, int(os.environ.get('SM3_BENCH_SEGMENTS', '4')))) if split else 1
+    seg_stages = {2: [(3, 2), (1, 0)], 3: [(3,), (2,), (1, 0)], 4: [(3,), (2,), (1,), (0,)]}.get(n_seg, [(3, 2, 1, 0)])
     named = [(n, p) for n, p in net.named_parameters() if p.requires_grad]
-    late_params = [p for n, p in reversed(named) if n.startswith(LATE)]
-    early_params = [p for n, p in reversed(named) if not n.startswith(LATE)]
-    reducer = BucketedGradReducer(params, bucket_mb=64.0, groups=[late_params, early_params] if split else None,
-                                  force_comm=force_dist)
+
+    def stage_of(name):
+        for st in (3, 2, 1):
+            if name.startswith((f'stages.{st}.', f'downsample_layers.{st}.', f'norm{st}.')):
+                return st
+        return 0  # stage 0, its norm, the stem
+    seg_params = [[p for n, p in reversed(named) if stage_of(n) in sts] for sts in seg_stages]
+    reducer = BucketedGradReducer(params, bucket_mb=64.0, groups=seg_params if split else None, force_comm=force_dist)
     reducer.broadcast_parameters(0, module=net)
     # optimizer of local_configs/main_SM3Det.py: AdamW(lr 1e-4, betas (0.9, 0.999), wd 0.05), one param group per
     # parameter (paramwise_cfg / dynamic-lr hook), grad_clip max_norm 35 -- here one fused launch with a per-tensor lr vector
@@ -1048,32 +1057,50 @@ def main():
             reducer.pack_all()
             return l
 
-        def seg_late():
-            """forward + backward of everything above the stage-1 output (tokens `hb`); same loss, split by term"""
+        def seg_losses(outs):
+            """the step's loss split by segment: gate-loss terms and output projections of the stages a segment owns"""
+            terms = net._gate_loss_terms
+            nt = max(len(terms), 1)
+            ls = []
+            for sts in seg_stages:
+                l = sum((g for i, g in terms if i in sts), zero) / nt
+                for i, (o, r) in enumerate(zip(outs, proj)):
+                    if i in sts:
+                        l = l + (o * r).sum() * 1e-4
+                ls.append(l)
+            return ls
+
+        def seg_first():
+            """forward + backward of the top segment (everything above the tokens leaving stage seg_stages[1][0])"""
             reducer.zero_grad()
             outs, _ = forward()
-            terms, hb = net._gate_loss_terms, net._boundary_tokens
-            nt = max(len(terms), 1)
-            l_late = sum((g for i, g in terms if i >= 2), zero) / nt
-            l_early = sum((g for i, g in terms if i < 2), zero) / nt
-            for i, (o, r) in enumerate(zip(outs, proj)):
-                t = (o * r).sum() * 1e-4
-                if i >= 2:
-                    l_late = l_late + t
-                else:
-                    l_early = l_early + t
-            # autograd.grad, not backward(inputs=[..., hb]): the latter would EXECUTE hb's producer node (and free its
+            ls = seg_losses(outs)
+            toks = net._boundary_tokens  # {stage: tokens leaving it}
+            below = toks[seg_stages[1][0]]
+            # autograd.grad, not backward(inputs=[..., tok]): the latter would EXECUTE the token's producer node (and free its
             # saved tensors) instead of just capturing the gradient that arrives at it
-            grads = torch.autograd.grad(opt.scale(l_late), [hb] + late_params, allow_unused=True)
-            for p, g in zip(late_params, grads[1:]):
+            grads = torch.autograd.grad(opt.scale(ls[0]), [below] + seg_params[0], allow_unused=True)
+            for p, g in zip(seg_params[0], grads[1:]):
                 p.grad = g
             reducer.pack_group(0)
-            return l_late, l_early, hb, grads[0]
+            return ls, toks, grads[0]
 
-        def seg_early(l_early, hb, ghb):
-            torch.autograd.backward([opt.scale(l_early), hb], grad_tensors=[torch.ones_like(l_early), ghb],
-                                    inputs=early_params)
-            reducer.pack_group(1)
+        def seg_next(k, ls, toks, g_in):
+            """backward of segment k: its own loss terms plus the gradient arriving at the tokens that leave its top stage"""
+            top = toks[seg_stages[k][0]]
+            last = k == len(seg_stages) - 1
+            if last:
+                torch.autograd.backward([opt.scale(ls[k]), top], grad_tensors=[torch.ones_like(ls[k]), g_in],
+                                        inputs=seg_params[k])
+                reducer.pack_group(k)
+                return None
+            below = toks[seg_stages[k + 1][0]]
+            grads = torch.autograd.grad([opt.scale(ls[k]), top], [below] + seg_params[k],
+                                        grad_outputs=[torch.ones_like(ls[k]), g_in], allow_unused=True)
+            for p, g in zip(seg_params[k], grads[1:]):
+                p.grad = g
+            reducer.pack_group(k)
+            return grads[0]
 
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -1087,13 +1114,15 @@ def main():
         try:
             g_fb, g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             if split:
-                net.stage_boundary = 1
-                g_fb2 = torch.cuda.CUDAGraph()
+                net.stage_boundary = [sts[0] for sts in seg_stages[1:]]  # the tokens leaving the top stage of each lower segment
+                g_segs = [g_fb] + [torch.cuda.CUDAGraph() for _ in seg_stages[1:]]
                 with torch.cuda.graph(g_fb, **cap_kw):
-                    l_late, l_early, hb, ghb = seg_late()
-                with torch.cuda.graph(g_fb2, pool=g_fb.pool(), **cap_kw):
-                    seg_early(l_early, hb, ghb)
-                    graph_loss = (l_late + l_early).detach()
+                    ls, toks, g_in = seg_first()
+                for k in range(1, len(seg_stages)):
+                    with torch.cuda.graph(g_segs[k], pool=g_fb.pool(), **cap_kw):
+                        g_in = seg_next(k, ls, toks, g_in)
+                        if k == len(seg_stages) - 1:
+                            graph_loss = sum(ls[1:], ls[0]).detach()
                 net.stage_boundary = None
             else:
                 with torch.cuda.graph(g_fb, **cap_kw):
@@ -1101,7 +1130,8 @@ def main():
             keep_alive = [p.grad for p in params]  # the tensors the graphs write the gradients to  # noqa: F841
             g_fb.replay()
             if split:
-                g_fb2.replay()
+                for gk in g_segs[1:]:
+                    gk.replay()
             reducer.finalize(repack=False)  # N>1: p.grad -> slices of the reduced buckets
             opt.refresh_grad_pointers()
             with torch.cuda.graph(g_opt, pool=g_fb.pool(), **cap_kw):
@@ -1109,10 +1139,9 @@ def main():
 
             if split:
                 def run():
-                    g_fb.replay()                      # forward + backward of stages 3, 2 (+ pack of their buckets)
-                    reducer.allreduce_group_async(0)   # RCCL stream: overlaps with ...
-                    g_fb2.replay()                     # ... the backward of stages 1, 0 (+ pack)
-                    reducer.allreduce_group_async(1)
+                    for k, gk in enumerate(g_segs):       # forward + backward of the top segment, then segment by segment:
+                        gk.replay()                        # ... the backward of segment k (+ the pack of its buckets)
+                        reducer.allreduce_group_async(k)   # RCCL stream: overlaps with the replay of segment k + 1
                     reducer.finalize(repack=False)
                     g_opt.replay()
                     return graph_loss
@@ -1275,6 +1304,7 @@ def main():
                        'global_batch': world * BATCH, 'resolution': RES, 'parallelism': f'dp{world}',
                        'grad_buckets': reducer.num_buckets, 'hip_graph': bool(use_graph),
                        'wgrad_side_stream': bool(overlap_was), 'split_backward': bool(split and use_graph),
+                       'backward_segments': (n_seg if (split and use_graph) else 1),
                        'dist_backend': (backend if multi else None), 'collective_avg': bool(reducer._avg),
                        # share of the gradient bytes the backward kernels wrote straight into the bucket slices (no pack copy)
                        'grad_bytes_in_place_frac': (round(reducer.pack_stats['in_place_bytes'] /

@@ -420,8 +420,12 @@ class ConvNeXt_moe(nn.Module):
                 if gl is not None:
                     gate_losses.append(gl)
                     self._gate_loss_terms.append((i, gl))
-            if boundary is not None and i == boundary:
-                self._boundary_tokens = tok
+            if boundary is not None and (i == boundary or (isinstance(boundary, (list, tuple)) and i in boundary)):
+                if isinstance(boundary, (list, tuple)):  # several boundaries: {stage: tokens leaving it}
+                    self._boundary_tokens = dict(self._boundary_tokens or {})
+                    self._boundary_tokens[i] = tok
+                else:
+                    self._boundary_tokens = tok
             if i in self.out_indices:
                 norm_layer = getattr(self, f'norm{i}')
                 C = self.channels[i]

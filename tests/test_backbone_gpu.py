@@ -432,3 +432,32 @@ def test_full_size_1024_bs2_size_independent_properties():
     (sum((o * o).mean() for o in outs) + gl).backward()
     for n, p in net.named_parameters():
         assert p.grad is not None and bool(torch.isfinite(p.grad).all()), n
+
+
+def test_second_backward_without_zero_grad_accumulates_with_bucket_slices_attached():
+    """The FFN / expert weight-gradient GEMMs write straight into the parameter's data-parallel bucket slice
+    (`BucketedGradReducer` hangs it on the parameter as `_sm3_grad_view`, `backbone_ops._bucket_out`), and after
+    `finalize()` p.grad IS that slice.  A second backward without `reducer.zero_grad()` (gradient accumulation) must then
+    ACCUMULATE: the GEMM may not overwrite the slice that still holds the first gradient (the advisor's finding: 2 x new
+    instead of old + new).  Slices are attached by hand here (no process group needed), every parameter."""
+    fx = load_fixture('moe_e4k2')
+    net = _build(fx['cfg'], fx['state_dict']).train()
+    noise = [n.cuda() for n in fx['noise']]
+    drop = [d.cuda() for d in fx['drop_scale']]
+
+    def run():
+        outs, gl = net(fx['x'].cuda(), ['single'], noise=noise, drop_scale=drop)
+        loss_of(outs, gl).backward()
+    run()
+    once = {n: p.grad.detach().clone() for n, p in net.named_parameters()}
+    for p in net.parameters():
+        p.grad = None
+        p._sm3_grad_view = torch.zeros_like(p)
+    run()  # first pass: the big weight gradients land in their slices (adopted, no copy)
+    in_place = [n for n, p in net.named_parameters() if p.grad.data_ptr() == p._sm3_grad_view.data_ptr()]
+    assert any(n.endswith(('w1', 'w2')) for n in in_place), in_place
+    for n, p in net.named_parameters():
+        assert rel_err(p.grad, once[n]) < 1e-6, n
+    run()  # second pass WITHOUT dropping the gradients: old + new
+    for n, p in net.named_parameters():
+        assert rel_err(p.grad, 2 * once[n]) < 1e-5, (n, rel_err(p.grad, 2 * once[n]))

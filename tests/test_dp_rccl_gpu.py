@@ -34,8 +34,8 @@ def test_split_backward_graph_replay_with_rccl_collectives_world_size_1():
     cfg = dist_run['config']
     assert 'capture failed' not in err, err[-1500:]
     assert cfg['dist_backend'] == 'nccl' and cfg['collective_avg'] is True
-    assert cfg['hip_graph'] is True and cfg['split_backward'] is True
-    assert cfg['grad_buckets'] >= 2 and cfg['replica_checksum_spread'] == 0.0
+    assert cfg['hip_graph'] is True and cfg['split_backward'] is True and cfg['backward_segments'] == 4
+    assert cfg['grad_buckets'] >= 4 and cfg['replica_checksum_spread'] == 0.0
     # the FFN / expert weight gradients (95 % of the bytes) are written by the weight-gradient GEMMs straight into their
     # bucket slices: the pack pass copies only the small tensors
     assert cfg['grad_bytes_in_place_frac'] >= 0.9, cfg['grad_bytes_in_place_frac']
@@ -103,3 +103,36 @@ def test_full_model_data_parallel_workload_one_rank_collectives(backend):
     assert cfg['grad_bytes_in_place_frac'] >= 0.5
     assert out['value'] > 0 and all(v == v for v in out['loss_terms'].values())
     assert {'sar_loss_cls', 'rgb_loss_rpn_cls', 'ifr_loss_bbox'} <= set(out['loss_terms'])
+
+
+def test_two_segment_replay_still_available():
+    """SM3_BENCH_SEGMENTS=2 keeps round 5's flow (stages 3+2 | 1+0): same loss as the four-segment default"""
+    four, _ = _bench(dict(SM3_BENCH_FORCE_DIST='1', SM3_BENCH_SPLIT='1'))
+    two, _ = _bench(dict(SM3_BENCH_FORCE_DIST='1', SM3_BENCH_SPLIT='1', SM3_BENCH_SEGMENTS='2'))
+    assert two['config']['backward_segments'] == 2 and four['config']['backward_segments'] == 4
+    assert abs(two['loss'] - four['loss']) <= 1e-4 * max(1.0, abs(four['loss'])), (two['loss'], four['loss'])
+
+
+def test_bench_gpus2_on_rccl_when_two_gpus_are_present():
+    """The first run with MORE THAN ONE RCCL rank.  Every box this build has seen has one GPU, so this test skips itself
+    there; on the first multi-GPU box it runs `python bench.py --gpus 2` exactly as the driver's SCALE command does (self-
+    launched ranks on 127.0.0.1, one rank per GPU, `nccl` = RCCL over xGMI) for both workloads and checks what only a real
+    two-rank run can show: RCCL saw two ranks, the four-segment replay with asynchronous AVG all-reduces completes, and the
+    replicas hold identical parameters afterwards (checksum spread exactly 0)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip(f'{torch.cuda.device_count()} GPU visible: the two-rank RCCL run needs two')
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY='0', SM3_BENCH_RES='512')
+    for workload in ('backbone', 'full_model'):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+                            '--no-ops', '--no-cpu-baseline', '--workload', workload], env=env, capture_output=True, text=True,
+                           timeout=1200)
+        assert r.returncode == 0, (workload, r.stdout[-1000:], r.stderr[-3000:])
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+        assert len(lines) == 1, lines
+        out = json.loads(lines[0])
+        cfg = out['config']
+        assert out['n_gpus'] == 2 and cfg['dist_backend'] == 'nccl' and cfg.get('collective_avg', True) is True, cfg
+        assert cfg['replica_checksum_spread'] == 0.0, cfg
+        assert out['value'] > 0 and out['loss'] == out['loss']
