@@ -620,6 +620,34 @@ int sm3_dla_lr(const float* losses, int n, const int32_t* loss_subnet, int n_sub
                int backbone_policy, int warmup_iters, float warmup_ratio, float T, float b, float ema_beta, float* lr,
                sm3_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * SAR branch, loss side of mmdet's GFLHead (local_configs/main_SM3Det.py:29-48,145-149; consumed at
+ * mmrotate/models/detectors/trisource_H1stage_R2stage_detector.py:235-369).  mmdet 2.x is not vendored by the reference:
+ * semantics restated from atss_assigner.py:47-201, gfl_head.py:16-50,210-330, gfocal_loss.py:12-52,95-118,
+ * iou_loss.py:120-135 ("parity unpinned"; pinned on this package's two independent restatements).
+ * Anchors (A,4) are level-major, level l = [level_off[l], level_off[l+1]) (HOST int[num_levels+1]), level_stride HOST floats.
+ * sm3_atss_assign (one image): best[A] uint64, zeroed here; an anchor that is a positive of some gt gets
+ *   max over those gts of (IoU bits << 32 | ~gt index) -- highest IoU wins, lower gt index on ties; candidates = per level the
+ *   `topk` valid anchors nearest to the gt centre, ties to the lower anchor index; threshold = mean + unbiased std of the
+ *   candidates' IoUs; positive = IoU >= threshold and anchor centre inside the gt by more than 0.01.  valid: A bytes or NULL.
+ * sm3_atss_decode: best -> gt_inds (0 = negative, i + 1) and max_overlaps (-1e8 where unassigned; may be NULL).
+ * sm3_gfl_loss_fwd: cls (B,A,C) logits, bbox (B,A,4(reg_max+1)) logits, best (B,A) keys, gts / gt_labels = all images'
+ *   ground truth concatenated with gt_off[b] (DEVICE int32[B]) = first gt of image b, valid (B,A) bytes or NULL.  Writes
+ *   sums = 4 x 8 doubles [term][level]: 0 sum of GIoU loss x weight_target, 1 DFL x weight_target, 2 QFL x label weight,
+ *   3 weight_target (= avg_factor), and pos_count[B] -- the per-level sums mmdet's loss_single returns before normalisation.
+ * sm3_gfl_loss_bwd: coef = DEVICE 3 x 8 floats (d total / d sums[0..2][level]); writes d cls, d bbox (every element). */
+int sm3_atss_assign(const float* anchors, int A, const int* level_off, const float* level_stride, int num_levels,
+                    const float* gts, int k, const uint8_t* valid, int topk, void* best, sm3_stream_t stream);
+int sm3_atss_decode(const void* best, int A, int64_t* gt_inds, float* max_overlaps, sm3_stream_t stream);
+int sm3_gfl_loss_fwd(const float* cls, const float* bbox, const float* anchors, int B, int A, int C, int reg_max,
+                     const int* level_off, const float* level_stride, int num_levels, const void* best, const float* gts,
+                     const int64_t* gt_labels, const int* gt_off, const uint8_t* valid, float pos_weight, float beta,
+                     double* sums, int* pos_count, sm3_stream_t stream);
+int sm3_gfl_loss_bwd(const float* cls, const float* bbox, const float* anchors, int B, int A, int C, int reg_max,
+                     const int* level_off, const float* level_stride, int num_levels, const void* best, const float* gts,
+                     const int64_t* gt_labels, const int* gt_off, const uint8_t* valid, float pos_weight, float beta,
+                     const float* coef, float* dcls, float* dbbox, sm3_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

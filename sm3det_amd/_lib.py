@@ -53,6 +53,10 @@ def _declare(lib):
         'sm3_random_sample_fixed': (I, [P, P, I, I, I, F, P, P, P, P, P, P, S, P]),
         'sm3_roi_align_rotated_backward_tiled_workspace_bytes': (S, [I, I, I, I, I, I, P, P, I]),
         'sm3_roi_align_rotated_backward_tiled': (I, [P, P, P, P, P, P, I, F, I, I, I, I, I, I, I, I, I, P, S, P]),
+        'sm3_atss_assign': (I, [P, I, P, P, I, P, I, P, I, P, P]),
+        'sm3_atss_decode': (I, [P, I, P, P, P]),
+        'sm3_gfl_loss_fwd': (I, [P, P, P, I, I, I, I, P, P, I, P, P, P, P, P, F, F, P, P, P]),
+        'sm3_gfl_loss_bwd': (I, [P, P, P, I, I, I, I, P, P, I, P, P, P, P, P, F, F, P, P, P, P]),
     }
     from . import _lib_backbone, det_losses
     sig.update(_lib_backbone.signatures())

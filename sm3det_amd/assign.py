@@ -228,8 +228,24 @@ class ATSSAssigner:
         self.topk = int(topk)
 
     def assign(self, bboxes, num_level_bboxes, gt_bboxes, gt_bboxes_ignore=None, gt_labels=None, valid=None):
-        from .gfl_losses import atss_assign
+        """on the device since round 6 (sm3_atss_assign + sm3_atss_decode, csrc/gfl.hip); the masked torch form
+        `gfl_losses.atss_assign` is the restatement the kernel is tested against.  Equal centre distances at the top-k cut go to
+        the lower anchor index (torch.topk leaves that order unspecified)."""
+        from .gfl_head import atss_best_keys
         if gt_bboxes_ignore is not None:
             raise NotImplementedError('gt_bboxes_ignore')
-        gt_inds, max_ov, labels = atss_assign(bboxes, list(num_level_bboxes), gt_bboxes, gt_labels, self.topk, valid)
+        require_gpu(bboxes, gt_bboxes)
+        n = bboxes.size(0)
+        v8 = None if valid is None else valid.to(torch.uint8).reshape(1, n).contiguous()
+        best = atss_best_keys(bboxes[:, :4], [int(x) for x in num_level_bboxes], [1.0] * len(num_level_bboxes), [gt_bboxes], v8,
+                              self.topk)
+        gt_inds = torch.empty(n, dtype=torch.long, device=bboxes.device)
+        max_ov = torch.empty(n, dtype=torch.float32, device=bboxes.device)
+        with torch.cuda.device(bboxes.device):
+            check(lib().sm3_atss_decode(ptr(best[0]), n, ptr(gt_inds), ptr(max_ov), stream_ptr()), 'atss_decode')
+        labels = None
+        if gt_labels is not None:
+            pos = gt_inds > 0
+            labels = torch.where(pos, gt_labels.long()[(gt_inds - 1).clamp(min=0)] if gt_labels.numel() else gt_inds,
+                                 gt_inds.new_full((), -1))
         return AssignResult(gt_bboxes.size(0), gt_inds, max_ov, labels)

@@ -253,6 +253,78 @@ class GFLHead(nn.Module):
         dev = cls_scores[0].device
         lvl_anchors = self._anchors(sizes, dev)
         num_level = [int(a.shape[0]) for a in lvl_anchors]
+        anchors = self._anchors_cat(sizes, lvl_anchors, dev)
+        B = len(gt_bboxes)
+        A, R = anchors.shape[0], self.reg_max
+        tc = self.train_cfg or {}
+        asg = dict(tc.get('assigner') or dict(type='ATSSAssigner', topk=9))
+        if asg.get('type') != 'ATSSAssigner':
+            raise NotImplementedError(f"GFLHead on MI355X: assigner {asg.get('type')!r} (the SM3Det configs use ATSSAssigner)")
+        if tc.get('allowed_border', -1) >= 0:
+            raise NotImplementedError('allowed_border >= 0 (the SM3Det configs use -1)')
+        qb = float((self.loss_cls_cfg or {}).get('beta', 2.0))
+        w_cls = float((self.loss_cls_cfg or {}).get('loss_weight', 1.0))
+        w_dfl = float((self.loss_dfl_cfg or {}).get('loss_weight', 0.25))
+        w_box = float((self.loss_bbox_cfg or {}).get('loss_weight', 2.0))
+        valid = self._valid_u8(sizes, [m.get('pad_shape', m.get('img_shape')) for m in img_metas], dev)  # (B, A) bytes
+        # mmdet runs get_targets per image (ATSSAssigner + PseudoSampler) and loss_single per level (multi_apply): ~200 torch
+        # launches per step in round 5's masked torch form.  Here: one ATSS launch per image, then ONE pass per anchor of every
+        # image evaluates the three losses (sums per level, the numbers loss_single returns before its normalisers) and one
+        # more pass their gradients (csrc/gfl.hip); what is left in torch is the handful of scalar normalisations below.
+        best = atss_best_keys(anchors, num_level, self.strides, gt_bboxes, valid, int(asg.get('topk', 9)))
+        gts_all, labels_all, gt_off = self._gt_tables(gt_bboxes, gt_labels, dev)
+        cs = torch.cat([c.permute(0, 2, 3, 1).reshape(B, -1, self.cls_out_channels) for c in cls_scores], 1)
+        bp = torch.cat([r.permute(0, 2, 3, 1).reshape(B, -1, 4 * (R + 1)) for r in bbox_preds], 1)
+        sums, wt_sum, npos = _GFLLossFn.apply(cs, bp, anchors, best, gts_all, labels_all, gt_off, valid,
+                                              (tuple(num_level), tuple(self.strides), R, qb, float(tc.get('pos_weight', -1))))
+        # get_targets: num_total_pos = sum over the images of max(#positives, 1); loss: reduce_mean over ranks, max(., 1)
+        num_total = _reduce_mean(npos.clamp(min=1).sum().float()).clamp(min=1.0)
+        avg_factor = _reduce_mean(wt_sum.sum()).clamp(min=1.0)
+        l_box = sums[0] * (w_box / avg_factor)
+        l_dfl = sums[1] * (w_dfl / 4.0 / avg_factor)                                        # avg_factor 4.0
+        l_cls = sums[2] * (w_cls / num_total)
+        return dict(loss_cls=list(l_cls.unbind(0)), loss_bbox=list(l_box.unbind(0)), loss_dfl=list(l_dfl.unbind(0)))
+
+    def _anchors_cat(self, sizes, lvl_anchors, device):
+        key = (tuple(sizes), str(device))
+        cache = self.__dict__.setdefault('_anchor_cat_cache', {})
+        if key not in cache:
+            cache[key] = torch.cat(lvl_anchors).float().contiguous()
+        return cache[key]
+
+    def _valid_u8(self, sizes, pad_shapes, device):
+        """(B, A) valid flags as bytes for one (pyramid geometry, padded shapes): built once, reused every step"""
+        key = (tuple(sizes), tuple(tuple(int(v) for v in ps[:2]) for ps in pad_shapes), str(device))
+        cache = self.__dict__.setdefault('_valid_u8_cache', {})
+        if key not in cache:
+            cache[key] = torch.stack([self._valid_cat(sizes, ps, device) for ps in pad_shapes]).to(torch.uint8).contiguous()
+        return cache[key]
+
+    def _gt_tables(self, gt_bboxes, gt_labels, device):
+        """all images' gts / labels concatenated + the device vector of first-gt indices (cached per tuple of gt counts: its
+        upload is a host -> device copy, which a hipGraph capture does not allow -- the warm-up step creates it)"""
+        counts = tuple(int(g.shape[0]) for g in gt_bboxes)
+        cache = self.__dict__.setdefault('_gt_off_cache', {})
+        key = (counts, str(device))
+        if key not in cache:
+            off, acc = [], 0
+            for c in counts:
+                off.append(acc)
+                acc += c
+            cache[key] = torch.tensor(off, dtype=torch.int32, device=device)
+        if sum(counts) == 0:
+            return (torch.zeros(1, 4, device=device), torch.zeros(1, dtype=torch.long, device=device), cache[key])
+        return (torch.cat([g.float().reshape(-1, 4) for g in gt_bboxes]).contiguous(),
+                torch.cat([l.long().reshape(-1) for l in gt_labels]).contiguous(), cache[key])
+
+    def loss_torch(self, cls_scores, bbox_preds, gt_bboxes, gt_labels, img_metas, gt_bboxes_ignore=None):
+        """round 5's masked torch form of `loss` (get_targets + one pass over all levels in plain PyTorch): kept as the
+        restatement the kernels are tested against (tests/test_gfl_gpu.py); not on the training path"""
+        from . import gfl_losses as GL
+        sizes = [tuple(c.shape[-2:]) for c in cls_scores]
+        dev = cls_scores[0].device
+        lvl_anchors = self._anchors(sizes, dev)
+        num_level = [int(a.shape[0]) for a in lvl_anchors]
         anchors = torch.cat(lvl_anchors)
         valid = [self._valid_cat(sizes, m.get('pad_shape', m.get('img_shape')), dev) for m in img_metas]
         labels, label_w, box_t, pos = self.get_targets(anchors, num_level, valid, gt_bboxes, gt_labels)
@@ -261,13 +333,8 @@ class GFLHead(nn.Module):
         w_cls = float((self.loss_cls_cfg or {}).get('loss_weight', 1.0))
         w_dfl = float((self.loss_dfl_cfg or {}).get('loss_weight', 0.25))
         w_box = float((self.loss_bbox_cfg or {}).get('loss_weight', 2.0))
-        # get_targets: num_total_pos = sum over the images of max(#positives, 1); loss: reduce_mean over ranks, max(., 1)
         num_total = _reduce_mean(pos.sum(dim=1).clamp(min=1).sum().float()).clamp(min=1.0)
         R = self.reg_max
-        # mmdet runs loss_single once per level (multi_apply).  Every term is per anchor and only the final sums are per
-        # level, so all levels go through ONE pass here -- per-anchor stride / centre / level tables are built once per
-        # pyramid geometry -- and the per-level sums are one product with the (A, levels) membership matrix: a fifth of the
-        # launches, the same numbers up to the order of the fp32 sums.
         ctr, lvl1h = self._loss_tables(sizes, anchors, num_level, dev)     # (A, 2) centres / stride, (A, L) one-hot
         A = anchors.shape[0]
         cs = torch.cat([c.permute(0, 2, 3, 1).reshape(B, -1, self.cls_out_channels) for c in cls_scores], 1)
@@ -359,6 +426,78 @@ class GFLHead(nn.Module):
     def simple_test(self, feats, img_metas, rescale=False):
         """BBoxTestMixin.simple_test_bboxes (dense_test_mixins.py:18-38)"""
         return self.get_bboxes(*self(feats), img_metas=img_metas, rescale=rescale)
+
+
+
+# ------------------------------------------------------------------------------------------- loss kernels (round 6)
+def _level_tables(num_level, strides):
+    """HOST tables of sm3_atss_assign / sm3_gfl_loss_*: level offsets and strides (ctypes arrays, built per pyramid geometry)"""
+    import ctypes
+    off = [0]
+    for n in num_level:
+        off.append(off[-1] + int(n))
+    return (ctypes.c_int * len(off))(*off), (ctypes.c_float * len(num_level))(*[float(s) for s in strides])
+
+
+def atss_best_keys(anchors, num_level, strides, gt_bboxes_list, valid, topk):
+    """ATSS assignment of every image on the device (sm3_atss_assign, csrc/gfl.hip): (B, A) int64 keys -- 0 = no positive,
+    else (IoU bits << 32 | ~gt index of the image).  valid (B, A) uint8 or None."""
+    from ._lib import check, lib, ptr, require_gpu, stream_ptr
+    require_gpu(anchors)
+    B, A = len(gt_bboxes_list), anchors.shape[0]
+    off, st = _level_tables(num_level, strides)
+    best = torch.empty(B, A, dtype=torch.int64, device=anchors.device)
+    anchors = anchors.float().contiguous()
+    with torch.cuda.device(anchors.device):
+        for b, g in enumerate(gt_bboxes_list):
+            g = g.float().contiguous()
+            check(lib().sm3_atss_assign(ptr(anchors), A, off, st, len(num_level), ptr(g) if g.numel() else None, int(g.shape[0]),
+                                        ptr(valid[b]) if valid is not None else None, int(topk), ptr(best[b]), stream_ptr()),
+                  'atss_assign')
+    return best
+
+
+class _GFLLossFn(Function):
+    """per-level sums of the three GFL losses (GIoU x weight, DFL x weight, QFL x label weight) + weight sums + positive
+    counts, one kernel forward (sm3_gfl_loss_fwd) and one backward (sm3_gfl_loss_bwd)"""
+
+    @staticmethod
+    def forward(ctx, cs, bp, anchors, best, gts, gt_labels, gt_off, valid, meta):
+        from ._lib import check, lib, ptr, require_gpu, stream_ptr
+        require_gpu(cs, bp, anchors, best)
+        num_level, strides, R, beta, pos_weight = meta
+        cs, bp = cs.float().contiguous(), bp.float().contiguous()
+        B, A, C = cs.shape
+        off, st = _level_tables(num_level, strides)
+        sums = torch.empty(4, 8, dtype=torch.float64, device=cs.device)
+        npos = torch.empty(B, dtype=torch.int32, device=cs.device)
+        args = (ptr(cs), ptr(bp), ptr(anchors), B, A, C, int(R), off, st, len(num_level), ptr(best), ptr(gts), ptr(gt_labels),
+                ptr(gt_off), ptr(valid) if valid is not None else None, float(pos_weight), float(beta))
+        with torch.cuda.device(cs.device):
+            check(lib().sm3_gfl_loss_fwd(*args, ptr(sums), ptr(npos), stream_ptr()), 'gfl_loss_fwd')
+        ctx.save_for_backward(cs, bp, anchors, best, gts, gt_labels, gt_off, valid)
+        ctx.meta = meta
+        L = len(num_level)
+        ctx.mark_non_differentiable(npos)
+        out = sums[:, :L].float()
+        return out[:3].contiguous(), out[3].contiguous(), npos
+
+    @staticmethod
+    def backward(ctx, d_sums, _d_wt, _d_npos):
+        from ._lib import check, lib, ptr, stream_ptr
+        cs, bp, anchors, best, gts, gt_labels, gt_off, valid = ctx.saved_tensors
+        num_level, strides, R, beta, pos_weight = ctx.meta
+        B, A, C = cs.shape
+        off, st = _level_tables(num_level, strides)
+        coef = torch.zeros(3, 8, dtype=torch.float32, device=cs.device)
+        coef[:, :len(num_level)] = d_sums.float()
+        dcs, dbp = torch.empty_like(cs), torch.empty_like(bp)
+        with torch.cuda.device(cs.device):
+            check(lib().sm3_gfl_loss_bwd(ptr(cs), ptr(bp), ptr(anchors), B, A, C, int(R), off, st, len(num_level), ptr(best),
+                                         ptr(gts), ptr(gt_labels), ptr(gt_off), ptr(valid) if valid is not None else None,
+                                         float(pos_weight), float(beta), ptr(coef), ptr(dcs), ptr(dbp), stream_ptr()),
+                  'gfl_loss_bwd')
+        return dcs, dbp, None, None, None, None, None, None, None
 
 
 def _reduce_mean(t):

@@ -82,3 +82,122 @@ def test_gfl_head_config_shapes_state_dict_and_values_vs_oracle():
     for a, b in zip(fg, fr):
         assert rel_err(a.grad, b.grad) < 1e-3
     assert len(got) == len(ref_p)
+
+
+# ------------------------------------------------------------------------------------------- loss-side kernels (round 6)
+def _pyramid_anchors(sizes, strides, scale=8.0):
+    out = []
+    for (h, w), s in zip(sizes, strides):
+        ys, xs = torch.meshgrid(torch.arange(h), torch.arange(w), indexing='ij')
+        cx, cy = xs.reshape(-1).float() * s, ys.reshape(-1).float() * s
+        half = scale * s / 2.0
+        out.append(torch.stack((cx - half, cy - half, cx + half, cy + half), 1))
+    return out
+
+
+def _random_gts(k, extent, g, lo=16.0, hi=160.0):
+    wh = torch.rand(k, 2, generator=g) * (hi - lo) + lo
+    c = torch.rand(k, 2, generator=g) * (extent - hi) + hi / 2
+    return torch.cat((c - wh / 2, c + wh / 2), 1)
+
+
+@pytest.mark.parametrize('seed,k,masked', [(0, 8, False), (1, 1, False), (2, 23, True), (3, 5, True), (4, 0, False)])
+def test_atss_kernel_equals_the_masked_torch_form(seed, k, masked):
+    """sm3_atss_assign (+ decode) against `gfl_losses.atss_assign` -- the restatement tests/test_gfl_loss_cpu.py pins on the
+    oracle's indexing form -- on the SAR pyramid of a 512^2 image (5 levels, 5 456 anchors), with anchors outside the padded
+    image masked: gt_inds integer-equal (random boxes: no exact distance ties; those have their own test below)."""
+    from sm3det_amd import gfl_losses as GL
+    from sm3det_amd.assign import ATSSAssigner
+    g = torch.Generator().manual_seed(seed)
+    strides = [8, 16, 32, 64, 128]
+    sizes = [(64, 64), (32, 32), (16, 16), (8, 8), (4, 4)]
+    lv = _pyramid_anchors(sizes, strides)
+    num = [a.shape[0] for a in lv]
+    anchors = torch.cat(lv).cuda()
+    gts = _random_gts(k, 512.0, g).cuda()
+    labels = torch.randint(0, 26, (k,), generator=g).cuda()
+    valid = None
+    if masked:  # positions beyond a 400 x 448 padded image
+        valid = torch.cat([((torch.arange(h)[:, None] * s < 400) & (torch.arange(w)[None, :] * s < 448)).reshape(-1)
+                           for (h, w), s in zip(sizes, strides)]).cuda()
+    want_inds, _, want_lab = GL.atss_assign(anchors, num, gts, labels, topk=9, valid=valid)
+    res = ATSSAssigner(topk=9).assign(anchors, num, gts, gt_labels=labels, valid=valid)
+    assert torch.equal(res.gt_inds, want_inds), int((res.gt_inds != want_inds).sum())
+    if k:
+        assert torch.equal(res.labels, want_lab)
+        pos = want_inds > 0
+        assert int(pos.sum()) > 0
+        ov = GL.bbox_overlaps(anchors, gts)
+        assert torch.equal(res.max_overlaps[pos], ov[pos, want_inds[pos] - 1])  # the winning IoU, bit for bit
+
+
+def test_atss_kernel_distance_ties_go_to_the_lower_anchor_index():
+    """a gt centred exactly between grid positions has equidistant anchors at the top-k cut; the kernel's rule (documented
+    in csrc/gfl.hip: lower index first) against a stable-sort evaluation of the same algorithm"""
+    import numpy as np
+    from sm3det_amd import gfl_losses as GL
+    from sm3det_amd.assign import ATSSAssigner
+    strides, sizes = [8, 16], [(16, 16), (8, 8)]
+    lv = _pyramid_anchors(sizes, strides)
+    num = [a.shape[0] for a in lv]
+    anchors = torch.cat(lv)
+    gts = torch.tensor([[28.0, 28.0, 100.0, 100.0], [4.0, 36.0, 60.0, 92.0]])  # centres (64, 64) and (32, 64): on / between nodes
+    topk = 9
+    a, gt = anchors.numpy().astype(np.float32), gts.numpy().astype(np.float32)
+    ov = GL.bbox_overlaps(anchors, gts).numpy()
+    cx, cy = (a[:, 0] + a[:, 2]) / 2, (a[:, 1] + a[:, 3]) / 2
+    best = np.full(a.shape[0], -1.0, np.float32)
+    want = np.zeros(a.shape[0], np.int64)
+    for gi in range(gt.shape[0]):
+        gx, gy = (gt[gi, 0] + gt[gi, 2]) / 2, (gt[gi, 1] + gt[gi, 3]) / 2
+        d = np.sqrt((cx - gx) ** 2 + (cy - gy) ** 2).astype(np.float32)
+        cand, s = [], 0
+        for n in num:
+            cand += list(s + np.argsort(d[s:s + n], kind='stable')[:topk])
+            s += n
+        c = np.array(cand)
+        thr = np.float32(ov[c, gi].astype(np.float64).mean()) + np.float32(ov[c, gi].astype(np.float64).std(ddof=1))
+        for i in c:
+            side = min(cx[i] - gt[gi, 0], cy[i] - gt[gi, 1], gt[gi, 2] - cx[i], gt[gi, 3] - cy[i])
+            if ov[i, gi] >= thr and side > 0.01 and ov[i, gi] > best[i]:
+                best[i], want[i] = ov[i, gi], gi + 1
+    res = ATSSAssigner(topk=topk).assign(anchors.cuda(), num, gts.cuda())
+    assert np.array_equal(res.gt_inds.cpu().numpy(), want), (np.nonzero(res.gt_inds.cpu().numpy() != want), want.sum())
+    assert want.sum() > 0
+
+
+@pytest.mark.parametrize('seed,ks,masked', [(0, (8, 8), False), (1, (3, 0), True), (2, (12, 5), True)])
+def test_gfl_loss_kernels_equal_the_masked_torch_form_values_and_gradients(seed, ks, masked):
+    """GFLHead.loss (one ATSS launch per image + sm3_gfl_loss_fwd / _bwd) against GFLHead.loss_torch (round 5's plain-PyTorch
+    evaluation of the same formulas, itself pinned on oracle/gfl_oracle.py by tests/test_gfl_loss_cpu.py): every per-level
+    loss value <= 1e-5 relative, gradients w.r.t. every head output <= 1e-4 (max-norm relative)."""
+    from sm3det_amd.gfl_head import GFLHead
+    torch.manual_seed(seed)
+    head = GFLHead(num_classes=26, in_channels=256, stacked_convs=4, feat_channels=256,
+                   anchor_generator=dict(type='AnchorGenerator', ratios=[1.0], octave_base_scale=8, scales_per_octave=1,
+                                         strides=[8, 16, 32, 64, 128]),
+                   loss_cls=dict(type='QualityFocalLoss', use_sigmoid=True, beta=2.0, loss_weight=1.0),
+                   loss_dfl=dict(type='DistributionFocalLoss', loss_weight=0.25), reg_max=16,
+                   loss_bbox=dict(type='GIoULoss', loss_weight=2.0),
+                   train_cfg=dict(assigner=dict(type='ATSSAssigner', topk=9), allowed_border=-1, pos_weight=-1)).cuda()
+    g = torch.Generator().manual_seed(100 + seed)
+    B, sizes = len(ks), [(64, 64), (32, 32), (16, 16), (8, 8), (4, 4)]
+    mk = lambda c: [(torch.randn(B, c, h, w, generator=g) * 1.5).cuda().requires_grad_(True) for h, w in sizes]  # noqa: E731
+    cls_a, box_a = mk(26), mk(68)
+    cls_b = [t.detach().clone().requires_grad_(True) for t in cls_a]
+    box_b = [t.detach().clone().requires_grad_(True) for t in box_a]
+    gts = [_random_gts(k, 512.0, g).cuda() for k in ks]
+    labels = [torch.randint(0, 26, (k,), generator=g).cuda() for k in ks]
+    metas = [dict(pad_shape=((400, 448, 3) if masked else (512, 512, 3)), img_shape=(512, 512, 3)) for _ in ks]
+    got = head.loss(cls_a, box_a, gts, labels, metas)
+    want = head.loss_torch(cls_b, box_b, gts, labels, metas)
+    wsum = torch.randn(3, 5, generator=g).cuda()
+    tot_g = sum((torch.stack(got[k]) * wsum[i]).sum() for i, k in enumerate(('loss_cls', 'loss_bbox', 'loss_dfl')))
+    tot_w = sum((torch.stack(want[k]) * wsum[i]).sum() for i, k in enumerate(('loss_cls', 'loss_bbox', 'loss_dfl')))
+    for k in ('loss_cls', 'loss_bbox', 'loss_dfl'):
+        a, b = torch.stack(got[k]).double(), torch.stack(want[k]).double()
+        assert float((a - b).abs().max() / b.abs().max().clamp(min=1e-12)) < 1e-5, (k, a, b)
+    tot_g.backward()
+    tot_w.backward()
+    for x, y in zip(cls_a + box_a, cls_b + box_b):
+        assert rel_err(x.grad, y.grad) < 1e-4, rel_err(x.grad, y.grad)

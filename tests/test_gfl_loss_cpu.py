@@ -64,7 +64,7 @@ def test_gfl_loss_matches_the_indexing_form_values_and_gradients(seed, ngts):
     reg = [torch.randn(B, 68, h, w).requires_grad_(True) for h, w in sizes]
     gts = [_gts(n, float(extent), 10 * seed + i) for i, n in enumerate(ngts)]
     metas = [dict(img_shape=(extent, extent, 3), pad_shape=(extent, extent, 3)) for _ in range(B)]
-    got = head.loss(cls, reg, [g[0] for g in gts], [g[1] for g in gts], metas)
+    got = head.loss_torch(cls, reg, [g[0] for g in gts], [g[1] for g in gts], metas)  # the masked torch restatement (the kernels are tested against it on the GPU)
     exp = GO.gfl_loss([c.detach() for c in cls], [r.detach() for r in reg], lvl, strides, [g[0] for g in gts],
                       [g[1] for g in gts], 26)
     for key in ('loss_cls', 'loss_bbox', 'loss_dfl'):
