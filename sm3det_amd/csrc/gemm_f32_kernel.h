@@ -1448,7 +1448,13 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16, CSUM, IO, MODE>()
       *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(p.aux_out) + ai) =
           f16x4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
     } else {
+#ifndef SM3_AUX_TEMPORAL  // (A/B: --variant aux_temporal restores the plain store)
+      // GELU' is not read again before the backward pass: a non-temporal store keeps it from evicting the activations the
+      // next GEMM reads (stage 0: act and GELU' are 201 MB each, the MALL holds 256 MB) -- 16.25 -> 16.16 ms per step, same box
+      __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p.aux_out + ai));
+#else
       *reinterpret_cast<f32x4*>(p.aux_out + ai) = v;
+#endif
     }
   };
   if (AUX_IN) {
@@ -1504,7 +1510,11 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16, CSUM, IO, MODE>()
           st_c(ci, y);
         } else if (EPI == EPI_BIAS_SCALE_RES) {
           const f32x4 y = v[it] + bv;
+#ifndef SM3_AUX_TEMPORAL
+          __builtin_nontemporal_store(y, reinterpret_cast<f32x4*>(p.aux_out + ai));  // y: saved for the backward pass only
+#else
           *reinterpret_cast<f32x4*>(p.aux_out + ai) = y;  // y and the residual stream are fp32 in every data path
+#endif
           const float rsc = p.rowscale ? p.rowscale[row / p.rows_per_scale] : 1.f;
           st_c(ci, pre[t % (AUX_DEPTH + 1)][it] + (gv * rsc) * y);
         } else if (EPI == EPI_GELU_BWD) {
