@@ -447,6 +447,10 @@ int sm3_dwconv7_fwd(const float* x, const float* w49, const float* bias, const f
                     int W, int C, int flip, sm3_stream_t stream);
 int sm3_dwconv7_bwd_weight(const float* x, const float* du, float* dw49, float* dbias, int B, int H, int W, int C,
                            sm3_stream_t stream);
+/* ... _acc: the same sums ADDED to dw49 / dbias (no fill): the caller provides zeros -- e.g. slices of ONE zero-filled
+ * arena for all blocks of a backward pass (18 fills -> 1) -- or a running sum */
+int sm3_dwconv7_bwd_weight_acc(const float* x, const float* du, float* dw49, float* dbias, int B, int H, int W, int C,
+                               sm3_stream_t stream);
 
 /* layer-scale / stochastic-depth backward of a dense block (:368-370): dy = gamma*rs[b]*dout ;
  * dgamma_db (2C, overwritten) = [ dgamma[c] = sum_t rs[b]*dout[t,c]*y[t,c] | db2[c] = sum_t dy[t,c] ] */

@@ -112,7 +112,8 @@ def main():
         t32, tb3 = timed(0), timed(2)
         alts = []
         if sweep:
-            for t in ((0, 1, 2) if mode == 'tn' else (0, 1, 5)):
+            big = '--big-tiles' in sys.argv  # + 128x192 (NT / NN / TN) and 192x128 (TN): two workgroups per CU
+            for t in (((0, 1, 2, 3, 4) if big else (0, 1, 2)) if mode == 'tn' else ((0, 1, 5, 3) if big else (0, 1, 5))):
                 sl = [0]
                 if '--splits' in sys.argv:
                     sl = [1, 2, 3, 4, 6, 8] if mode != 'tn' else [8, 16, 24, 32, 48, 64, 96, 128, 192, 256, 384, 512, 768]

@@ -42,6 +42,7 @@ def signatures():
         'sm3_layernorm_bwd': (I, [P, P, P, P, P, P, P, LL, I, I, I, I, I, P, S, P]),
         'sm3_dwconv7_fwd': (I, [P, P, P, P, P, I, I, I, I, I, P]),
         'sm3_dwconv7_bwd_weight': (I, [P, P, P, P, I, I, I, I, P]),
+        'sm3_dwconv7_bwd_weight_acc': (I, [P, P, P, P, I, I, I, I, P]),
         'sm3_scale_bwd_prep': (I, [P, P, P, P, I, P, P, LL, I, P, S, P]),
         'sm3_conv3x3_nhwc_workspace_bytes': (S, [I, I, I, I, I, I, I]),
         'sm3_conv3x3_nhwc_fwd': (I, [P, P, P, P, I, I, I, I, I, I, I, P, S, P]),

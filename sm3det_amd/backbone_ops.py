@@ -158,6 +158,35 @@ def _deferred_reduce(ws, T, C, ncols, out, params=()):
     lst.append((ws, nblk, ncols, out.data_ptr(), out.untyped_storage(), torch.cuda.current_stream(out.device)))
 
 
+# Zero-initialised accumulation targets of a backward pass (the depthwise weight / bias gradients, which their kernel builds
+# with atomics) come from ONE arena per pass, filled by ONE launch: 18 zero-fill launches per ConvNeXt-T step -> 1.  The arena
+# of a pass is sized by what the previous pass used (the first pass, or a pass that needs more, simply opens another chunk);
+# a pass is identified by autograd's graph-task id, and slices stay alive as long as the gradients that view them.
+_ZERO_ARENA = {}  # device index -> dict(task, buf, used, need)
+
+
+def _zero_slab(n, like):
+    di = like.device.index
+    try:
+        task = torch._C._current_graph_task_id()
+    except Exception:  # noqa: BLE001
+        task = -1
+    st = _ZERO_ARENA.get(di)
+    if task < 0:
+        return torch.zeros(n, device=like.device, dtype=torch.float32)
+    if st is None or st['task'] != task:
+        need = max(n, st['total'] if st is not None else 0)
+        st = _ZERO_ARENA[di] = dict(task=task, buf=torch.zeros(need, device=like.device, dtype=torch.float32), used=0,
+                                    total=0)
+    if st['used'] + n > st['buf'].numel():  # (first pass of a model, or a larger one: another chunk)
+        st['buf'] = torch.zeros(max(n, st['buf'].numel()), device=like.device, dtype=torch.float32)
+        st['used'] = 0
+    out = st['buf'][st['used']:st['used'] + n]
+    st['used'] += n
+    st['total'] += n
+    return out
+
+
 def _bucket_out(param, *shape):
     """the slice of the data-parallel gradient bucket that belongs to `param` (BucketedGradReducer hangs it on the
     parameter), as a FRESH tensor object over that memory -- or None.  A weight-gradient GEMM that writes there makes the
@@ -395,9 +424,9 @@ def _dw_ln_backward(dxn, dout, x, u, w49, lnw, mean, rstd, B, H, W, C):
     call('layernorm_bwd', dxn, u, lnw, mean, rstd, du, None, T, C, 16 if u.dtype == torch.float16 else 0, H, W, 0, ws, nb,
          nbytes=(8.0 + u.element_size()) * T * C)
     _deferred_reduce(ws, T, C, 2 * C, dwdb, params=(lnw,))  # d(ln weight) | d(ln bias); joined by the caller
-    dwb = _e(50, C, like=x)  # [dw49 (49,C); dbias (C)] in one buffer: one fill inside the kernel wrapper
+    dwb = _zero_slab(50 * C, x).view(50, C)  # [dw49 (49,C); dbias (C)]: zeros from the pass's arena (one fill per pass)
     dw49, dbdw = dwb[:49], dwb[49]
-    _on_side(x.device, lambda: call('dwconv7_bwd_weight', x, du, dw49, dbdw, B, H, W, C,
+    _on_side(x.device, lambda: call('dwconv7_bwd_weight_acc', x, du, dw49, dbdw, B, H, W, C,
                                     nbytes=8.0 * T * C))  # joined by the caller
     dx = _e(T, C, like=x)
     call('dwconv7_fwd', du, w49, None, dout, dx, B, H, W, C, 1, nbytes=12.0 * T * C)  # flip=1: reversed taps

@@ -48,7 +48,7 @@ VARIANTS = {
     'trace_stagger': ['-DSM3_TRACE=1', '-DSM3_STAGGER=1'],
     'lpt8': ['-DSM3_ROUTER_LPT=8'], 'lpt2': ['-DSM3_ROUTER_LPT=2'],  # lanes per token of the MoE router kernels
     'abl_nocvt': ['-DSM3_ABL_NOCVT=1'],  # bf16x3 loop without the split arithmetic (stores kept)
-    'b3_nomix': ['-DSM3_B3_NOMIX=1'], 'b3_occ2': ['-DSM3_B3_OCC=2'], 'b3_unsigned': ['-DSM3_B3_SIGNED=0'], 'f16_spills': ['-DSM3_F16_KEEP_SPILLS=1'], 'aux_temporal': ['-DSM3_AUX_TEMPORAL=1'], 'b3_two_sets': ['-DSM3_B3_SIGNED=1'], 'dw_onetile': ['-DSM3_DW_MULTITILE=0'], 'dw_wgrad_1024': ['-DSM3_DW_WGRAD_ONE_ROUND=0'],
+    'b3_nomix': ['-DSM3_B3_NOMIX=1'], 'b3_occ2': ['-DSM3_B3_OCC=2'], 'b3_unsigned': ['-DSM3_B3_SIGNED=0'], 'f16_spills': ['-DSM3_F16_KEEP_SPILLS=1'], 'aux_temporal': ['-DSM3_AUX_TEMPORAL=1'], 'b3_slp': ['-fslp-vectorize'], 'b3_two_sets': ['-DSM3_B3_SIGNED=1'], 'dw_onetile': ['-DSM3_DW_MULTITILE=0'], 'dw_wgrad_1024': ['-DSM3_DW_WGRAD_ONE_ROUND=0'],
  # bf16x3 GEMMs at three workgroups per CU (register budget 168 instead of 256)
     'abl_noepi': ['-DSM3_ABL_NOEPI=1'], 'abl_loop_only_mfma': ['-DSM3_ABL_NOLOAD=1', '-DSM3_ABL_NOSTORE=1', '-DSM3_ABL_NOEPI=1'],
 }

@@ -888,12 +888,14 @@ int sm3_dwconv7_fwd(const float* x, const float* w49, const float* bias, const f
   return launch_status();
 }
 
-int sm3_dwconv7_bwd_weight(const float* x, const float* du, float* dw49, float* dbias, int B, int H, int W, int C,
-                           sm3_stream_t stream) {
+static int dwconv7_bwd_weight_impl(const float* x, const float* du, float* dw49, float* dbias, int B, int H, int W, int C,
+                                   int zero_fill, sm3_stream_t stream) {
   if (!x || !du || !dw49 || !dbias || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || C > 1024)
     return SM3_ERR_INVALID_ARG;
   hipStream_t st = (hipStream_t)stream;
-  if (dbias == dw49 + (size_t)49 * C) {  // one (50, C) buffer [dw49; dbias]: one fill
+  if (!zero_fill) {
+    // sm3_dwconv7_bwd_weight_acc: the kernels ADD their partial sums (atomics) into what the caller provides
+  } else if (dbias == dw49 + (size_t)49 * C) {  // one (50, C) buffer [dw49; dbias]: one fill
     sm3_zero_async(dw49, sizeof(float) * 50 * C, st);
   } else {
     sm3_zero_async(dw49, sizeof(float) * 49 * C, st);
@@ -912,6 +914,16 @@ int sm3_dwconv7_bwd_weight(const float* x, const float* du, float* dw49, float* 
   const size_t lds = (size_t)spb * 8 * C * sizeof(float);
   dwconv7_bwd_weight_kernel<<<grid, nq * spb, lds, st>>>(x, du, dw49, dbias, B, H, W, C, spb);
   return launch_status();
+}
+
+int sm3_dwconv7_bwd_weight(const float* x, const float* du, float* dw49, float* dbias, int B, int H, int W, int C,
+                           sm3_stream_t stream) {
+  return dwconv7_bwd_weight_impl(x, du, dw49, dbias, B, H, W, C, 1, stream);
+}
+
+int sm3_dwconv7_bwd_weight_acc(const float* x, const float* du, float* dw49, float* dbias, int B, int H, int W, int C,
+                               sm3_stream_t stream) {
+  return dwconv7_bwd_weight_impl(x, du, dw49, dbias, B, H, W, C, 0, stream);
 }
 
 int sm3_scale_bwd_prep(const float* dout, const float* y, const float* gamma, const float* rowscale,

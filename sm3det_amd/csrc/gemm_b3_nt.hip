@@ -13,6 +13,7 @@ static int nt_b3_by_tile(const GemmParams& p, int tile, dim3 grid, hipStream_t s
     case 0: gemm_f32_kernel<MODE_NT, EPI, 16, T128x128, 0, 2><<<grid, NTHREADS, 0, st>>>(p); return SM3_OK;
     case 1: gemm_f32_kernel<MODE_NT, EPI, 16, T128x96, 0, 2><<<grid, NTHREADS, 0, st>>>(p); return SM3_OK;
     case 5: gemm_f32_kernel<MODE_NT, EPI, 16, T64x128, 0, 2><<<grid, NTHREADS, 0, st>>>(p); return SM3_OK;
+    case 3: gemm_f32_kernel<MODE_NT, EPI, 16, T128x192, 0, 2><<<grid, NTHREADS, 0, st>>>(p); return SM3_OK;  // two workgroups per CU
   }
   return SM3_ERR_INVALID_ARG;
 }

@@ -15,6 +15,8 @@ int launch_tn_b3(const GemmParams& p, int tile, dim3 grid, hipStream_t st) {
     case 0: go_tn_b3<T128x128>(p, grid, st); return SM3_OK;
     case 1: go_tn_b3<T128x96>(p, grid, st); return SM3_OK;
     case 2: go_tn_b3<T96x128>(p, grid, st); return SM3_OK;
+    case 3: go_tn_b3<T128x192>(p, grid, st); return SM3_OK;  // six 32x32 blocks per wave: two workgroups per CU
+    case 4: go_tn_b3<T192x128>(p, grid, st); return SM3_OK;
   }
   return SM3_ERR_INVALID_ARG;
 }

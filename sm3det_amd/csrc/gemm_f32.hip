@@ -290,7 +290,8 @@ Cfg choose_cfg(const sm3_gemm_desc* d) {
     if (c.tile < 0) { c.tile = t_tile >= 0 ? t_tile : 0; best_s = 1; }
     c.bk = bk;
     if (c.tile == 3) c.bk = 16;
-    if (d->compute != 0 && c.tile != 0 && c.tile != 1 && c.tile != 5) c.tile = 0;  // fp16 / bf16x3: 128x128 / 128x96 / 64x128
+    if (d->compute == 1 && c.tile != 0 && c.tile != 1 && c.tile != 5) c.tile = 0;  // fp16: 128x128 / 128x96 / 64x128
+    if (d->compute == 2 && c.tile != 0 && c.tile != 1 && c.tile != 5 && c.tile != 3) c.tile = 0;  // bf16x3: + 128x192
     if (d->compute == 2) c.bk = 16;
     tile_dims(c.tile, c.bm, c.bn);
     c.ntn = (d->N + c.bn - 1) / c.bn;
@@ -349,7 +350,7 @@ Cfg choose_cfg(const sm3_gemm_desc* d) {
   }
   if (d->compute == 2) {
     c.bk = 16;
-    if (c.tile > 2) c.tile = 0;
+    if (c.tile > 4) c.tile = 0;  // (128x192 / 192x128: through the tuning override)
   }
   tile_dims(c.tile, c.bm, c.bn);
   c.ntn = (d->N + c.bn - 1) / c.bn;
