@@ -47,6 +47,7 @@ MI355X_HBM_PEAK_GBS = 8000.0  # same guide: HBM3E ~8 TB/s
 MI355X_BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: dense bf16 MFMA (v_mfma_f32_32x32x16_bf16), measured 2495
 # bf16x3 form of the fp32 GEMMs: six bf16 products per fp32 product -> fp32-equivalent ceiling of the matrix pipe
 MI355X_BF16X3_PEAK_TFLOPS = MI355X_BF16_MFMA_PEAK_TFLOPS / 6.0
+MI355X_F16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: dense fp16 MFMA rate = the bf16 one (v_mfma_f32_32x32x16_f16)
 BATCH = 2
 RES = int(os.environ.get('SM3_BENCH_RES', '1024'))  # 1024 = BASELINE config; the override is a debugging aid only
 CONFIG_FILE = os.path.join(ROOT, 'sm3det_amd', 'configs', 'baseline_configs.json')
@@ -1235,7 +1236,7 @@ def main():
         # passes exist for the headline workload (fp32 and AMP), other configs report null
         traffic = traffic_file = None
         if args.config == DEFAULT_CONFIG or (args.amp and args.config == 'SM3Det_convnext_t'):  # the same backbone
-            for rnd in ('r05', 'r04', 'r03', 'r02'):
+            for rnd in ('r06', 'r05', 'r04', 'r03', 'r02'):
                 cand = os.path.join('profiles', rnd, 'pmc_traffic_amp.json' if args.amp else 'pmc_traffic.json')
                 try:
                     with open(os.path.join(ROOT, cand)) as f:
@@ -1266,10 +1267,15 @@ def main():
                             peak_note='dense bf16 MFMA peak 2500 TF/s / 6 products per fp32 product; achieved = fp32 FLOP / time',
                             x_native_fp32_mfma_peak=round(achieved / MI355X_FP32_MFMA_PEAK_TFLOPS, 3),
                             hbm_gbs=round(gbs, 1), hbm_frac=round(gbs / MI355X_HBM_PEAK_GBS, 4))
-            if traffic_file is not None and 'r05' not in traffic_file:
+            if traffic_file is not None and not any(r in traffic_file for r in ('r05', 'r06')):
                 roofline.update(traffic=None, traffic_source=None)  # the older passes measured the native-fp32 kernels
-        if args.amp:  # fp16 operands: 16x the matrix rate -> the family streams its operands: HBM-bound
+        if args.amp:  # fp16 operands: 16x the matrix rate of fp32 -> priced against BOTH ceilings; the nearer one is `bound`,
+            # and `regime` says "latency" while neither fraction reaches 0.5 (launches of ~30 us on a 256-CU part)
             gbs = g_by / (g_ms * 1e-3) / 1e9 if g_ms > 0 else 0.0
+            hbm_frac, mfma_frac = gbs / MI355X_HBM_PEAK_GBS, achieved / MI355X_F16_MFMA_PEAK_TFLOPS
+            roofline.update(regime='latency' if max(hbm_frac, mfma_frac) < 0.5 else ('hbm' if hbm_frac >= mfma_frac else 'mfma'),
+                            hbm_frac=round(hbm_frac, 4), mfma_frac=round(mfma_frac, 4),
+                            mfma_peak_tflops=MI355X_F16_MFMA_PEAK_TFLOPS)
             roofline.update(bound='hbm', kernel='gemm_f32_kernel<.., F16, IO> (v_mfma_f32_32x32x16_f16; activations stored '
                             'fp16 in HBM, weights / residual stream / C-wide gradients fp32 and rounded in the loader)',
                             achieved=round(gbs, 1), peak=MI355X_HBM_PEAK_GBS, unit='GB/s',
