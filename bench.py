@@ -503,8 +503,8 @@ def full_model_bench():
     MultitaskFPN x3, GFLHead with ATSS + QFL / DFL / GIoU for the SAR pair, OrientedRPNHead + OrientedStandardRoIHead with
     their real targets and losses for the RGB and the IR image) -> BaseDetector._parse_losses -> backward -> grad-clip(35)
     + AdamW over all 178 M parameters.  Inputs are device-resident; the step is sync-free and replayed from two hipGraphs
-    when capture succeeds.  The SAR loss side is plain PyTorch (mmdet code, restated, parity unpinned); everything else
-    runs on this package's kernels."""
+    when capture succeeds.  The SAR loss side (ATSS, QFL / DFL / GIoU) is restated from mmdet (not vendored: parity unpinned)
+    and runs on csrc/gfl.hip like everything else."""
     import copy
     import numpy as np
     from sm3det_amd import detector  # noqa: F401
@@ -1346,8 +1346,8 @@ def main():
                     result['full_model_imgs_per_sec'] = fm['imgs_per_sec']
                     result['full_model_workload'] = (
                         'TriSourceDetector of main_SM3Det.py built from the config dict, one training step at the native mix 2 SAR + '
-                        '1 RGB + 1 IR @1024^2: backbone (4 images) + MultitaskFPN x3 + GFLHead (ATSS, QFL/DFL/GIoU: plain PyTorch, '
-                        'unpinned) + 2 x (OrientedRPNHead + OrientedStandardRoIHead) with real targets / losses + the dynamic-lr policy of '
+                        '1 RGB + 1 IR @1024^2: backbone (4 images) + MultitaskFPN x3 + GFLHead (ATSS, QFL/DFL/GIoU: device kernels, '
+                        'restated from mmdet, unpinned) + 2 x (OrientedRPNHead + OrientedStandardRoIHead) with real targets / losses + the dynamic-lr policy of '
                         "the config's lr_config (one per-tensor lr from the 11 loss EMAs, on the device) + backward + clip + "
                         'AdamW over 178 M parameters; device-resident synthetic inputs, no data pipeline')
                 except Exception as e:  # noqa: BLE001  (never lose the headline line to the extra workload)

@@ -25,6 +25,7 @@ from torch.autograd import Function
 from . import _lib
 from . import _lib_backbone as LB
 from . import backbone_ops as ops
+from . import level_streams
 from .registry import ROTATED_NECKS as _REG
 
 call, colsum = LB.call, LB.colsum
@@ -260,12 +261,13 @@ class MultitaskFPN(nn.Module):
         if add_extra_convs is None:
             add_extra_convs = self.add_extra_convs
         xs = [_to_nhwc(t) for t in inputs]
-        laterals = [lc.forward_nhwc(xs[i + start_level])
-                    for i, lc in enumerate(list(self.lateral_convs)[start_level:])]
+        lcs = list(self.lateral_convs)[start_level:]
+        laterals = level_streams.map_levels(lambda x, lc: lc.forward_nhwc(x), xs[start_level:start_level + len(lcs)], lcs)
         used = len(laterals)
         for i in range(used - 1, 0, -1):  # top-down path :123-135
             laterals[i - 1] = upsample2x_add(laterals[i - 1], laterals[i])
-        outs = [self.fpn_convs[i + start_level].forward_nhwc(laterals[i]) for i in range(used)]
+        outs = level_streams.map_levels(lambda x, fc: fc.forward_nhwc(x), laterals,
+                                        list(self.fpn_convs)[start_level:start_level + used])
         if self.num_outs > len(outs):  # :142-161
             if not add_extra_convs:
                 for _ in range(self.num_outs - used):

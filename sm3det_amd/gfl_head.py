@@ -32,6 +32,7 @@ from torch.autograd import Function
 
 from . import _lib
 from . import _lib_backbone as LB
+from . import level_streams
 from .fpn import _Conv, _to_nchw_view, _to_nhwc, conv3x3_nhwc
 from .registry import MODELS as _REG
 
@@ -170,7 +171,7 @@ class GFLHead(nn.Module):
 
     def forward(self, feats):
         """multi_apply(forward_single, feats, self.scales) -> (list of cls scores, list of bbox preds)"""
-        outs = [self.forward_single(f, s) for f, s in zip(feats, self.scales)]
+        outs = level_streams.map_levels(self.forward_single, feats, list(self.scales))
         return [o[0] for o in outs], [o[1] for o in outs]
 
     # ------------------------------------------------------------------------------------------- training side

@@ -26,6 +26,7 @@ import torch.nn as nn
 
 from . import _lib
 from . import _lib_backbone as LB
+from . import level_streams
 from . import backbone_ops as ops
 from . import mmcv_ops
 from .fpn import _Conv, _to_nhwc, conv3x3_nhwc
@@ -286,7 +287,7 @@ class OrientedRPNHead(nn.Module):
     def forward(self, feats):
         """multi_apply(forward_single, feats) -> (list of cls scores, list of bbox preds)"""
         fused = self._fused_heads()
-        outs = [self.forward_single(f, fused) for f in feats]
+        outs = level_streams.map_levels(lambda f: self.forward_single(f, fused), feats)
         return [o[0] for o in outs], [o[1] for o in outs]
 
     # ------------------------------------------------------------------------------------------ proposals
