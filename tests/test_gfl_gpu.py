@@ -201,3 +201,53 @@ def test_gfl_loss_kernels_equal_the_masked_torch_form_values_and_gradients(seed,
     tot_w.backward()
     for x, y in zip(cls_a + box_a, cls_b + box_b):
         assert rel_err(x.grad, y.grad) < 1e-4, rel_err(x.grad, y.grad)
+
+
+# ------------------------------------------------------------------------------------------- pyramid levels on parallel streams
+@pytest.mark.parametrize('mode', [1, 2])
+def test_levels_on_parallel_streams_give_the_serial_loops_bits(mode, monkeypatch):
+    """sm3det_amd/level_streams.py (opt-in): the five levels of the shared-weight heads on their own streams -- outputs,
+    input gradients and the (level-accumulated) parameter gradients must be the serial loop's, eagerly and replayed from a
+    hipGraph (fork / join captured as graph edges)."""
+    from sm3det_amd import level_streams
+    from sm3det_amd.rpn_head import OrientedRPNHead
+    torch.manual_seed(3)
+    head = OrientedRPNHead(in_channels=64, feat_channels=64).cuda()
+    g = torch.Generator().manual_seed(4)
+    feats = [torch.randn(2, 64, s, s, generator=g).cuda().contiguous(memory_format=torch.channels_last) for s in (32, 16, 8, 4, 2)]
+    R = None
+
+    def run():
+        nonlocal R
+        for p in head.parameters():
+            p.grad = None
+        fs = [f.detach().clone().requires_grad_(True) for f in feats]
+        cls, reg = head(fs)
+        if R is None:
+            R = [torch.randn(t.shape, generator=g).cuda() for t in cls + reg]
+        sum((a * r).sum() for a, r in zip(cls + reg, R)).backward()
+        return ([t.detach().clone() for t in cls + reg], [f.grad.clone() for f in fs],
+                [p.grad.clone() for p in head.parameters()])
+
+    monkeypatch.setattr(level_streams, 'MODE', 0)
+    monkeypatch.setattr(level_streams, 'ENABLED', False)
+    ref = run()
+    monkeypatch.setattr(level_streams, 'MODE', mode)
+    monkeypatch.setattr(level_streams, 'ENABLED', True)
+    got = run()
+    torch.cuda.synchronize()
+    for a, b in zip(sum(ref, []), sum(got, [])):
+        assert torch.equal(a, b)
+    # under capture
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        run()
+    torch.cuda.current_stream().wait_stream(side)
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        cap = run()
+    gr.replay()
+    torch.cuda.synchronize()
+    for a, b in zip(sum(ref, []), sum(cap, [])):
+        assert torch.equal(a, b)
