@@ -204,17 +204,27 @@ def test_gfl_loss_kernels_equal_the_masked_torch_form_values_and_gradients(seed,
 
 
 # ------------------------------------------------------------------------------------------- pyramid levels on parallel streams
+def _same_levels(ref, got):
+    """outputs and input gradients bit for bit; the shared-weight gradients are sums over the levels, which autograd forms in
+    the order the per-level gradients ARRIVE (stream-dependent): equal to fp32 rounding of a 5-term sum"""
+    for kind in (0, 1):
+        for i, (a, b) in enumerate(zip(ref[kind], got[kind])):
+            assert torch.equal(a, b), (kind, i, float((a - b).abs().max()))
+    for i, (a, b) in enumerate(zip(ref[2], got[2])):
+        assert float((a - b).abs().max()) <= 4e-7 * float(a.abs().max()), (i, float((a - b).abs().max()), float(a.abs().max()))
+
+
 @pytest.mark.parametrize('mode', [1, 2])
 def test_levels_on_parallel_streams_give_the_serial_loops_bits(mode, monkeypatch):
     """sm3det_amd/level_streams.py (opt-in): the five levels of the shared-weight heads on their own streams -- outputs,
-    input gradients and the (level-accumulated) parameter gradients must be the serial loop's, eagerly and replayed from a
-    hipGraph (fork / join captured as graph edges)."""
+    input gradients must be the serial loop's bit for bit and the (level-accumulated) parameter gradients equal to summation
+    order, eagerly and replayed from a hipGraph (fork / join captured as graph edges)."""
     from sm3det_amd import level_streams
     from sm3det_amd.rpn_head import OrientedRPNHead
     torch.manual_seed(3)
-    head = OrientedRPNHead(in_channels=64, feat_channels=64).cuda()
+    head = OrientedRPNHead(in_channels=128, feat_channels=128).cuda()
     g = torch.Generator().manual_seed(4)
-    feats = [torch.randn(2, 64, s, s, generator=g).cuda().contiguous(memory_format=torch.channels_last) for s in (32, 16, 8, 4, 2)]
+    feats = [torch.randn(2, 128, s, s, generator=g).cuda().contiguous(memory_format=torch.channels_last) for s in (32, 16, 8, 4, 2)]
     R = None
 
     def run():
@@ -236,8 +246,7 @@ def test_levels_on_parallel_streams_give_the_serial_loops_bits(mode, monkeypatch
     monkeypatch.setattr(level_streams, 'ENABLED', True)
     got = run()
     torch.cuda.synchronize()
-    for a, b in zip(sum(ref, []), sum(got, [])):
-        assert torch.equal(a, b)
+    _same_levels(ref, got)
     # under capture
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
@@ -249,5 +258,4 @@ def test_levels_on_parallel_streams_give_the_serial_loops_bits(mode, monkeypatch
         cap = run()
     gr.replay()
     torch.cuda.synchronize()
-    for a, b in zip(sum(ref, []), sum(cap, [])):
-        assert torch.equal(a, b)
+    _same_levels(ref, cap)
