@@ -460,6 +460,14 @@ int sm3_gemm_f32(const sm3_gemm_desc* d, void* workspace, size_t workspace_bytes
   p.rows_per_scale = d->rows_per_scale > 0 ? d->rows_per_scale : 1;
   p.ld_aux = d->ld_aux;
   p.colpart = cb ? (float*)((char*)workspace + sb) : nullptr;
+  {
+    // progress-ordered wave priority (gemm_f32_kernel.h, k-loop): only when every workgroup of the launch is resident at
+    // once on more than one workgroup per CU -- with further rounds to come the oldest-first order is the better pipeline
+    static const int mode = [] { const char* e = getenv("SM3_EQ_PRIO"); return e ? atoi(e) : 2; }();  // 0 off, 1 always, 2 auto
+    const long blocks = (long)c.ntn * c.ntm * (d->mode == MODE_TN ? (long)c.groups * c.splits : c.splits);
+    static const int forms = [] { const char* e = getenv("SM3_EQ_PRIO_FORMS"); return e ? atoi(e) : 6; }();  // bit per d->compute
+    p.eq_prio = ((forms >> d->compute) & 1) && (mode == 1 || (mode == 2 && blocks > kNumCU && blocks <= 3L * kNumCU));
+  }
 #ifdef SM3_TRACE
   p.trace = g_trace;
 #endif

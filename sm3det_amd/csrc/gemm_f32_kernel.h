@@ -90,6 +90,7 @@ struct GemmParams {
   int cC, sH, sW, rH, rW, cS, cT;
   int cU;  // per-tap source offset u(d), d = 0..2, 4 bits each: d (forward), 2 - d (input gradient), 1 - d/2 (same, stride 2)
   unsigned cInv, mRW, mRH;  // mRW/mRH: ceil(2^32 / rW), ceil(2^32 / rH) for exact umulhi division of row indices
+  int eq_prio;  // lower the wave priority with the workgroup's progress through K (see the k-loop)
 #ifdef SM3_TRACE  // measurement build only (python -m sm3det_amd.build --variant trace): per-workgroup phase timestamps
   unsigned long long* trace;  // [blocks][8]: s_memtime at entry / loop start / loop end / after fix-up / exit, HW_ID|XCC_ID<<32, nk, s_memrealtime
 #endif
@@ -1233,7 +1234,19 @@ __global__ __launch_bounds__(NTHREADS, (occupancy<TL, BK, F16, CSUM, IO, MODE>()
   // (bf16x3: a bulk body loads tile t + 3 unclamped and stores tile t + 1 as live)
   const int nk_bulk = max(0, nk - 3) & ~1;
   int kt = 0;
+  // eq_prio (single-round launches, host-decided): the issue arbiter prefers the OLDEST wave, so of the three workgroups
+  // that enter a CU together the first runs its loop in ~0.65 of the time of the last (17 / 27 / 37 us on 8192x1536x384,
+  // profiles/r06/gemm_trace.txt) and the CU spends the last third of the launch with one k-loop alive.  With no further
+  // workgroup to take a freed slot the shortest launch is the one where all three finish TOGETHER: every workgroup lowers
+  // its waves' priority as it advances (3 -> 0), so whoever is behind issues first.
+  // (quarters of the K range; geometric thresholds on the remaining k-tiles -- meeting again at 75 / 87 / 94 % -- measured
+  // the same: the loops of a CU end 9-11 us apart instead of 21, profiles/r06/gemm_trace_eq_prio.txt)
+  const int q1 = p.eq_prio ? (nk >> 2) & ~1 : -1, q2 = p.eq_prio ? (nk >> 1) & ~1 : -1, q3 = p.eq_prio ? (3 * nk >> 2) & ~1 : -1;
+  if (p.eq_prio) __builtin_amdgcn_s_setprio(3);
   for (; kt < nk_bulk; kt += 2) {
+    if (kt == q1) __builtin_amdgcn_s_setprio(2);
+    else if (kt == q2) __builtin_amdgcn_s_setprio(1);
+    else if (kt == q3) __builtin_amdgcn_s_setprio(0);
     if (B3) {
       body_b3(sa1, sb1, kt, 0, false);
       body_b3(sa0, sb0, kt + 1, 1, false);
