@@ -465,8 +465,9 @@ int sm3_gemm_f32(const sm3_gemm_desc* d, void* workspace, size_t workspace_bytes
     // once on more than one workgroup per CU -- with further rounds to come the oldest-first order is the better pipeline
     static const int mode = [] { const char* e = getenv("SM3_EQ_PRIO"); return e ? atoi(e) : 2; }();  // 0 off, 1 always, 2 auto
     const long blocks = (long)c.ntn * c.ntm * (d->mode == MODE_TN ? (long)c.groups * c.splits : c.splits);
+    static const int maxr = [] { const char* e = getenv("SM3_EQ_PRIO_MAXR"); return e ? atoi(e) : 3; }();  // workgroups per CU (A/B aid)
     static const int forms = [] { const char* e = getenv("SM3_EQ_PRIO_FORMS"); return e ? atoi(e) : 6; }();  // bit per d->compute
-    p.eq_prio = ((forms >> d->compute) & 1) && (mode == 1 || (mode == 2 && blocks > kNumCU && blocks <= 3L * kNumCU));
+    p.eq_prio = ((forms >> d->compute) & 1) && (mode == 1 || (mode == 2 && blocks > kNumCU && blocks <= (long)maxr * kNumCU));
   }
 #ifdef SM3_TRACE
   p.trace = g_trace;
