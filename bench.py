@@ -846,14 +846,14 @@ def ops_roofline(us):
     out = {}
 
     def hbm(name, key, nbytes):
-        if key in us:
+        if us.get(key):  # (absent or 0 in the SM3_BENCH_OPS=slice / =full profiling modes)
             gbs = nbytes / (us[key] * 1e-6) / 1e9
             out[name] = dict(bound='hbm', algorithmic_mb=round(nbytes / 1e6, 1), us=us[key], achieved=round(gbs, 1),
                              peak=MI355X_HBM_PEAK_GBS, unit='GB/s', frac=round(gbs / MI355X_HBM_PEAK_GBS, 4),
                              traffic=pmc.get(name, {}).get('hbm_bytes'))
 
     def valu(name, key, pairs, what):
-        if key in us:
+        if us.get(key):
             rate = pairs / (us[key] * 1e-6)
             ipp = pmc.get(name, {}).get('valu_lane_instr_per_pair')
             peak = MI355X_VALU_LANE_OPS / ipp if ipp else None
@@ -879,14 +879,14 @@ def ops_roofline(us):
     valu('nms_rotated_10000', 'nms_rotated_10000', 10000 * 9999 / 2, 'N(N-1)/2 rotated pair tests (mask) + serial sweep')
     valu('nms_rotated_2000', 'nms_rotated_2000', 2000 * 1999 / 2, 'N(N-1)/2 rotated pair tests (mask) + serial sweep')
     valu('nms_8768', 'nms_8768', 8768 * 8767 / 2, 'N(N-1)/2 horizontal pair tests (mask) + serial sweep')
-    if 'deform_conv2d_fwd_2x256x128x128' in us:
+    if us.get('deform_conv2d_fwd_2x256x128x128'):
         fl = 2.0 * 2 * 128 * 128 * 256 * 256 * 9
         t = us['deform_conv2d_fwd_2x256x128x128'] * 1e-6
         out['deform_conv2d_fwd'] = dict(bound='mfma', algorithmic_gflop=round(fl / 1e9, 1), us=round(t * 1e6, 1),
                                         achieved=round(fl / t / 1e12, 2), peak=MI355X_FP32_MFMA_PEAK_TFLOPS,
                                         unit='TFLOP/s', frac=round(fl / t / 1e12 / MI355X_FP32_MFMA_PEAK_TFLOPS, 4),
                                         algorithmic_mb=round(2 * 128 * 128 * (256 + 256 + 18) * 4 / 1e6, 1))
-    if 'deform_conv2d_bwd_2x256x128x128' in us:
+    if us.get('deform_conv2d_bwd_2x256x128x128'):
         fl = 2.0 * 2.0 * 2 * 128 * 128 * 256 * 256 * 9  # input-gradient GEMM + weight-gradient GEMM
         t = us['deform_conv2d_bwd_2x256x128x128'] * 1e-6
         out['deform_conv2d_bwd'] = dict(bound='mfma', algorithmic_gflop=round(fl / 1e9, 1), us=round(t * 1e6, 1),
@@ -1201,8 +1201,8 @@ def main():
     # alone (two kernels sharing the chip would each look slower), which is also what SM3_WGRAD_STREAM=0 + rocprofv3
     # --kernel-trace reports (profiles/).
     from sm3det_amd import backbone_ops as _bops
-    overlap_was = _bops.OVERLAP_WGRAD
-    _bops.OVERLAP_WGRAD = False
+    overlap_was, pair_was = _bops.OVERLAP_WGRAD, _bops.PAIR_DGRAD
+    _bops.OVERLAP_WGRAD, _bops.PAIR_DGRAD = False, 0
     # Three such steps, the one with the smallest summed bracket time is reported: a bracket also holds the host's launch
     # latency whenever the stream runs dry between e0 and the kernel, which a busy host inflates (observed once: 113 us
     # per GEMM launch instead of 103, with an unchanged 19.95 ms graph-replayed step).
@@ -1217,7 +1217,7 @@ def main():
             tot = sum(e0.elapsed_time(e1) for _n, _f, _b, e0, e1 in cand)
             if prof is None or tot < prof[0]:
                 prof = (tot, cand)
-    _bops.OVERLAP_WGRAD = overlap_was
+    _bops.OVERLAP_WGRAD, _bops.PAIR_DGRAD = overlap_was, pair_was
     if rank == 0:
         prof = prof[1]
         for name, flops, nbytes, e0, e1 in prof:

@@ -27,14 +27,19 @@ class _compute:
     """run the enclosed GEMM launches in the arithmetic the forward of this autograd node used (fp32, or fp16 operands
     under sm3det_amd.amp.autocast) -- backward may execute outside the autocast block"""
 
-    def __init__(self, mode):
-        self.mode = mode
+    def __init__(self, mode, pair=None):
+        self.mode, self.pair = mode, pair  # pair: the PAIR_DGRAD level in force when the node's forward ran (see `pairing`)
 
     def __enter__(self):
+        global PAIR_DGRAD
         self.old, LB.COMPUTE = LB.COMPUTE, self.mode
+        self.old_pair = PAIR_DGRAD
+        if self.pair is not None:
+            PAIR_DGRAD = self.pair
 
     def __exit__(self, *exc):
-        LB.COMPUTE = self.old
+        global PAIR_DGRAD
+        LB.COMPUTE, PAIR_DGRAD = self.old, self.old_pair
         return False
 
 
@@ -82,9 +87,61 @@ def _on_side(device, fn):
         return fn()
 
 
+_PAIRED = {}  # device -> a paired launch is outstanding on the side stream
+
+
 def _join_side(device):
-    if OVERLAP_WGRAD:
+    if OVERLAP_WGRAD or _PAIRED.pop(device, False):
         torch.cuda.current_stream(device).wait_stream(_side_stream(device))
+
+
+# SM3_PAIR_DGRAD: concurrent partners for the backward launches.  The input-gradient GEMM of an FFN layer (dh = dy . W2 with
+# GELU', dx = dh . W1) and that layer's weight gradient (dW2 = dy^T . act, dW1 = dh^T . xn) read the same operand and nothing
+# of each other.  Run one after the other each pays its own ramp and tail: a launch ends with CUs holding one or two
+# k-loops (a lone workgroup reaches ~48 % of the matrix pipe, profiles/r06/gemm_trace_eq_prio.txt), from stage 1 on the
+# input gradients are launches of one or two workgroups per CU, and every split-K weight gradient is a single round of 768.
+# Issued INPUT GRADIENT FIRST on this stream and the weight gradient right behind it on the side stream, the second
+# launch's workgroups take the slots the first one leaves empty.  The order matters: the older form (SM3_WGRAD_STREAM=1,
+# weight gradient first) lets the single-round launch occupy every slot and the partner queue behind it -- measured SLOWER
+# than no overlap at all.  Levels (same box, ms per step of the headline workload, profiles/r06/bench_pair_dgrad.txt):
+#   0 off 16.55 | 1 FC1 pair 16.58* | 2 + FC2 pair 15.83 | 3 + depthwise dgrad / wgrad 15.82 | 4 + gate dgrad / wgrad 15.72
+#   (* measured on another box against 16.88 for level 0)
+PAIR_DGRAD = int(os.environ.get('SM3_PAIR_DGRAD', '4'))
+PAIR_MAX_OUTPUTS = int(os.environ.get('SM3_PAIR_MAX_OUTPUTS', 1 << 30))  # (A/B aid: rows x C up to which pairs are formed)
+
+
+class pairing:
+    """``with pairing(level):`` the blocks whose FORWARD runs inside use this SM3_PAIR_DGRAD level in their backward.  The
+    whole-detector step turns it off: replayed from one hipGraph of ~2 500 nodes the cross-stream edges cost more than the
+    pairs gain (56.6 -> 58.0 ms; eager 57.4 -> 57.4), where the backbone step alone gains 0.8 of 16.6 ms."""
+
+    def __init__(self, level):
+        self.level = int(level)
+
+    def __enter__(self):
+        global PAIR_DGRAD
+        self.old, PAIR_DGRAD = PAIR_DGRAD, self.level
+
+    def __exit__(self, *exc):
+        global PAIR_DGRAD
+        PAIR_DGRAD = self.old
+        return False
+
+
+def _paired(device, main_fn, side_fn, outputs, level=1):
+    """-> (main_fn(), side_fn()); both may only read what is already enqueued on the current stream"""
+    if OVERLAP_WGRAD or PAIR_DGRAD < level or outputs > PAIR_MAX_OUTPUTS:
+        r_side = _on_side(device, side_fn)
+        return main_fn(), r_side
+    main, side = torch.cuda.current_stream(device), _side_stream(device)
+    ready = torch.cuda.Event()
+    ready.record(main)
+    r_main = main_fn()
+    side.wait_event(ready)
+    with torch.cuda.stream(side):
+        r_side = side_fn()
+    _PAIRED[device] = True
+    return r_main, r_side
 
 
 # The column reductions of the row kernels' per-workgroup partials produce PARAMETER gradients (d LayerNorm weight / bias,
@@ -426,10 +483,11 @@ def _dw_ln_backward(dxn, dout, x, u, w49, lnw, mean, rstd, B, H, W, C):
     _deferred_reduce(ws, T, C, 2 * C, dwdb, params=(lnw,))  # d(ln weight) | d(ln bias); joined by the caller
     dwb = _zero_slab(50 * C, x).view(50, C)  # [dw49 (49,C); dbias (C)]: zeros from the pass's arena (one fill per pass)
     dw49, dbdw = dwb[:49], dwb[49]
-    _on_side(x.device, lambda: call('dwconv7_bwd_weight_acc', x, du, dw49, dbdw, B, H, W, C,
-                                    nbytes=8.0 * T * C))  # joined by the caller
     dx = _e(T, C, like=x)
-    call('dwconv7_fwd', du, w49, None, dout, dx, B, H, W, C, 1, nbytes=12.0 * T * C)  # flip=1: reversed taps
+    _paired(x.device,
+            lambda: call('dwconv7_fwd', du, w49, None, dout, dx, B, H, W, C, 1, nbytes=12.0 * T * C),  # flip=1: reversed taps
+            lambda: call('dwconv7_bwd_weight_acc', x, du, dw49, dbdw, B, H, W, C, nbytes=8.0 * T * C),
+            T * C, level=3)  # joined by the caller
     return dx, dw49, dbdw, dwdb[0], dwdb[1]
 
 
@@ -448,14 +506,14 @@ class _DenseBlock(Function):
         y, out = _e(T, C, like=x), _e(T, C, like=x)
         gemm(LB.NT, act, w2, out, T, C, Hd, epilogue=LB.EPI_BIAS_SCALE_RES, bias=b2, aux_in=x, aux_out=y,
              gamma=gamma, rowscale=rs, rows_per_scale=H * W)
-        ctx.compute = LB.COMPUTE
+        ctx.compute, ctx.pair = LB.COMPUTE, PAIR_DGRAD
         ctx.save_for_backward(x, u, mean, rstd, xn, hpre, act, y, w49, lnw, w1, w2, gamma, rs)
         ctx.meta = (B, H, W)
         return out
 
     @staticmethod
     def backward(ctx, *grads):
-        with _compute(ctx.compute):
+        with _compute(ctx.compute, ctx.pair):
             return _DenseBlock._backward_impl(ctx, *grads)
 
     @staticmethod
@@ -472,12 +530,12 @@ class _DenseBlock(Function):
         _deferred_reduce(ws, T, C, 2 * C, dgdb, params=(gamma,))
         dgamma, db2 = dgdb[0], dgdb[1]
         pw1, pw2 = getattr(ctx, 'wparams', (None, None))
-        dw2 = _on_side(dev, lambda: _tn(dy, act, C, Hd, T, out=_bucket_out(pw2, C, Hd)))
         dh, db1 = _e(T, Hd, like=x, dtype=hpre.dtype), _e(Hd, like=x)
-        gemm(LB.NN, dy, w2, dh, T, Hd, C, epilogue=LB.EPI_GELU_BWD, aux_in=hpre, colsum_out=db1)
-        dw1 = _on_side(dev, lambda: _tn(dh, xn, Hd, C, T, out=_bucket_out(pw1, Hd, C)))
+        _, dw2 = _paired(dev, lambda: gemm(LB.NN, dy, w2, dh, T, Hd, C, epilogue=LB.EPI_GELU_BWD, aux_in=hpre, colsum_out=db1),
+                         lambda: _tn(dy, act, C, Hd, T, out=_bucket_out(pw2, C, Hd)), T * C, level=2)
         dxn = _e(T, C, like=x)  # not dy's buffer: the side-stream wgrad may still be reading dy
-        gemm(LB.NN, dh, w1, dxn, T, C, Hd)
+        _, dw1 = _paired(dev, lambda: gemm(LB.NN, dh, w1, dxn, T, C, Hd),
+                         lambda: _tn(dh, xn, Hd, C, T, out=_bucket_out(pw1, Hd, C)), T * C)
         dx, dw49, dbdw, dlnw, dlnb = _dw_ln_backward(dxn, dout, x, u, w49, lnw, mean, rstd, B, H, W, C)
         _join_side(dev)
         return dx, dw49, dbdw, dlnw, dlnb, dw1, db1, dw2, db2, dgamma, None, None, None, None, None
@@ -573,13 +631,14 @@ class _MoEBlock(Function):
                               token_slot, xslot, hpre, act, yslot, w49, lnw, wcat, snorm, scale, w1, w2, gamma, rs,
                               noise, sim, temp, tot)
         ctx.meta = (B, H, W, P, k, train, float(clamp_max), float(loss_coef))
+        ctx.pair = PAIR_DGRAD
         ctx.mark_non_differentiable(tot, offsets, top_idx)
         ctx.set_materialize_grads(False)  # else autograd fills a zero tensor per non-differentiable output per block
         return out, loss.reshape(()), tot, offsets, top_idx
 
     @staticmethod
     def backward(ctx, *grads):
-        with _compute(ctx.compute):
+        with _compute(ctx.compute, ctx.pair):
             return _MoEBlock._backward_impl(ctx, *grads)
 
     @staticmethod
@@ -611,14 +670,15 @@ class _MoEBlock(Function):
         db2 = _e(E, C, like=x)
 
         pw1, pw2 = getattr(ctx, 'wparams', (None, None))
-        dw2 = _on_side(dev, lambda: _tn_bias(dyslot, act, C, Hd, S, db2, out=_bucket_out(pw2, E, C, Hd), offsets=offsets,
-                                             num_groups=E))
         dh, db1 = _e(S, Hd, like=x, dtype=hpre.dtype), _e(E, Hd, like=x)
-        gemm(LB.NN, dyslot, w2, dh, S, Hd, C, epilogue=LB.EPI_GELU_BWD, aux_in=hpre, offsets=offsets, num_groups=E,
-             colsum_out=db1)
-        dw1 = _on_side(dev, lambda: _tn(dh, xslot, Hd, C, S, out=_bucket_out(pw1, E, Hd, C), offsets=offsets, num_groups=E))
+        _, dw2 = _paired(dev, lambda: gemm(LB.NN, dyslot, w2, dh, S, Hd, C, epilogue=LB.EPI_GELU_BWD, aux_in=hpre,
+                                           offsets=offsets, num_groups=E, colsum_out=db1),
+                         lambda: _tn_bias(dyslot, act, C, Hd, S, db2, out=_bucket_out(pw2, E, C, Hd), offsets=offsets,
+                                          num_groups=E), S * C, level=2)
         dxslot = _e(S, C, like=x)  # not dyslot's buffer: the side-stream wgrad may still be reading it
-        gemm(LB.NN, dh, w1, dxslot, S, C, Hd, offsets=offsets, num_groups=E)
+        _, dw1 = _paired(dev, lambda: gemm(LB.NN, dh, w1, dxslot, S, C, Hd, offsets=offsets, num_groups=E),
+                         lambda: _tn(dh, xslot, Hd, C, S, out=_bucket_out(pw1, E, Hd, C), offsets=offsets, num_groups=E),
+                         S * C)
         # router backward
         nblk = _lib.lib().sm3_moe_router_partial_rows(T)
         dhcat, dcn, ds_part = _e(T, PC, like=x), _e(T, E, like=x), _e(nblk, like=x, dtype=torch.float64)
@@ -652,10 +712,12 @@ class _MoEBlock(Function):
             dsn = dsn4 if E4 == E else dsn4[:, :E].contiguous()
             call('moe_gate_prep_bwd', dwcat, dbcat, dsn, ds_part, nblk, sim.contiguous(), temp, clamp_max, P, C, E,
                  dwp, dbp, dwn, dsim, dtemp)
-        _on_side(dev, gate_wgrad)
         dxn = _e(T, C, like=x)
-        gemm(LB.NN, dhcat, wcat, dxn, T, C, PC)
-        call('moe_gather_add', dxslot, token_slot, dxn, T, C, k, 1, nbytes=4.0 * (k + 2) * T * C)
+
+        def gate_dgrad():
+            gemm(LB.NN, dhcat, wcat, dxn, T, C, PC)
+            call('moe_gather_add', dxslot, token_slot, dxn, T, C, k, 1, nbytes=4.0 * (k + 2) * T * C)
+        _paired(dev, gate_dgrad, gate_wgrad, T * C, level=4)
         dx, dw49, dbdw, dlnw, dlnb = _dw_ln_backward(dxn, dout, x, u, w49, lnw, mean, rstd, B, H, W, C)
         _join_side(dev)
         return (dx, dw49, dbdw, dlnw, dlnb, dwp, dbp, dwn, dsim, None if dtemp is None else dtemp.reshape(temp.shape),

@@ -16,11 +16,15 @@ truths per image, so a whole training step can be captured into hipGraphs (``ben
 The multi-task reweighting branches (``multi_tasks_reweight='uncertainty' | 'dwa'``, :306-338) are restated too; no
 SM3Det config of BASELINE.json enables them.
 """
+import os
+
 import torch
 import torch.nn as nn
 
-from . import h2d
+from . import backbone_ops, h2d
 from .registry import MODELS
+
+_PAIR_IN_DETECTOR = int(os.environ.get('SM3_PAIR_DGRAD_DETECTOR', '0'))
 
 
 @MODELS.register_module()
@@ -93,7 +97,10 @@ class TriSourceDetector(nn.Module):
     # ---- features ------------------------------------------------------------------------------------------------
     def extract_feat(self, batch_inputs, datasets, is_train=False):
         """:141-173.  batch_inputs: list of per-source image stacks (train) or one tensor (test)."""
-        x = self.backbone(batch_inputs, datasets)
+        # (SM3_PAIR_DGRAD_DETECTOR: concurrent backward partners inside the backbone, off in the whole-detector step --
+        # measured slower under one large hipGraph, see backbone_ops.pairing)
+        with backbone_ops.pairing(_PAIR_IN_DETECTOR):
+            x = self.backbone(batch_inputs, datasets)
         loss = None
         if isinstance(x, tuple) and len(x) == 2 and not torch.is_tensor(x[0]):
             x, loss = x
