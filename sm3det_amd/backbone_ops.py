@@ -131,6 +131,9 @@ def _join_side(device, force=False):
 # than no overlap at all.  Levels (same box, ms per step of the headline workload, profiles/r06/bench_pair_dgrad.txt):
 #   0 off 16.55 | 1 FC1 pair 16.58* | 2 + FC2 pair 15.83 | 3 + depthwise dgrad / wgrad 15.82 | 4 + gate dgrad / wgrad 15.72
 #   (* measured on another box against 16.88 for level 0)
+# Not kept (measured): the same idea in the FORWARD pass -- the two halves of the batch as FC1(a) | FC2(a) beside FC1(b) | FC2(b)
+# for the stage-2 / 3 dense blocks, whose FC2 is a launch of one workgroup per CU -- 15.59 -> 15.75 ms: half-size launches and two
+# more graph edges per block cost more than the fill gains.
 PAIR_DGRAD = int(os.environ.get('SM3_PAIR_DGRAD', '4'))
 PAIR_MAX_OUTPUTS = int(os.environ.get('SM3_PAIR_MAX_OUTPUTS', 1 << 30))  # (A/B aid: rows x C up to which pairs are formed)
 
