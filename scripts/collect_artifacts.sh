@@ -27,12 +27,13 @@ profile() {  # profile <suffix> <bench args...>: stats (serial [+ overlap]) and 
   local MODES="serial"; [ -z "$SFX" ] && MODES="serial overlap"
   for MODE in $MODES; do
     rm -rf /tmp/prof_$MODE
-    if [ $MODE = serial ]; then export SM3_WGRAD_STREAM=0; else export SM3_WGRAD_STREAM=1; fi
+    # serial: no concurrent partners (per-kernel durations of each kernel ALONE); overlap: the production schedule (SM3_PAIR_DGRAD default)
+    if [ $MODE = serial ]; then export SM3_PAIR_DGRAD=0; else unset SM3_PAIR_DGRAD; fi
     rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$MODE -o p -- python $R/bench.py "$@" --steps 6 --warmup 2 --no-cpu-baseline --no-ops > $O/${TAG}_rocprof_$MODE$SFX.log 2>&1
     find /tmp/prof_$MODE -name "*kernel_stats.csv" -exec cp {} $O/${TAG}_kernel_stats_$MODE$SFX.csv \;
     grep -h '^{' $O/${TAG}_rocprof_$MODE$SFX.log | tail -1 > $O/${TAG}_bench_under_rocprof_$MODE$SFX.json
   done
-  export SM3_WGRAD_STREAM=0
+  export SM3_PAIR_DGRAD=0
   for C in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/pmc_$C
     rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmc_$C -o p -- python $R/bench.py "$@" --steps 2 --warmup 1 --no-cpu-baseline --no-ops --no-graph > $O/${TAG}_pmc_$C$SFX.log 2>&1
@@ -48,9 +49,12 @@ profile() {  # profile <suffix> <bench args...>: stats (serial [+ overlap]) and 
   rm -rf /tmp/pmc_tcc
   rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum --kernel-trace --output-format csv -d /tmp/pmc_tcc -o p -- python $R/bench.py "$@" --steps 2 --warmup 1 --no-cpu-baseline --no-ops --no-graph > $O/${TAG}_pmc_tcc$SFX.log 2>&1
   D=$(dirname $(find /tmp/pmc_tcc -name "*counter_collection.csv" | head -1)); python $R/scripts/pmc_summary.py $D > $O/${TAG}_pmc_tcc_top$SFX.txt 2>&1; cp $D/summary.json $O/${TAG}_pmc_tcc_summary$SFX.json
-  unset SM3_WGRAD_STREAM
+  unset SM3_PAIR_DGRAD
 }
 profile ""
+# idle time / concurrency of one replayed step of the production schedule
+rm -rf /tmp/kt; SM3_BENCH_NATIVE=0 rocprofv3 --kernel-trace --output-format csv -d /tmp/kt -o p -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-ops > $O/${TAG}_kt.log 2>&1
+python $R/scripts/graph_gaps.py /tmp/kt > $O/${TAG}_graph_gaps.txt 2>&1
 # the full detector alone (the third named workload): kernel statistics of SM3_BENCH_OPS=full
 rm -rf /tmp/prof_full
 SM3_BENCH_OPS=full rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_full -o p -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/${TAG}_rocprof_full.log 2>&1

@@ -15,7 +15,7 @@ done
 for f in kernel_stats_serial kernel_stats_overlap kernel_stats_serial_amp full_model_kernel_stats; do
   [ -s $G/${TAG}_$f.csv ] && cp $G/${TAG}_$f.csv $P/$f.csv
 done
-for f in pmc_FETCH_SIZE_top pmc_WRITE_SIZE_top mfma_bench_top pmc_FETCH_SIZE_top_amp pmc_WRITE_SIZE_top_amp mfma_bench_top_amp pmc_tcc_top pmc_tcc_top_amp summary; do
+for f in pmc_FETCH_SIZE_top pmc_WRITE_SIZE_top mfma_bench_top pmc_FETCH_SIZE_top_amp pmc_WRITE_SIZE_top_amp mfma_bench_top_amp pmc_tcc_top pmc_tcc_top_amp summary graph_gaps; do
   [ -s $G/${TAG}_$f.txt ] && cp $G/${TAG}_$f.txt $P/$f.txt
 done
 for f in $G/fullsize_*.json; do [ -s $f ] && cp $f $P/; done
