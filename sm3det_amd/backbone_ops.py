@@ -131,6 +131,8 @@ def _join_side(device, force=False):
 # than no overlap at all.  Levels (same box, ms per step of the headline workload, profiles/r06/bench_pair_dgrad.txt):
 #   0 off 16.55 | 1 FC1 pair 16.58* | 2 + FC2 pair 15.83 | 3 + depthwise dgrad / wgrad 15.82 | 4 + gate dgrad / wgrad 15.72
 #   (* measured on another box against 16.88 for level 0)
+# Not kept (measured): two / three side streams that the pairs rotate over -- 15.69 -> 16.44 / 16.76 ms (more than two GEMMs
+# sharing the chip lose more than the fill gains).
 # Not kept (measured): the same idea in the FORWARD pass -- the two halves of the batch as FC1(a) | FC2(a) beside FC1(b) | FC2(b)
 # for the stage-2 / 3 dense blocks, whose FC2 is a launch of one workgroup per CU -- 15.59 -> 15.75 ms: half-size launches and two
 # more graph edges per block cost more than the fill gains.
