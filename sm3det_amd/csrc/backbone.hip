@@ -608,7 +608,9 @@ __global__ __launch_bounds__(256) void moe_combine_bwd_kernel(
     }
     // all k slot indices and gates first, then all k x NV expert-output vectors (independent requests: one round trip for
     // the indices, one for the vectors -- the j-loop used to chain index -> vector -> store per expert), then the math
-    constexpr int KB = 4;  // experts per batch (top-k of the SM3Det configs: 2)
+    // experts per batch (top-k of the SM3Det configs: 2).  The widest rows (NV > 4: C > 1024, no SM3Det stage) take one expert
+    // at a time: four experts x eight vectors were 128 registers of look-ahead, 141 of them spilled
+    constexpr int KB = NV > 4 ? 1 : 4;
     for (int j0 = 0; j0 < k; j0 += KB) {
       float g[KB];
       long sl[KB];

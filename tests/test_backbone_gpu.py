@@ -461,3 +461,41 @@ def test_second_backward_without_zero_grad_accumulates_with_bucket_slices_attach
     run()  # second pass WITHOUT dropping the gradients: old + new
     for n, p in net.named_parameters():
         assert rel_err(p.grad, 2 * once[n]) < 1e-5, (n, rel_err(p.grad, 2 * once[n]))
+
+
+@pytest.mark.parametrize('C,k', [(96, 2), (384, 2), (768, 3), (1024, 2), (1536, 2), (2048, 3)])
+def test_moe_combine_kernels_every_row_width_vs_fp64(C, k):
+    """moe_combine_fwd / moe_combine_bwd against an fp64 torch restatement for every vector-count variant of the row
+    dispatch (C = 2048 is the <64, 8> instantiation that spilled 141 VGPRs until round 6; no SM3Det stage is that wide).
+    Reference semantics: MoE_layer.forward's combine, convnext_moe.py:286-293 (`gates x expert outputs`, layer scale,
+    drop-path row scale, shortcut)."""
+    import torch
+    from sm3det_amd import _lib_backbone as LB
+    T, HW = 1024, 512
+    g = torch.Generator().manual_seed(C + k)
+    S = T * k
+    perm = torch.randperm(S, generator=g).to(torch.int32).reshape(T, k)  # token_slot: a permutation of the slots
+    yslot = torch.randn(S, C, generator=g)
+    gates = torch.rand(T, k, generator=g)
+    x = torch.randn(T, C, generator=g)
+    gamma = torch.randn(C, generator=g)
+    rs = torch.tensor([1.0, 0.0]) / 0.9  # one image dropped by drop-path
+    dout = torch.randn(T, C, generator=g)
+    dev = lambda t: t.cuda().contiguous()  # noqa: E731
+    ys, ts, gt, xd, gm, rsd, dd = map(dev, (yslot, perm, gates, x, gamma, rs, dout))
+    out = torch.empty(T, C, device='cuda')
+    LB.call('moe_combine_fwd', ys, ts, gt, xd, gm, rsd, HW, out, T, C, k)
+    row_rs = rs.double().repeat_interleave(HW)[:, None]
+    mix = (gates.double()[:, :, None] * yslot.double()[perm.long()]).sum(1)  # (T, C)
+    ref = x.double() + gamma.double() * row_rs * mix
+    assert float((out.cpu().double() - ref).abs().max()) < 1e-5 * float(ref.abs().max())
+    dys, dg, dgam = torch.full((S, C), float('nan'), device='cuda'), torch.empty(T, k, device='cuda'), torch.empty(C, device='cuda')
+    ws, nb = LB.row_ws(C, xd)
+    LB.call('moe_combine_bwd', dd, ys, ts, gt, gm, rsd, HW, dys, dg, dgam, T, C, k, ws, nb)
+    d = gamma.double() * row_rs * dout.double()  # (T, C)
+    ref_dys = torch.zeros(S, C, dtype=torch.float64)
+    ref_dys[perm.long().reshape(-1)] = (gates.double()[:, :, None] * d[:, None, :]).reshape(S, C)
+    ref_dg = (d[:, None, :] * yslot.double()[perm.long()]).sum(2)
+    ref_dgam = (row_rs * dout.double() * mix).sum(0)
+    for got, want, tol in ((dys, ref_dys, 1e-6), (dg, ref_dg, 1e-5), (dgam, ref_dgam, 1e-4)):
+        assert float((got.cpu().double() - want).abs().max()) <= tol * max(float(want.abs().max()), 1e-12)
