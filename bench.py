@@ -1304,12 +1304,17 @@ def main():
                        'gemm_arith': ('fp16 operands, fp32 accumulate (AMP)' if args.amp else
                                       ('bf16x3: fp32 tensors; each operand element split exactly into three bf16 pieces, six bf16 MFMA '
                                        'products (i+j<=2) accumulated in fp32 -- fp32-equivalent (error vs fp64 <= the native fp32 '
-                                       "kernel's x1.5 per shape: profiles/r05/gemm_b3_eval.txt); SM3_GEMM_ARITH=f32 runs the native "
+                                       "kernel's x1.5 per shape: profiles/r06/gemm_b3_sweep.txt); SM3_GEMM_ARITH=f32 runs the native "
                                        'v_mfma_f32_32x32x2_f32 form (value_native_f32_mfma)' if LB.ARITH32 == 2 else
                                        'native fp32 MFMA (v_mfma_f32_32x32x2_f32)')),
                        'global_batch': world * BATCH, 'resolution': RES, 'parallelism': f'dp{world}',
                        'grad_buckets': reducer.num_buckets, 'hip_graph': bool(use_graph),
                        'wgrad_side_stream': bool(overlap_was), 'split_backward': bool(split and use_graph),
+                       # concurrent backward partners (backbone_ops._paired): input-gradient GEMM on the main stream, its layer's
+                       # weight gradient right behind it on a side stream; level 4 = FC2, FC1, depthwise and gate pairs; the side
+                       # stream is joined once per backward pass.  `roofline` is measured with the pairs OFF (each kernel alone).
+                       'backward_pairs_level': int(pair_was), 'side_stream_joined_per': ('pass' if _bops.DEFER_JOIN else 'block'),
+                       'gemm_eq_prio': os.environ.get('SM3_EQ_PRIO', '2 (auto: single-round launches)'),
                        'backward_segments': (n_seg if (split and use_graph) else 1),
                        'dist_backend': (backend if multi else None), 'collective_avg': bool(reducer._avg),
                        # share of the gradient bytes the backward kernels wrote straight into the bucket slices (no pack copy)
