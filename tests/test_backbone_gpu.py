@@ -278,6 +278,12 @@ def test_dwconv7_fwd_and_grads(B, H, W, C):
     LB.call('dwconv7_bwd_weight', x, go, dw49, db, B, H, W, C)
     assert rel_err(dw49.t().reshape(C, 1, 7, 7), wr.grad) < 1e-4
     assert rel_err(db, br.grad) < 1e-4
+    # the accumulating form (round 6: the buffers of a whole backward pass come zero-filled from ONE arena): adds to what is there
+    pre_w, pre_b = torch.randn(49, C, device='cuda'), torch.randn(C, device='cuda')
+    acc_w, acc_b = pre_w.clone(), pre_b.clone()
+    LB.call('dwconv7_bwd_weight_acc', x, go, acc_w, acc_b, B, H, W, C)
+    assert rel_err((acc_w - pre_w).t().reshape(C, 1, 7, 7), wr.grad) < 1e-4
+    assert rel_err(acc_b - pre_b, br.grad) < 1e-4
 
 
 def test_stem_patchify_linear_equals_conv():
