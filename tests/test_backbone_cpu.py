@@ -77,3 +77,32 @@ def test_collect_by_source_matches_reference_gather_logic():
     got = collect_by_source(data, ['sar', 'rgb', 'ifr'])
     assert [t.tolist() for t in got['sar']] == [[0.0, 0.0], [1.0, 1.0]]
     assert len(got['rgb']) == 1 and got['ifr'] == ['meta']
+
+
+def test_backward_schedule_switches_host_logic():
+    """host side of the concurrent-backward-partner schedule (backbone_ops): the `pairing` context sets and restores the
+    level, `_compute` carries a node's level into its backward, nothing is deferred outside a backward pass, and the per-level
+    stream helper of the heads degrades to the plain loop off the GPU"""
+    from sm3det_amd import backbone_ops as B, level_streams
+    from sm3det_amd import _lib_backbone as LB
+    base = B.PAIR_DGRAD
+    with B.pairing(0):
+        assert B.PAIR_DGRAD == 0
+        with B.pairing(3):
+            assert B.PAIR_DGRAD == 3
+        assert B.PAIR_DGRAD == 0
+    assert B.PAIR_DGRAD == base
+    mode = LB.COMPUTE
+    with B._compute(mode, pair=2):  # a node whose forward ran at level 2 runs its backward at level 2 ...
+        assert B.PAIR_DGRAD == 2
+    with B._compute(mode):          # ... and one that recorded nothing leaves the switch alone
+        assert B.PAIR_DGRAD == base
+    assert B.PAIR_DGRAD == base and LB.COMPUTE == mode
+    assert not B._callback_armed(torch.device('cpu'))  # no backward pass running: a join can never be deferred
+    # below the requested level / off the GPU a pair is just the two calls (weight gradient first, as before round 6)
+    order = []
+    with B.pairing(0):
+        r = B._paired(torch.device('cpu'), lambda: order.append('main') or 'm', lambda: order.append('side') or 's', 1)
+    assert r == ('m', 's') and order == ['side', 'main']
+    outs = level_streams.map_levels(lambda x, s: x * s, [torch.ones(2), torch.ones(3)], [2.0, 3.0])
+    assert [float(o.sum()) for o in outs] == [4.0, 9.0]
